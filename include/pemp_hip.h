@@ -1,0 +1,148 @@
+/*
+ * pemp_hip.h -- C ABI of libpemp_hip.so: the MI355X (gfx950) kernels of the PEMP
+ * prototype-matching hot path.
+ *
+ * The reference (Jarvis73/PEMP) has no native/FFI interface: its hot path is a chain of stock
+ * ATen ops issued from networks/{backbones,pemp_stage1,pemp_stage2,baseline}.py.  Each entry
+ * point below names the reference call site(s) (file:line, relative to the reference root) whose
+ * arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 unless the name/type says otherwise;
+ *  - activations are NHWC ("pixel-major": [N][H][W][C], C contiguous) with an explicit per-pixel
+ *    stride `ld*` in elements, so a kernel can read/write a channel slice of a wider buffer;
+ *  - conv weights are "KRSC": [Cout][KH][KW][Cin], Cin contiguous (the GEMM K axis);
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *  - no hidden allocation, no global mutable state; re-entrant across streams and devices;
+ *  - return value: 0 ok, <0 invalid argument (see pemp_last_error()), >0 a hipError_t.
+ */
+#ifndef PEMP_HIP_H
+#define PEMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEMP_ABI_VERSION 1
+
+/* flags for pemp_conv_desc.flags */
+#define PEMP_CONV_RELU 1u          /* y = max(y, 0) after affine (+ residual)            */
+#define PEMP_CONV_SHIFT_PER_IMAGE 2u /* shift is [N][Cout] instead of [Cout]              */
+#define PEMP_CONV_STEM4 4u         /* input is NHWC4, K axis = taps x 4 channels (7x7 stem) */
+
+typedef struct pemp_conv_desc {
+    int32_t N, H, W;        /* input images, input spatial size                                  */
+    int32_t Cin, ldx;       /* input channels read, input per-pixel stride (>= Cin)              */
+    int32_t Ho, Wo;         /* output spatial size (caller computes; checked)                    */
+    int32_t Cout, ldy;      /* output channels, output per-pixel stride (>= Cout)                */
+    int32_t KH, KW;         /* kernel size                                                       */
+    int32_t stride, pad, dil;
+    int32_t ldr;            /* residual per-pixel stride (ignored when residual == NULL)         */
+    int32_t Kpad;           /* weight row length in floats (>= KH*KW*Cin, multiple of 32)        */
+    uint32_t flags;
+    int32_t tile;           /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile           */
+} pemp_conv_desc;
+
+const char* pemp_last_error(void);
+int pemp_abi_version(void);
+
+/* Convolution + per-channel affine (+ residual) (+ ReLU) as one implicit GEMM on
+ * v_mfma_f32_32x32x2_f32:   y[n,ho,wo,co] = act( scale[co] * sum_{kh,kw,ci} x[...] * w[co,kh,kw,ci]
+ *                                               + shift[co] (+ residual[n,ho,wo,co]) )
+ * scale == NULL means 1, shift == NULL means 0.
+ * Replaces nn.Conv2d + nn.BatchNorm2d(eval) + ReLU + residual add:
+ *   networks/backbones.py:47-52,66-75 (BottleNeck), :89-91 (stem), :110-111 (downsample),
+ *   :330-357,366 (ASPPV2 convs + layer6), :281-305,319 (ASPP), :375-397 (VGG16);
+ *   networks/pemp_stage1.py:74,77 (purifier); networks/baseline.py:61 (projection).        */
+int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y,
+                         const float* scale, const float* shift, const float* residual,
+                         void* stream);
+
+/* [N,3,H,W] image (+ optional [N,1,H,W] prior; NULL -> 0) -> NHWC4 [N,H,W,4].
+ * Replaces torch.cat/view at networks/pemp_stage1.py:139, pemp_stage2.py:130-138.          */
+int pemp_pack_input_nhwc4_f32(const float* img, const float* prior, float* out,
+                              int N, int H, int W, void* stream);
+
+/* nn.MaxPool2d(k, s, p, ceil_mode) on NHWC: networks/backbones.py:92 (3/2/1 ceil), :378-392.
+ * Ho/Wo are given by the caller (checked against the formula).                              */
+int pemp_maxpool2d_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int ldx,
+                            int Ho, int Wo, int ldy, int k, int s, int p, void* stream);
+
+/* F.adaptive_avg_pool2d(x,(1,1)) on NHWC: y[n][c] = mean_i x[n][i][c]
+ * (networks/backbones.py:311,360).                                                          */
+int pemp_global_avgpool_nhwc_f32(const float* x, float* y, int N, int HW, int C, int ldx,
+                                 void* stream);
+
+/* y[m][c] = x[m][c]*scale[c] + shift[c] for `nb` (scale,shift,y) triples sharing one x
+ * (the BatchNorm that PRECEDES each ASPPV2 branch conv: networks/backbones.py:328,334,340,346,352). */
+int pemp_channel_affine_multi_f32(const float* x, int ldx, int M, int C, int nb,
+                                  const float* const* scale, const float* const* shift,
+                                  float* const* y, const int* ldy, void* stream);
+
+/* Meta-prototype module, steps (i)-(v) of networks/pemp_stage1.py:201-213 (= pemp_stage2.py:170-186):
+ * soft-assign every support pixel to the p fg / p bg centres, masked, and pool.
+ *   feat   [B*S][n][ldf] support features (NHWC, c channels), n = h*w
+ *   mask   [B*S][2][H][W] full-resolution support mask (ch0 fg, ch1 bg); resized on the fly with
+ *          F.interpolate(..., mode="nearest") semantics (pemp_stage1.py:147)
+ *   ctr    [c][2p] learnable centres (pemp_stage1.py:104-105)
+ *   protos [B][2p][c] out: row j<p = fg prototype j, row p+j = bg prototype j (mean over S)
+ *   ws     workspace of pemp_mpm_workspace_bytes() bytes                                     */
+size_t pemp_mpm_workspace_bytes(int B, int S, int n, int c, int p);
+int pemp_mpm_protos_f32(const float* feat, int ldf, const float* mask, const float* ctr,
+                        float* protos, void* ws, size_t ws_bytes,
+                        int B, int S, int h, int w, int H, int W, int c, int p, void* stream);
+
+/* Plain masked average pooling (protos == 0 branch, networks/pemp_stage1.py:223-227) when
+ * full_res == 0, and the Baseline form over bilinearly upsampled features
+ * (networks/baseline.py:100-110) when full_res == 1 (computed through the adjoint of the
+ * align_corners=True interpolation, never materialising the upsampled tensor).
+ *   protos [B][2][c] out: row 0 = fg, row 1 = bg                                             */
+size_t pemp_map_workspace_bytes(int B, int S, int n, int c);
+int pemp_masked_avg_pool_f32(const float* feat, int ldf, const float* mask, float* protos,
+                             void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W,
+                             int c, int full_res, void* stream);
+
+/* F.cosine_similarity(qry, proto) * dist_scalar for every prototype, max over the p prototypes
+ * of each group, stacked (bg, fg): networks/pemp_stage1.py:214-215,256-260.
+ *   qry    [B][n][ldf] query features (Q == 1, as the reference's broadcasting requires)
+ *   protos [B][2p][c]  (layout of pemp_mpm_protos_f32 / pemp_masked_avg_pool_f32 with p = 1)
+ *   pred   [B][2][n]   out, ch0 = bg, ch1 = fg
+ *   resp   [B][n] uint8 out or NULL: response index of pemp_stage1.py:217-222 (0..2p-1)      */
+int pemp_cosine_proto_max_f32(const float* qry, int ldf, const float* protos, float* pred,
+                              uint8_t* resp, int B, int n, int c, int p, float dist_scalar,
+                              void* stream);
+
+/* F.interpolate(pred, (Ho,Wo), "bilinear", align_corners=True) -> logits [B][2][Ho][Wo]
+ * (networks/pemp_stage1.py:157,162; baseline.py:117).                                        */
+int pemp_upsample_bilinear_ac_f32(const float* pred, float* out, int B, int C, int h, int w,
+                                  int Ho, int Wo, void* stream);
+
+/* F.interpolate(resp.float(), (Ho,Wo), "nearest").long() (networks/pemp_stage1.py:158-159).   */
+int pemp_upsample_nearest_u8_i64(const uint8_t* resp, int64_t* out, int B, int h, int w,
+                                 int Ho, int Wo, void* stream);
+
+/* The tail of Evaluator.test_step fused (entry/pemp_stage1.py:48-53 + core/metrics.py:9-23):
+ * upsample (as above) + argmax over the 2 classes + CrossEntropyLoss(ignore_index=255) partial
+ * sums + FewShotMetric tp/fp/fn for class rows {bg, fg}.
+ *   target int64 [B][Ho][Wo]; pred_out uint8 [B][Ho][Wo];
+ *   stats  double [B][8] out: {ce_sum, n_valid, tp_bg, fp_bg, fn_bg, tp_fg, fp_fg, fn_fg}
+ *   logits_out [B][2][Ho][Wo] or NULL.                                                       */
+size_t pemp_eval_tail_workspace_bytes(int B, int Ho, int Wo);
+int pemp_eval_tail_f32(const float* pred, const int64_t* target, uint8_t* pred_out,
+                       float* logits_out, double* stats, void* ws, size_t ws_bytes,
+                       int B, int h, int w, int Ho, int Wo, void* stream);
+
+/* ResNetCM.comm statistics (networks/backbones.py:208-216): mask' = max_pool2d(mask,3,stride,1);
+ * mean over ALL pixels and max over pixels of x*mask' per image and channel.
+ *   x [N][Hx*Wx][ldx], mask_in [N][Hm][Wm], mask_out [N][Hx][Wx], stat [N][2][C] (mean, max)  */
+int pemp_cm_reduce_f32(const float* x, int ldx, const float* mask_in, float* mask_out, float* stat,
+                       int N, int Hm, int Wm, int Hx, int Wx, int C, int stride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEMP_HIP_H */

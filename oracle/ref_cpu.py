@@ -1,0 +1,327 @@
+"""ORACLE -- test infrastructure, not product code.
+
+CPU restatement (plain torch fp32 ops, reference op order) of the PEMP prototype-matching hot
+path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product path (``pemp_amd``) never does and fails loudly without its HIP
+library.
+
+Pinning: the reference's own tests hold no golden vector for this arithmetic, so
+the restatement is pinned by outputs of the reference itself, produced in the build container by
+``tests/golden/make_golden.py`` (imports /root/reference/networks/*.py on CPU) and committed under
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this file against them.
+
+Every function cites the reference lines it restates (paths relative to the reference root).
+All functions are functional: weights come in as a ``{state_dict key: tensor}`` mapping using
+the reference's key names.  Eval-mode semantics only (BatchNorm uses running
+statistics, DropBlock/Dropout are identities) -- that is what the parity configs exercise.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+
+
+# ------------------------------------------------------------------------------------------
+# building blocks
+# ------------------------------------------------------------------------------------------
+def _bn(x, sd, p):
+    """nn.BatchNorm2d in eval mode (networks/backbones.py:48-52,90,111,328)."""
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS)
+
+
+def _conv(x, sd, p, stride=1, padding=0, dilation=1):
+    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, padding, dilation)
+
+
+def bottleneck(x, sd, p, stride, dilation, downsample):
+    """BottleNeck.forward, networks/backbones.py:64-77 (stride sits on conv1, :47)."""
+    out = F.relu(_bn(_conv(x, sd, p + ".conv1", stride=stride), sd, p + ".bn1"))
+    out = F.relu(_bn(_conv(out, sd, p + ".conv2", padding=dilation, dilation=dilation), sd, p + ".bn2"))
+    out = _bn(_conv(out, sd, p + ".conv3"), sd, p + ".bn3")
+    if downsample:
+        res = _bn(_conv(x, sd, p + ".downsample.0", stride=stride), sd, p + ".downsample.1")
+    else:
+        res = x
+    return F.relu(out + res)
+
+
+_LAYER_CFG = {  # name: (stride, dilation) -- networks/backbones.py:97-99
+    "layer1": (1, 1), "layer2": (2, 1), "layer3": (1, 2),
+}
+
+
+def _res_layer(x, sd, p, name, blocks):
+    stride, dil = _LAYER_CFG[name]
+    # block 0 always has a downsample in layers 1-3 (channel change / stride / dilation, :108)
+    x = bottleneck(x, sd, f"{p}.{name}.0", stride, dil, True)
+    for i in range(1, blocks):
+        x = bottleneck(x, sd, f"{p}.{name}.{i}", 1, dil, False)
+    return x
+
+
+def resnet_stem(x, sd, p):
+    """conv1 7x7 s2 p3 -> bn -> relu -> maxpool 3/2/1 ceil_mode (backbones.py:89-92,125)."""
+    x = F.relu(_bn(_conv(x, sd, p + ".conv1", stride=2, padding=3), sd, p + ".bn1"))
+    return F.max_pool2d(x, 3, 2, 1, ceil_mode=True)
+
+
+def resnet(x, sd, p, layers=(3, 4, 6)):
+    """ResNet.forward with ret_features=False (networks/backbones.py:124-136)."""
+    x = resnet_stem(x, sd, p)
+    for name, n in zip(("layer1", "layer2", "layer3"), layers):
+        x = _res_layer(x, sd, p, name, n)
+    return x
+
+
+def _comm(x, mask, sd, lin, stride, spq):
+    """ResNetCM.comm (networks/backbones.py:208-222)."""
+    mask = F.max_pool2d(mask, 3, stride, 1)
+    masked = (x * mask).view(x.shape[0], x.shape[1], -1)
+    mean = masked.mean(dim=-1).view(x.shape[0] // spq, spq, -1).mean(dim=1)
+    mx = masked.max(dim=-1)[0].view(x.shape[0] // spq, spq, -1).mean(dim=1)
+    feat = F.linear(torch.cat([mean, mx], dim=1), sd[lin + ".weight"], sd[lin + ".bias"])
+    feat = feat[:, None, :, None, None].expand(-1, spq, -1, *x.shape[-2:])
+    return feat.reshape(x.shape[0], -1, *x.shape[-2:]), mask
+
+
+def resnet_cm(x, mask, sd, p, spq, layers=(3, 4, 6)):
+    """ResNetCM.forward (networks/backbones.py:224-247)."""
+    mask = F.max_pool2d(mask, 3, 2, 1)
+    x1 = resnet_stem(x, sd, p)
+    c, mask = _comm(x1, mask, sd, p + ".linear1", 2, spq)
+    x2 = _res_layer(torch.cat([x1, c], 1), sd, p, "layer1", layers[0])
+    c, mask = _comm(x2, mask, sd, p + ".linear2", 1, spq)
+    x3 = _res_layer(torch.cat([x2, c], 1), sd, p, "layer2", layers[1])
+    c, mask = _comm(x3, mask, sd, p + ".linear3", 2, spq)
+    return _res_layer(torch.cat([x3, c], 1), sd, p, "layer3", layers[2])
+
+
+_ASPP_DIL = (None, 0, 6, 12, 18)  # aspp_0 = global branch, aspp_1 = 1x1, then dilations
+
+
+def aspp_v2(x, sd, p):
+    """ASPPV2.forward, BN -> (DropBlock) -> conv -> ReLU per branch (backbones.py:324-369)."""
+    g = F.adaptive_avg_pool2d(x, (1, 1))
+    g = F.relu(_conv(_bn(g, sd, p + ".aspp_0.0"), sd, p + ".aspp_0.2"))
+    outs = [g.expand(-1, -1, *x.shape[-2:])]
+    for i in range(1, 5):
+        d = _ASPP_DIL[i]
+        outs.append(F.relu(_conv(_bn(x, sd, f"{p}.aspp_{i}.0"), sd, f"{p}.aspp_{i}.2",
+                                 padding=d, dilation=max(d, 1))))
+    return _conv(torch.cat(outs, 1), sd, p + ".layer6")
+
+
+def aspp(x, sd, p):
+    """ASPP.forward, conv -> ReLU -> (Dropout2d) per branch (backbones.py:279-321)."""
+    g = F.relu(_conv(F.adaptive_avg_pool2d(x, (1, 1)), sd, p + ".aspp_0.0"))
+    outs = [g.expand(-1, -1, *x.shape[-2:])]
+    for i in range(1, 5):
+        d = _ASPP_DIL[i]
+        outs.append(F.relu(_conv(x, sd, f"{p}.aspp_{i}.0", padding=d, dilation=max(d, 1))))
+    return _conv(torch.cat(outs, 1), sd, p + ".layer6")
+
+
+def purifier(x, sd, p, v2=True):
+    """encoder.purifier (networks/pemp_stage1.py:73-80; pemp_stage2.py:65-72)."""
+    x = F.relu(_conv(x, sd, p + ".0"))
+    x = F.relu(_conv(x, sd, p + ".3", padding=1))
+    return aspp_v2(x, sd, p + ".6") if v2 else aspp(x, sd, p + ".6")
+
+
+_VGG = (  # (conv index in nn.Sequential, dilation, relu) / "P2" pool s2 / "P1" pool s1 -- backbones.py:375-397
+    (0, 1, True), (2, 1, True), "P2", (5, 1, True), (7, 1, True), "P2",
+    (10, 1, True), (12, 1, True), (14, 1, True), "P2",
+    (17, 1, True), (19, 1, True), (21, 1, True), "P1",
+    (24, 2, True), (26, 2, True), (28, 2, None),
+)
+
+
+def vgg16(x, sd, p, last_relu=False):
+    """VGG16.forward (networks/backbones.py:372-405)."""
+    for item in _VGG:
+        if item == "P2":
+            x = F.max_pool2d(x, 3, 2, 1)
+        elif item == "P1":
+            x = F.max_pool2d(x, 3, 1, 1)
+        else:
+            idx, d, relu = item
+            x = _conv(x, sd, f"{p}.features.{idx}", padding=d, dilation=d)
+            if relu or (relu is None and last_relu):
+                x = F.relu(x)
+    return x
+
+
+def encoder_stage1(x, sd, backbone="resnet50"):
+    """PEMPStage1.encoder (networks/pemp_stage1.py:60-100)."""
+    if backbone == "vgg16":
+        return vgg16(x, sd, "encoder.backbone")
+    layers = (3, 4, 6) if backbone == "resnet50" else (3, 4, 23)
+    return purifier(resnet(x, sd, "encoder.backbone", layers), sd, "encoder.purifier", v2=True)
+
+
+def encoder_baseline(x, sd, backbone="vgg16"):
+    """Baseline.encoder (networks/baseline.py:48-63)."""
+    if backbone == "vgg16":
+        return vgg16(x, sd, "encoder.backbone")
+    return _conv(resnet(x, sd, "encoder.backbone"), sd, "encoder.projection")
+
+
+# ------------------------------------------------------------------------------------------
+# heads
+# ------------------------------------------------------------------------------------------
+def compute_similarity(fg_proto, bg_proto, qry_fts, dist_scalar=20):
+    """networks/pemp_stage1.py:232-261 (= pemp_stage2.py:204-233 = baseline.py:120-149)."""
+    fg = F.cosine_similarity(qry_fts, fg_proto[..., None, None], dim=1) * dist_scalar
+    bg = F.cosine_similarity(qry_fts, bg_proto[..., None, None], dim=1) * dist_scalar
+    return torch.stack((bg, fg), dim=1)
+
+
+def mpm(sup_fts, qry_fts, sup_fg, sup_bg, ctr, protos, dist_scalar=20, ret_ind=False):
+    """PEMPStage1.mpm (networks/pemp_stage1.py:165-230); returns (pred, response|None, protos[B,c,2p])."""
+    B, S, c, h, w = sup_fts.shape
+    sup_fts = sup_fts.reshape(-1, c, h * w)
+    qry_fts = qry_fts.reshape(-1, c, 1, h, w)
+    sup_fg = sup_fg.reshape(-1, 1, h * w)
+    sup_bg = sup_bg.reshape(-1, 1, h * w)
+    response = None
+    if ctr is not None:
+        ctr = ctr.view(1, c, protos * 2)
+        mask = torch.stack((sup_fg, sup_bg), dim=1)                                   # [BS,2,1,hw]
+        D = -((sup_fts.unsqueeze(2) - ctr.unsqueeze(3)) ** 2).sum(dim=1)              # [BS,2p,hw]
+        D = D.view(-1, 2, protos, h * w)
+        D = (torch.softmax(D, dim=2) * mask).view(-1, 1, protos * 2, h * w)
+        masked = sup_fts.view(-1, c, 1, h * w) * D                                    # [BS,c,2p,hw]
+        new = (masked.sum(dim=3) / (D.sum(dim=3) + 1e-6)).view(B, S, c, 2, protos)
+        new = new.transpose(3, 4).reshape(B, S, c * protos, 2).mean(dim=1)            # [B,cp,2]
+        adaptive_p = new.view(B, c, protos, 2).transpose(2, 3).reshape(B, c, -1)      # stage2 :185
+        fg_proto, bg_proto = new.view(B, c, protos, 2).unbind(dim=3)                  # [B,c,p]
+        mv = compute_similarity(fg_proto, bg_proto, qry_fts, dist_scalar).max(dim=2)
+        pred = mv.values
+        if ret_ind:
+            ind = mv.indices
+            response = ind[:, 0].clone()
+            sel = pred.argmax(dim=1) == 1
+            response[sel] = ind[:, 1][sel] + 3
+        return pred, response, adaptive_p
+    fg_vecs = torch.sum(sup_fts * sup_fg, dim=-1) / (sup_fg.sum(dim=-1) + 1e-5)
+    bg_vecs = torch.sum(sup_fts * sup_bg, dim=-1) / (sup_bg.sum(dim=-1) + 1e-5)
+    fg_proto = fg_vecs.view(B, S, c).mean(dim=1)
+    bg_proto = bg_vecs.view(B, S, c).mean(dim=1)
+    pred = compute_similarity(fg_proto, bg_proto, qry_fts.view(-1, c, h, w), dist_scalar)
+    return pred, None, torch.stack((fg_proto, bg_proto), dim=2)
+
+
+def _finish(pred, response, out_shape):
+    out = F.interpolate(pred, out_shape, mode="bilinear", align_corners=True)
+    if response is None:
+        return out
+    r = F.interpolate(response.unsqueeze(1).float(), out_shape, mode="nearest")
+    return out, r.squeeze(1).long()
+
+
+def stage1_forward(sd, sup_img, sup_mask, qry_img, out_shape=None, ret_ind=False,
+                   backbone="resnet50", protos=3, dist_scalar=20, ret_lowres=False):
+    """PEMPStage1.forward (networks/pemp_stage1.py:111-163)."""
+    B, S, ch, H, W = sup_img.shape
+    Q = qry_img.shape[1]
+    x = torch.cat((sup_img, qry_img), dim=1).view(B * (S + Q), ch, H, W)
+    f = encoder_stage1(x, sd, backbone)
+    _, c, h, w = f.shape
+    f = f.view(B, S + Q, c, h, w)
+    m = F.interpolate(sup_mask.view(B * S, 2, H, W), (h, w), mode="nearest")
+    fg, bg = m.unbind(dim=1)
+    ctr = sd.get("ctr") if protos > 0 else None
+    pred, resp, _ = mpm(f[:, :S], f[:, S:], fg, bg, ctr, protos, dist_scalar, ret_ind)
+    if ret_lowres:
+        return pred, f
+    return _finish(pred, resp, out_shape if out_shape is not None else (H, W))
+
+
+def baseline_forward(sd, sup_img, sup_mask, qry_img, out_shape=None, backbone="vgg16",
+                     dist_scalar=20, ret_lowres=False):
+    """Baseline.forward (networks/baseline.py:69-118): MAP over bilinearly upsampled features."""
+    B, S, C, H, W = sup_img.shape
+    Q = qry_img.shape[1]
+    x = torch.cat((sup_img, qry_img), dim=1).view(B * (S + Q), C, H, W)
+    f = encoder_baseline(x, sd, backbone)
+    _, c, h, w = f.shape
+    f = f.view(B, S + Q, c, h, w)
+    sup = F.interpolate(f[:, :S].reshape(B * S, c, h, w), (H, W), mode="bilinear", align_corners=True)
+    qry = f[:, S:].reshape(B * Q, c, h, w)
+    mfg, mbg = sup_mask.view(B * S, 2, H, W).split(1, dim=1)
+    fgv = torch.sum(sup * mfg, dim=(2, 3)) / (mfg.sum(dim=(2, 3)) + 1e-5)
+    bgv = torch.sum(sup * mbg, dim=(2, 3)) / (mbg.sum(dim=(2, 3)) + 1e-5)
+    fgp = fgv.view(B, S, -1).mean(dim=1)
+    bgp = bgv.view(B, S, -1).mean(dim=1)
+    pred = compute_similarity(fgp, bgp, qry, dist_scalar)
+    if ret_lowres:
+        return pred, f
+    return F.interpolate(pred, out_shape if out_shape is not None else (H, W),
+                         mode="bilinear", align_corners=True)
+
+
+def stage2_forward(sd, sup_img, sup_mask, qry_img, qry_prior, out_shape=None, ret_ind=False,
+                   protos2=3, dist_scalar=20, ret_lowres=False):
+    """PEMPStage2.forward, ResNet-50+CM (networks/pemp_stage2.py:104-162)."""
+    B, S, ch, H, W = sup_img.shape
+    Q = qry_img.shape[1]
+    img = torch.cat((sup_img, qry_img), dim=1).view(B * (S + Q), ch, H, W)
+    prior = torch.cat((sup_mask[:, :, :1], qry_prior.view(B, Q, *qry_prior.shape[-3:]).float()), dim=1)
+    prior = prior.view(B * (S + Q), 1, H, W)
+    f = resnet_cm(torch.cat((img, prior), dim=1), prior, sd, "encoder.backbone", S + Q)
+    f = purifier(f, sd, "encoder.purifier", v2=False)
+    _, c, h, w = f.shape
+    f = f.view(B, S + Q, c, h, w)
+    m = F.interpolate(sup_mask.view(B * S, 2, H, W), (h, w), mode="nearest")
+    fg, bg = m.unbind(dim=1)
+    ctr = sd.get("ctr") if protos2 > 0 else None
+    pred, resp, adaptive_p = mpm(f[:, :S], f[:, S:], fg, bg, ctr, protos2, dist_scalar, ret_ind)
+    if ret_lowres:
+        return pred, f, adaptive_p
+    return _finish(pred, resp, out_shape if out_shape is not None else (H, W))
+
+
+# ------------------------------------------------------------------------------------------
+# harness pieces: loss, test_step, metric
+# ------------------------------------------------------------------------------------------
+def ce_loss(logits, target):
+    """losses.get('ce') = nn.CrossEntropyLoss(ignore_index=255) (core/losses.py:10)."""
+    return F.cross_entropy(logits, target, ignore_index=255)
+
+
+def test_step(forward_fn, inputs, qry_msk):
+    """Evaluator.test_step (entry/pemp_stage1.py:48-53): forward at the GT's size, CE, argmax."""
+    logits = forward_fn(*inputs, tuple(qry_msk.shape[-2:]))
+    tgt = qry_msk.view(-1, *qry_msk.shape[-2:])
+    loss = float(ce_loss(logits, tgt))
+    return logits.argmax(dim=1).numpy(), loss, logits
+
+
+class FewShotMetric:
+    """core/metrics.py:4-35 (integer tp/fp/fn table, mIoU over val labels, binary IoU)."""
+
+    def __init__(self, classes):
+        self.stat = np.zeros((classes + 1, 3))
+
+    def update(self, pred, ref, cls):
+        pred = np.asarray(pred, np.uint8)
+        ref = np.asarray(ref, np.uint8)
+        for i, ci in enumerate(cls):
+            p, r = pred[i], ref[i]
+            valid = r != 255
+            for j, c in enumerate([0, int(ci)]):
+                self.stat[c, 0] += int(((p == j) & (r == j) & valid).sum())
+                self.stat[c, 1] += int(((p == j) & (r != j) & valid).sum())
+                self.stat[c, 2] += int(((p != j) & (r == j) & valid).sum())
+
+    def miou(self, labels, binary=False):
+        stat = np.c_[self.stat[0], self.stat[1:].sum(axis=0)].T if binary else self.stat[labels]
+        tp, fp, fn = stat.T
+        per = tp / (tp + fp + fn)
+        return per, per.mean()
+
+
+def to_torch_sd(np_sd):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in np_sd.items()}

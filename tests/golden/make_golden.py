@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference; the GPU box never has it).  The
+reference's hot-path modules (networks/backbones.py, pemp_stage1.py, pemp_stage2.py,
+baseline.py) are imported unmodified from /root/reference and executed on CPU.  Two third-party
+packages they import are not installed in the image (no network): ``sacred`` (config injection)
+and ``dropblock`` (train-only regulariser).  This script puts two minimal in-process stand-ins
+for those packages on sys.path -- an ``Ingredient`` whose ``capture`` fills missing arguments
+by name from a dict, and a ``DropBlock2D`` that is the identity (its eval-mode behaviour) --
+exactly as SURVEY.md §8(c) recorded.  No reference source is copied or altered.
+
+Inputs come from pemp_amd.synth (bit-exact on any host), so each fixture stores only the seeds
+and the expected OUTPUTS (+ a few sampled intermediates).
+
+usage:  python tests/golden/make_golden.py [--only NAME]
+"""
+import argparse
+import json
+import logging
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from pemp_amd import synth  # noqa: E402
+
+
+def _install_standins():
+    import inspect
+    import functools
+
+    sacred = types.ModuleType("sacred")
+
+    class Ingredient:
+        def __init__(self, name, **kw):
+            self.name = name
+            self.cfg = {}
+
+        def config(self, fn):
+            return fn
+
+        def config_hook(self, fn):
+            return fn
+
+        def capture(self, fn):
+            sig = inspect.signature(fn)
+            ing = self
+
+            @functools.wraps(fn)
+            def wrapper(*a, **k):
+                bound = sig.bind_partial(*a, **k)
+                for p in sig.parameters:
+                    if p not in bound.arguments and p in ing.cfg:
+                        k[p] = ing.cfg[p]
+                return fn(*a, **k)
+            return wrapper
+
+    sacred.Ingredient = Ingredient
+    sys.modules["sacred"] = sacred
+
+    dropblock = types.ModuleType("dropblock")
+
+    class DropBlock2D(torch.nn.Module):
+        def __init__(self, drop_prob=0.1, block_size=4):
+            super().__init__()
+
+        def forward(self, x):
+            if self.training:
+                raise RuntimeError("stand-in DropBlock2D is eval-only")
+            return x
+
+    dropblock.DropBlock2D = DropBlock2D
+    sys.modules["dropblock"] = dropblock
+
+
+def _build(module, cls_name, cfg, ctor_args, tmp):
+    """Instantiate a reference model with random torchvision-layout 'pretrained' file, eval mode."""
+    from networks import backbones
+    module.net_ingredient.cfg = dict(cfg)
+    bb = cfg.get("backbone2") if cls_name == "PEMPStage2" else cfg["backbone"]
+    if bb == "vgg16":
+        pre = backbones.VGG16(3, None).state_dict()
+    else:
+        pre = backbones.ResNet(3, backbones.BottleNeck, [3, 4, 6, 3], pretrained=None).state_dict()
+    f = Path(tmp) / f"pre_{bb}.pth"
+    torch.save(pre, f)
+    module.pretrained_weights[bb] = f
+    logger = logging.getLogger("golden")
+    model = getattr(module, cls_name)(*ctor_args, logger)
+    return model.eval()
+
+
+def _load_wgen(model, seed=1234):
+    sd = synth.gen_state_dict({k: v for k, v in model.state_dict().items()}, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return sd
+
+
+def _keys_fixture(model, name):
+    spec = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()]
+    (OUT / f"state_keys_{name}.json").write_text(json.dumps(spec))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _metric_counts(pred, ref):
+    out = []
+    for j in (0, 1):
+        v = ref != 255
+        out.append([int(((pred == j) & (ref == j) & v).sum()),
+                    int(((pred == j) & (ref != j) & v).sum()),
+                    int(((pred != j) & (ref == j) & v).sum())])
+    return np.array(out, np.int64)
+
+
+def _capture_lowres(model, mod):
+    """Hook compute_similarity/mpm to grab features-level intermediates without touching the reference."""
+    grabbed = {}
+    enc = model.encoder
+
+    def hook(_m, _i, o):
+        grabbed["features"] = o.detach()
+    h = enc.register_forward_hook(hook)
+    return grabbed, h
+
+
+def _episode_case(model, kind, seeds, shot, H, out_hws, extra=None):
+    """Run reference on episodes; return dict of arrays."""
+    res = {"seeds": np.array(seeds), "shot": np.array(shot), "H": np.array(H)}
+    grabbed, h = _capture_lowres(model, None)
+    for n, seed in enumerate(seeds):
+        ep = synth.make_episode(seed, shot=shot, height=H, width=H, out_hw=out_hws[n])
+        sup, msk, qry = _t(ep["sup_img"])[None], _t(ep["sup_mask"])[None], _t(ep["qry_img"])[None]
+        gt = _t(ep["qry_mask"])
+        out_shape = tuple(gt.shape[-2:])
+        with torch.no_grad():
+            if kind == "stage1":
+                logits, resp = model(sup, msk, qry, out_shape, ret_ind=True)
+            elif kind == "baseline":
+                logits, resp = model(sup, msk, qry, out_shape), None
+            elif kind == "stage2":
+                prior = extra["prior"][n]
+                logits, resp = model(sup, msk, qry, prior, out_shape, ret_ind=True)
+            loss = float(torch.nn.functional.cross_entropy(logits, gt, ignore_index=255))
+        feats = grabbed["features"]                       # [S+Q, c, h, w]
+        pred = logits.argmax(1).numpy().astype(np.uint8)
+        res[f"e{n}_out_hw"] = np.array(out_shape)
+        res[f"e{n}_loss"] = np.array(loss, np.float64)
+        res[f"e{n}_argmax_bits"] = np.packbits(pred.reshape(-1))
+        res[f"e{n}_counts"] = _metric_counts(pred[0], ep["qry_mask"][0])
+        res[f"e{n}_logits_s7"] = logits[0, :, ::7, ::7].numpy()
+        res[f"e{n}_feat_c8"] = feats[:, ::8].numpy() if feats.shape[-1] <= 13 else feats[:, ::8, ::5, ::5].numpy()
+        if resp is not None:
+            res[f"e{n}_resp_s7"] = resp[0, ::7, ::7].numpy().astype(np.uint8)
+        if kind == "stage2":
+            res[f"e{n}_adaptive_p"] = model.adaptive_p.numpy()
+        if H <= 97:
+            res[f"e{n}_logits"] = logits[0].numpy()
+    h.remove()
+    return res
+
+
+def gen_stage1(tmp, backbone, tag, cases):
+    from networks import pemp_stage1 as m
+    cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone=backbone, protos=3,
+               drop_rate=0.1, block_size=4)
+    model = _build(m, "PEMPStage1", cfg, (), tmp)
+    _load_wgen(model)
+    _keys_fixture(model, tag)
+    for cname, (seeds, shot, H, hws) in cases.items():
+        np.savez_compressed(OUT / f"{tag}_{cname}.npz", **_episode_case(model, "stage1", seeds, shot, H, hws))
+        print("wrote", tag, cname)
+    return model
+
+
+def gen_stage1_map(tmp):
+    """protos=0 branch: plain masked average pooling (pemp_stage1.py:223-228)."""
+    from networks import pemp_stage1 as m
+    cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=0,
+               drop_rate=0.1, block_size=4)
+    model = _build(m, "PEMPStage1", cfg, (), tmp)
+    _load_wgen(model)
+    grabbed, h = _capture_lowres(model, None)
+    res = {}
+    ep = synth.make_episode(11, shot=2, height=97, width=97, out_hw=(80, 120))
+    with torch.no_grad():
+        logits = model(_t(ep["sup_img"])[None], _t(ep["sup_mask"])[None], _t(ep["qry_img"])[None], (80, 120))
+    res["seeds"] = np.array([11]); res["shot"] = np.array(2); res["H"] = np.array(97)
+    res["e0_out_hw"] = np.array((80, 120)); res["e0_logits"] = logits[0].numpy()
+    np.savez_compressed(OUT / "stage1_rn50_map_small.npz", **res)
+    h.remove()
+    print("wrote stage1 map")
+
+
+def gen_baseline(tmp, backbone, tag, cases):
+    from networks import baseline as m
+    cfg = dict(dist_scalar=20, init_channels=3, backbone=backbone, out_channels=512)
+    model = _build(m, "Baseline", cfg, (), tmp)
+    _load_wgen(model)
+    _keys_fixture(model, tag)
+    for cname, (seeds, shot, H, hws) in cases.items():
+        np.savez_compressed(OUT / f"{tag}_{cname}.npz", **_episode_case(model, "baseline", seeds, shot, H, hws))
+        print("wrote", tag, cname)
+
+
+def gen_stage2(tmp, stage1_model, cases):
+    from networks import pemp_stage2 as m
+    for cname, (seeds, shot, H, hws) in cases.items():
+        cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
+                   drop_rate=0.1, block_size=4, backbone2="resnet50", protos2=3, drop_rate2=0.5, cm=True)
+        model = _build(m, "PEMPStage2", cfg, (shot, 1), tmp)
+        _load_wgen(model, seed=4321)
+        _keys_fixture(model, "stage2_rn50cm")
+        priors = []
+        for n, seed in enumerate(seeds):                    # stage-1 prior, entry/pemp_stage2.py:58-60
+            ep = synth.make_episode(seed, shot=shot, height=H, width=H, out_hw=hws[n])
+            with torch.no_grad():
+                p = stage1_model(_t(ep["sup_img"])[None], _t(ep["sup_mask"])[None], _t(ep["qry_img"])[None])
+            priors.append(p.argmax(dim=1, keepdim=True))
+        res = _episode_case(model, "stage2", seeds, shot, H, hws, extra={"prior": priors})
+        for n, p in enumerate(priors):
+            res[f"e{n}_prior_bits"] = np.packbits(p.numpy().astype(np.uint8).reshape(-1))
+        np.savez_compressed(OUT / f"stage2_rn50cm_{cname}.npz", **res)
+        print("wrote stage2", cname)
+
+
+def gen_index_facts():
+    """G8: index-map facts of the stock ops."""
+    import torch.nn.functional as F
+    r = {}
+    for (i, o) in ((401, 51), (97, 13)):
+        src = F.interpolate(torch.arange(i, dtype=torch.float32).view(1, 1, 1, i), (1, o), mode="nearest")
+        r[f"nearest_{i}_{o}"] = src.view(-1).numpy().astype(np.int64)
+    r["pool_ceil_201"] = np.array(F.max_pool2d(torch.zeros(1, 1, 201, 201), 3, 2, 1, ceil_mode=True).shape[-1])
+    r["pool_ceil_49"] = np.array(F.max_pool2d(torch.zeros(1, 1, 49, 49), 3, 2, 1, ceil_mode=True).shape[-1])
+    x = torch.zeros(1, 1, 401, 401)
+    sizes = []
+    for s in (2, 2, 2, 1):
+        x = F.max_pool2d(x, 3, s, 1)
+        sizes.append(x.shape[-1])
+    r["vgg_sizes_401"] = np.array(sizes)
+    np.savez_compressed(OUT / "index_facts.npz", **r)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    _install_standins()
+    sys.path.insert(0, str(REF))
+    small = {"small": ([3, 4], 1, 97, [(97, 97), (80, 120)]),
+             "small5": ([5], 5, 97, [(64, 90)])}
+    full = {"full": ([5678, 5679], 1, 401, [synth.QUERY_SIZES[5678 % 5], synth.QUERY_SIZES[5679 % 5]])}
+    with tempfile.TemporaryDirectory() as tmp:
+        only = args.only
+        s1 = None
+        if only in ("", "stage1", "stage2"):
+            s1 = gen_stage1(tmp, "resnet50", "stage1_rn50", {**small, **full} if only != "stage2" else {})
+        if only in ("", "map"):
+            gen_stage1_map(tmp)
+        if only in ("", "stage1vgg"):
+            gen_stage1(tmp, "vgg16", "stage1_vgg16", {"small": small["small"]})
+        if only in ("", "baseline"):
+            gen_baseline(tmp, "vgg16", "baseline_vgg16",
+                         {"small": small["small"], "small5": small["small5"],
+                          "full": ([5678], 1, 401, [synth.QUERY_SIZES[5678 % 5]])})
+            gen_baseline(tmp, "resnet50", "baseline_rn50", {"small": small["small"]})
+        if only in ("", "stage2"):
+            gen_stage2(tmp, s1, {"small": ([3], 1, 97, [(80, 120)]), "small5": ([5], 5, 97, [(64, 90)])})
+        if only in ("", "facts"):
+            gen_index_facts()
+
+
+if __name__ == "__main__":
+    main()
