@@ -138,7 +138,8 @@ int pemp_eval_tail_f32(const float* pred, const int64_t* target, uint8_t* pred_o
 
 /* ResNetCM.comm statistics (networks/backbones.py:208-216): mask' = max_pool2d(mask,3,stride,1);
  * mean over ALL pixels and max over pixels of x*mask' per image and channel.
- *   x [N][Hx*Wx][ldx], mask_in [N][Hm][Wm], mask_out [N][Hx][Wx], stat [N][2][C] (mean, max)  */
+ *   x [N][Hx*Wx][ldx], mask_in [N][Hm][Wm], mask_out [N][Hx][Wx], stat [N][2][C] (mean, max).
+ * x == NULL pools the mask only (the extra pool at backbones.py:227).                          */
 int pemp_cm_reduce_f32(const float* x, int ldx, const float* mask_in, float* mask_out, float* stat,
                        int N, int Hm, int Wm, int Hx, int Wx, int C, int stride, void* stream);
 

@@ -1,0 +1,85 @@
+"""ctypes binding of libpemp_hip.so (the C ABI declared in include/pemp_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a symbol cannot be
+resolved this module raises, loudly, at first use.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime our .so binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpemp_hip.so")
+
+c_fp = C.c_void_p          # device pointers travel as integers
+c_int = C.c_int
+c_size = C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    """struct pemp_conv_desc (include/pemp_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "H", "W", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "KH", "KW",
+                 "stride", "pad", "dil", "ldr", "Kpad")] + [("flags", C.c_uint32), ("tile", C.c_int32)]
+
+
+CONV_RELU = 1
+CONV_SHIFT_PER_IMAGE = 2
+CONV_STEM4 = 4
+
+#: every symbol include/pemp_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "pemp_last_error": (C.c_char_p, []),
+    "pemp_abi_version": (c_int, []),
+    "pemp_conv2d_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "pemp_pack_input_nhwc4_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    "pemp_maxpool2d_nhwc_f32": (c_int, [c_fp, c_fp] + [c_int] * 11 + [c_fp]),
+    "pemp_global_avgpool_nhwc_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "pemp_channel_affine_multi_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int,
+                                              C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp),
+                                              C.POINTER(c_int), c_fp]),
+    "pemp_mpm_workspace_bytes": (c_size, [c_int] * 5),
+    "pemp_mpm_protos_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_size] + [c_int] * 8 + [c_fp]),
+    "pemp_map_workspace_bytes": (c_size, [c_int] * 4),
+    "pemp_masked_avg_pool_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_size] + [c_int] * 8 + [c_fp]),
+    "pemp_cosine_proto_max_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,
+                                          C.c_float, c_fp]),
+    "pemp_upsample_bilinear_ac_f32": (c_int, [c_fp, c_fp] + [c_int] * 6 + [c_fp]),
+    "pemp_upsample_nearest_u8_i64": (c_int, [c_fp, c_fp] + [c_int] * 5 + [c_fp]),
+    "pemp_eval_tail_workspace_bytes": (c_size, [c_int] * 3),
+    "pemp_eval_tail_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size] + [c_int] * 5 + [c_fp]),
+    "pemp_cm_reduce_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp]),
+}
+
+_lib = None
+
+
+class PempHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle with prototypes set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PempHipError(
+            f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "pemp_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pemp_abi_version() != 1:
+        raise PempHipError(f"ABI version mismatch: library {lib.pemp_abi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pemp_last_error().decode(errors="replace")
+        kind = "invalid argument" if rc < 0 else f"hipError {rc}"
+        raise PempHipError(f"{what}: {kind}: {msg}")

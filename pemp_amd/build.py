@@ -1,0 +1,32 @@
+"""Build libpemp_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libpemp_hip.so")
+SOURCES = ("conv_igemm.hip", "pool_misc.hip", "head.hip")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "pemp_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,533 @@
+// Prototype head of PEMP on gfx950: meta-prototype module (soft assignment + masked pooling),
+// plain / full-resolution masked average pooling, pixel x prototype cosine map with group max,
+// and the upsample / argmax / cross-entropy / IoU-count tail of the evaluator.
+//
+// All of these are streaming kernels over [pixels][c] feature maps (c contiguous): their bound
+// is HBM/L2 bandwidth (AI ~ 3 flop/B at 2p = 6 prototypes), so the design is wave-per-pixel
+// coalesced 16-B loads + wavefront shuffles, partial sums in a fixed order (deterministic).
+#include "common.h"
+
+namespace pemp {
+
+constexpr int MAXJ = 8;     // 2p <= 8
+constexpr int MAXCL = 8;    // channels per lane: c <= 64*MAXCL = 512
+constexpr int PCHUNK = 32;  // pixels per pooling block
+
+// F.interpolate(mode="nearest") source index (legacy rule: floor(dst * in/out), scale in fp32)
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+    float scale = (float)in / (float)out;
+    int s = (int)floorf((float)dst * scale);
+    return min(s, in - 1);
+}
+
+// -----------------------------------------------------------------------------------------------
+// assign weights  A[bs][j][i]
+//   MODE 0: meta-prototype soft assignment, networks/pemp_stage1.py:205-207
+//   MODE 1: plain masks (fg, bg) at feature resolution, pemp_stage1.py:224-225
+// one wave per pixel.
+template <int MODE>
+__global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ feat, int ldf,
+                                                     const float* __restrict__ mask,
+                                                     const float* __restrict__ ctr, float* __restrict__ A,
+                                                     int n, int h, int w, int H, int W, int c, int p) {
+    const int bs = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int J = MODE == 0 ? 2 * p : 2;
+    const int ncl = (c + 255) / 256;  // float4 chunks per lane
+
+    float cw[MAXJ][MAXCL];            // this lane's slice of ctr (MODE 0)
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < MAXCL / 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int ch = t * 256 + lane * 4 + e;
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j) cw[j][t * 4 + e] = (t < ncl && ch < c && j < J) ? ctr[ch * J + j] : 0.f;
+            }
+    }
+    const float* mk = mask + (size_t)bs * 2 * H * W;
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        const int y = i / w, x = i - y * w;
+        const int sy = nearest_src(y, H, h), sx = nearest_src(x, W, w);
+        const float mfg = mk[(size_t)sy * W + sx];
+        const float mbg = mk[(size_t)H * W + (size_t)sy * W + sx];
+        float* out = A + ((size_t)bs * J) * n + i;
+        if (MODE == 1) {
+            if (lane == 0) {
+                out[0] = mfg;
+                out[n] = mbg;
+            }
+            continue;
+        }
+        const float* xp = feat + ((size_t)bs * n + i) * ldf;
+        float d[MAXJ];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) d[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXCL / 4; ++t) {
+            int ch = t * 256 + lane * 4;
+            if (t < ncl && ch < c) {
+                float4 v = *(const float4*)(xp + ch);
+                float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < MAXJ; ++j) {
+                        float df = xv[e] - cw[j][t * 4 + e];
+                        d[j] += df * df;
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) d[j] = -wave_sum(d[j]);
+        if (lane == 0) {
+            for (int g = 0; g < 2; ++g) {
+                float mx = -INFINITY;
+                for (int j = 0; j < p; ++j) mx = fmaxf(mx, d[g * p + j]);
+                float e[MAXJ / 2], s = 0.f;
+                for (int j = 0; j < p; ++j) {
+                    e[j] = expf(d[g * p + j] - mx);
+                    s += e[j];
+                }
+                const float m = g == 0 ? mfg : mbg;
+                for (int j = 0; j < p; ++j) out[(size_t)(g * p + j) * n] = (e[j] / s) * m;
+            }
+        }
+    }
+}
+
+// MODE 2 (Baseline): A_g[p] = sum_P m_g[P] * W[P][p], W = bilinear align_corners weights of the
+// h x w -> H x W upsampling (adjoint of networks/baseline.py:100), plus exact mask sums.
+// one thread per low-res pixel and group.
+__global__ void adjoint_mask_kernel(const float* __restrict__ mask, float* __restrict__ A, int n, int h, int w,
+                                    int H, int W) {
+    const int bs = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * n) return;
+    const int g = idx / n, i = idx - g * n;
+    const int y = i / w, x = i - y * w;
+    const float* m = mask + ((size_t)bs * 2 + g) * H * W;
+    const float sh = h > 1 && H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sw = w > 1 && W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    // rows Y whose source coordinate sh*Y lies in (y-1, y+1)
+    int Y0 = sh > 0.f ? max(0, (int)floorf((float)(y - 1) / sh) - 1) : 0;
+    int Y1 = sh > 0.f ? min(H - 1, (int)ceilf((float)(y + 1) / sh) + 1) : H - 1;
+    int X0 = sw > 0.f ? max(0, (int)floorf((float)(x - 1) / sw) - 1) : 0;
+    int X1 = sw > 0.f ? min(W - 1, (int)ceilf((float)(x + 1) / sw) + 1) : W - 1;
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        float fy = sh * (float)Y;
+        int y0 = (int)fy;
+        int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        float ly = fy - (float)y0;
+        float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y && y1 != y0 ? ly : 0.f);
+        if (y1 == y0 && y0 == y) wy = 1.f;
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int X = X0; X <= X1; ++X) {
+            float fx = sw * (float)X;
+            int x0 = (int)fx;
+            int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            float lx = fx - (float)x0;
+            float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x && x1 != x0 ? lx : 0.f);
+            if (x1 == x0 && x0 == x) wx = 1.f;
+            if (wx != 0.f) row += wx * m[(size_t)Y * W + X];
+        }
+        acc += wy * row;
+    }
+    A[((size_t)bs * 2 + g) * n + i] = acc;
+}
+
+// exact full-resolution mask sums (integers in fp32), one block per (bs, g)
+__global__ __launch_bounds__(256) void mask_sum_kernel(const float* __restrict__ mask, float* __restrict__ out,
+                                                       int HW) {
+    __shared__ float red[4];
+    const float* m = mask + (size_t)blockIdx.x * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += m[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// -----------------------------------------------------------------------------------------------
+// pooling partial sums: part[bs][chunk][j][c] = sum_{i in chunk} x[i][c] * A[j][i]
+//                       asum[bs][chunk][j]    = sum_{i in chunk} A[j][i]
+// thread t owns channels t and t+256 (coalesced across the block), pixels in order.
+__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ feat, int ldf,
+                                                           const float* __restrict__ A, float* __restrict__ part,
+                                                           float* __restrict__ asum, int n, int c, int J,
+                                                           int nchunks) {
+    __shared__ float As[MAXJ][PCHUNK];
+    const int bs = blockIdx.y, ck = blockIdx.x;
+    const int i0 = ck * PCHUNK;
+    const int np = min(PCHUNK, n - i0);
+    for (int t = threadIdx.x; t < J * PCHUNK; t += 256) {
+        int j = t / PCHUNK, i = t - j * PCHUNK;
+        As[j][i] = i < np ? A[((size_t)bs * J + j) * n + i0 + i] : 0.f;
+    }
+    __syncthreads();
+    float acc[2][MAXJ];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) acc[k][j] = 0.f;
+    const float* xb = feat + ((size_t)bs * n + i0) * ldf;
+    for (int i = 0; i < np; ++i) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int ch = threadIdx.x + 256 * k;
+            if (ch < c) {
+                float v = xb[(size_t)i * ldf + ch];
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j)
+                    if (j < J) acc[k][j] += v * As[j][i];
+            }
+        }
+    }
+    float* pb = part + ((size_t)bs * nchunks + ck) * J * c;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int ch = threadIdx.x + 256 * k;
+        if (ch < c)
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j)
+                if (j < J) pb[(size_t)j * c + ch] = acc[k][j];
+    }
+    if (threadIdx.x < J) {
+        float s = 0.f;
+        for (int i = 0; i < np; ++i) s += As[threadIdx.x][i];
+        asum[((size_t)bs * nchunks + ck) * J + threadIdx.x] = s;
+    }
+}
+
+// protos[b][j][c] = mean_s ( sum_chunks part / (denominator + eps) )
+__global__ __launch_bounds__(256) void pool_final_kernel(const float* __restrict__ part,
+                                                         const float* __restrict__ asum,
+                                                         const float* __restrict__ den_override,
+                                                         float* __restrict__ protos, int S, int c, int J, int nchunks,
+                                                         float eps) {
+    const int b = blockIdx.y, j = blockIdx.x;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float tot = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const int bs = b * S + s;
+            float num = 0.f, den = 0.f;
+            for (int k = 0; k < nchunks; ++k) {
+                num += part[(((size_t)bs * nchunks + k) * J + j) * c + ch];
+                den += asum[((size_t)bs * nchunks + k) * J + j];
+            }
+            if (den_override) den = den_override[bs * J + j];
+            tot += num / (den + eps);
+        }
+        protos[((size_t)b * J + j) * c + ch] = tot / (float)S;
+    }
+}
+
+// -----------------------------------------------------------------------------------------------
+// cosine map + group max (networks/pemp_stage1.py:214-222,256-260), one wave per query pixel.
+// torch>=2 F.cosine_similarity: each vector is divided by max(||.||, 1e-8), then dotted.
+__global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ qry, int ldf,
+                                                     const float* __restrict__ protos, float* __restrict__ pred,
+                                                     uint8_t* __restrict__ resp, int n, int c, int p, float scalar) {
+    __shared__ float pn[MAXJ][64 * MAXCL];
+    __shared__ float nrm[MAXJ];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int J = 2 * p;
+    const float* pb = protos + (size_t)b * J * c;
+    for (int j = wave; j < J; j += 4) {
+        float s = 0.f;
+        for (int ch = lane; ch < c; ch += 64) {
+            float v = pb[(size_t)j * c + ch];
+            s += v * v;
+        }
+        s = wave_sum(s);
+        if (lane == 0) nrm[j] = fmaxf(sqrtf(s), 1e-8f);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < J * c; t += 256) {
+        int j = t / c, ch = t - j * c;
+        pn[j][ch] = pb[t] / nrm[j];
+    }
+    __syncthreads();
+    const int ncl = (c + 255) / 256;
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        const float* xp = qry + ((size_t)b * n + i) * ldf;
+        float xv[MAXCL];
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXCL / 4; ++t) {
+            int ch = t * 256 + lane * 4;
+            float4 v = (t < ncl && ch < c) ? *(const float4*)(xp + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[t * 4 + 0] = v.x; xv[t * 4 + 1] = v.y; xv[t * 4 + 2] = v.z; xv[t * 4 + 3] = v.w;
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        ss = wave_sum(ss);
+        const float nx = fmaxf(sqrtf(ss), 1e-8f);
+        float dot[MAXJ];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) dot[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAXCL / 4; ++t) {
+            int ch = t * 256 + lane * 4;
+            if (t < ncl && ch < c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float xn = xv[t * 4 + e] / nx;
+#pragma unroll
+                    for (int j = 0; j < MAXJ; ++j)
+                        if (j < J) dot[j] += xn * pn[j][ch + e];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) dot[j] = wave_sum(dot[j]) * scalar;
+        if (lane == 0) {
+            float best[2];
+            int bi[2];
+            for (int g = 0; g < 2; ++g) {  // g = 0: fg rows [0,p), g = 1: bg rows [p,2p)
+                best[g] = dot[g * p];
+                bi[g] = 0;
+                for (int j = 1; j < p; ++j)
+                    if (dot[g * p + j] > best[g]) {
+                        best[g] = dot[g * p + j];
+                        bi[g] = j;
+                    }
+            }
+            pred[((size_t)b * 2 + 0) * n + i] = best[1];  // channel 0 = bg
+            pred[((size_t)b * 2 + 1) * n + i] = best[0];  // channel 1 = fg
+            if (resp) resp[(size_t)b * n + i] = (uint8_t)(best[0] > best[1] ? bi[0] + 3 : bi[1]);
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------
+// bilinear, align_corners=True (ATen area_pixel_compute_scale: (in-1)/(out-1) in fp32)
+struct Bilin {
+    int i0, i1;
+    float l;
+};
+__device__ __forceinline__ Bilin bilin(int dst, int in, int out) {
+    float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    float f = scale * (float)dst;
+    Bilin b;
+    b.i0 = min((int)f, in - 1);
+    b.i1 = b.i0 + (b.i0 < in - 1 ? 1 : 0);
+    b.l = f - (float)b.i0;
+    return b;
+}
+__device__ __forceinline__ float bilerp(const float* __restrict__ p, int w, Bilin by, Bilin bx) {
+    float v00 = p[by.i0 * w + bx.i0], v01 = p[by.i0 * w + bx.i1];
+    float v10 = p[by.i1 * w + bx.i0], v11 = p[by.i1 * w + bx.i1];
+    // explicit rounding points so that every kernel using this helper produces the same bits
+    float h0 = 1.f - by.l, w0 = 1.f - bx.l;
+    float top = __fmaf_rn(bx.l, v01, __fmul_rn(w0, v00));
+    float bot = __fmaf_rn(bx.l, v11, __fmul_rn(w0, v10));
+    return __fmaf_rn(by.l, bot, __fmul_rn(h0, top));
+}
+
+__global__ void upsample_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int BC, int h, int w,
+                                         int Ho, int Wo) {
+    long long total = (long long)BC * Ho * Wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int X = (int)(i % Wo);
+        long long t = i / Wo;
+        int Y = (int)(t % Ho);
+        int bc = (int)(t / Ho);
+        out[i] = bilerp(in + (size_t)bc * h * w, w, bilin(Y, h, Ho), bilin(X, w, Wo));
+    }
+}
+
+__global__ void upsample_nearest_kernel(const uint8_t* __restrict__ in, int64_t* __restrict__ out, int B, int h,
+                                        int w, int Ho, int Wo) {
+    long long total = (long long)B * Ho * Wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int X = (int)(i % Wo);
+        long long t = i / Wo;
+        int Y = (int)(t % Ho);
+        int b = (int)(t / Ho);
+        out[i] = in[((size_t)b * h + nearest_src(Y, h, Ho)) * w + nearest_src(X, w, Wo)];
+    }
+}
+
+// eval tail: upsample + argmax + CE partials + tp/fp/fn partials.  part[b][blk][8] doubles.
+__global__ __launch_bounds__(256) void eval_tail_kernel(const float* __restrict__ pred,
+                                                        const int64_t* __restrict__ target,
+                                                        uint8_t* __restrict__ pred_out, float* __restrict__ logits,
+                                                        double* __restrict__ part, int h, int w, int Ho, int Wo) {
+    __shared__ double red[4][8];
+    const int b = blockIdx.y;
+    const int npix = Ho * Wo;
+    const float* p0 = pred + (size_t)b * 2 * h * w;
+    const float* p1 = p0 + h * w;
+    double ce = 0.0;
+    int cnt[7] = {0, 0, 0, 0, 0, 0, 0};  // valid, tp0, fp0, fn0, tp1, fp1, fn1
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        int Y = i / Wo, X = i - Y * Wo;
+        Bilin by = bilin(Y, h, Ho), bx = bilin(X, w, Wo);
+        float l0 = bilerp(p0, w, by, bx), l1 = bilerp(p1, w, by, bx);
+        int am = l1 > l0 ? 1 : 0;
+        pred_out[(size_t)b * npix + i] = (uint8_t)am;
+        if (logits) {
+            logits[((size_t)b * 2 + 0) * npix + i] = l0;
+            logits[((size_t)b * 2 + 1) * npix + i] = l1;
+        }
+        if (target) {
+            int t = (int)target[(size_t)b * npix + i];
+            if (t != 255) {
+                float m = fmaxf(l0, l1);
+                float lse = m + logf(expf(l0 - m) + expf(l1 - m));
+                ce += (double)(lse - (t == 1 ? l1 : l0));
+                cnt[0]++;
+                for (int j = 0; j < 2; ++j) {
+                    cnt[1 + 3 * j] += (am == j && t == j);
+                    cnt[2 + 3 * j] += (am == j && t != j);
+                    cnt[3 + 3 * j] += (am != j && t == j);
+                }
+            }
+        }
+    }
+    double v[8];
+    v[0] = ce;
+    for (int k = 0; k < 7; ++k) v[k + 1] = (double)cnt[k];
+    for (int k = 0; k < 8; ++k) {
+        double x = v[k];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        int k = threadIdx.x;
+        part[((size_t)b * gridDim.x + blockIdx.x) * 8 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+__global__ void eval_tail_final_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
+    const int b = blockIdx.x, k = threadIdx.x;
+    if (k < 8) {
+        double s = 0.0;
+        for (int i = 0; i < nblk; ++i) s += part[((size_t)b * nblk + i) * 8 + k];
+        stats[b * 8 + k] = s;
+    }
+}
+
+static inline int tail_blocks(int Ho, int Wo) {
+    int nb = cdiv(Ho * Wo, 256 * 4);
+    return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+}
+static inline int nchunks_of(int n) { return cdiv(n, PCHUNK); }
+
+}  // namespace pemp
+
+using namespace pemp;
+
+// workspace layout for pooling: A[BS][J][n] | part[BS][nchunks][J][c] | asum[BS][nchunks][J] | msum[BS][2]
+static size_t pool_ws_bytes(int BS, int n, int c, int J) {
+    size_t nck = nchunks_of(n);
+    size_t f = (size_t)BS * J * n + (size_t)BS * nck * J * c + (size_t)BS * nck * J + (size_t)BS * 2 + 16;
+    return f * sizeof(float);
+}
+
+extern "C" size_t pemp_mpm_workspace_bytes(int B, int S, int n, int c, int p) {
+    return pool_ws_bytes(B * S, n, c, 2 * p);
+}
+extern "C" size_t pemp_map_workspace_bytes(int B, int S, int n, int c) { return pool_ws_bytes(B * S, n, c, 2); }
+
+static int pooled_protos(int mode, const float* feat, int ldf, const float* mask, const float* ctr, float* protos,
+                         void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W, int c, int p,
+                         hipStream_t st) {
+    const int BS = B * S, n = h * w;
+    const int J = mode == 0 ? 2 * p : 2;
+    PEMP_REQUIRE(feat && mask && protos && ws, "protos: null pointer");
+    PEMP_REQUIRE(B > 0 && S > 0 && h > 0 && w > 0 && H > 0 && W > 0, "protos: bad dims");
+    PEMP_REQUIRE(c > 0 && c % 4 == 0 && c <= 64 * MAXCL && ldf >= c && ldf % 4 == 0, "protos: c=%d must be a multiple of 4 and <= %d", c, 64 * MAXCL);
+    PEMP_REQUIRE(J >= 2 && J <= MAXJ, "protos: 2p=%d not in 2..%d", J, MAXJ);
+    PEMP_REQUIRE(ws_bytes >= pool_ws_bytes(BS, n, c, J), "protos: workspace too small");
+    PEMP_REQUIRE(((uintptr_t)feat & 15) == 0, "protos: feat must be 16-byte aligned");
+    const int nck = nchunks_of(n);
+    float* A = (float*)ws;
+    float* part = A + (size_t)BS * J * n;
+    float* asum = part + (size_t)BS * nck * J * c;
+    float* msum = asum + (size_t)BS * nck * J;
+    const int ablk = min(cdiv(n, 4), 1024);
+    if (mode == 0) {
+        PEMP_REQUIRE(ctr, "protos: ctr is null");
+        hipLaunchKernelGGL(assign_kernel<0>, dim3(ablk, BS), dim3(256), 0, st, feat, ldf, mask, ctr, A, n, h, w, H, W, c, p);
+    } else if (mode == 1) {
+        hipLaunchKernelGGL(assign_kernel<1>, dim3(ablk, BS), dim3(256), 0, st, feat, ldf, mask, ctr, A, n, h, w, H, W, c, 1);
+    } else {
+        hipLaunchKernelGGL(adjoint_mask_kernel, dim3(cdiv(2 * n, 256), BS), dim3(256), 0, st, mask, A, n, h, w, H, W);
+        hipLaunchKernelGGL(mask_sum_kernel, dim3(BS * 2), dim3(256), 0, st, mask, msum, H * W);
+    }
+    int e = launch_status("protos/assign");
+    if (e) return e;
+    hipLaunchKernelGGL(pool_partial_kernel, dim3(nck, BS), dim3(256), 0, st, feat, ldf, A, part, asum, n, c, J, nck);
+    hipLaunchKernelGGL(pool_final_kernel, dim3(J, B), dim3(256), 0, st, part, asum, mode == 2 ? msum : (const float*)nullptr,
+                       protos, S, c, J, nck, mode == 0 ? 1e-6f : 1e-5f);
+    return launch_status("protos/pool");
+}
+
+extern "C" int pemp_mpm_protos_f32(const float* feat, int ldf, const float* mask, const float* ctr, float* protos,
+                                   void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W, int c, int p,
+                                   void* stream) {
+    PEMP_REQUIRE(p >= 1 && p <= MAXJ / 2, "mpm_protos: p=%d not in 1..%d", p, MAXJ / 2);
+    return pooled_protos(0, feat, ldf, mask, ctr, protos, ws, ws_bytes, B, S, h, w, H, W, c, p, (hipStream_t)stream);
+}
+
+extern "C" int pemp_masked_avg_pool_f32(const float* feat, int ldf, const float* mask, float* protos, void* ws,
+                                        size_t ws_bytes, int B, int S, int h, int w, int H, int W, int c, int full_res,
+                                        void* stream) {
+    return pooled_protos(full_res ? 2 : 1, feat, ldf, mask, nullptr, protos, ws, ws_bytes, B, S, h, w, H, W, c, 1,
+                         (hipStream_t)stream);
+}
+
+extern "C" int pemp_cosine_proto_max_f32(const float* qry, int ldf, const float* protos, float* pred, uint8_t* resp,
+                                         int B, int n, int c, int p, float dist_scalar, void* stream) {
+    PEMP_REQUIRE(qry && protos && pred, "cosine: null pointer");
+    PEMP_REQUIRE(B > 0 && n > 0 && p >= 1 && 2 * p <= MAXJ, "cosine: bad dims");
+    PEMP_REQUIRE(c > 0 && c % 4 == 0 && c <= 64 * MAXCL && ldf >= c && ldf % 4 == 0, "cosine: c=%d must be a multiple of 4 and <= %d", c, 64 * MAXCL);
+    PEMP_REQUIRE(((uintptr_t)qry & 15) == 0, "cosine: qry must be 16-byte aligned");
+    hipLaunchKernelGGL(cosine_kernel, dim3(min(cdiv(n, 4), 1024), B), dim3(256), 0, (hipStream_t)stream, qry, ldf, protos,
+                       pred, resp, n, c, p, dist_scalar);
+    return launch_status("cosine");
+}
+
+extern "C" int pemp_upsample_bilinear_ac_f32(const float* pred, float* out, int B, int C, int h, int w, int Ho, int Wo,
+                                             void* stream) {
+    PEMP_REQUIRE(pred && out && B > 0 && C > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, "upsample: bad arguments");
+    long long total = (long long)B * C * Ho * Wo;
+    int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, out, B * C, h, w, Ho, Wo);
+    return launch_status("upsample_bilinear");
+}
+
+extern "C" int pemp_upsample_nearest_u8_i64(const uint8_t* resp, int64_t* out, int B, int h, int w, int Ho, int Wo,
+                                            void* stream) {
+    PEMP_REQUIRE(resp && out && B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, "upsample_nearest: bad arguments");
+    long long total = (long long)B * Ho * Wo;
+    int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, resp, out, B, h, w, Ho, Wo);
+    return launch_status("upsample_nearest");
+}
+
+extern "C" size_t pemp_eval_tail_workspace_bytes(int B, int Ho, int Wo) {
+    return (size_t)B * tail_blocks(Ho, Wo) * 8 * sizeof(double);
+}
+
+extern "C" int pemp_eval_tail_f32(const float* pred, const int64_t* target, uint8_t* pred_out, float* logits_out,
+                                  double* stats, void* ws, size_t ws_bytes, int B, int h, int w, int Ho, int Wo,
+                                  void* stream) {
+    PEMP_REQUIRE(pred && pred_out && stats && ws, "eval_tail: null pointer");
+    PEMP_REQUIRE(B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, "eval_tail: bad dims");
+    PEMP_REQUIRE(ws_bytes >= pemp_eval_tail_workspace_bytes(B, Ho, Wo), "eval_tail: workspace too small");
+    const int nb = tail_blocks(Ho, Wo);
+    hipLaunchKernelGGL(eval_tail_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, pred, target, pred_out,
+                       logits_out, (double*)ws, h, w, Ho, Wo);
+    hipLaunchKernelGGL(eval_tail_final_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const double*)ws, stats, nb);
+    return launch_status("eval_tail");
+}

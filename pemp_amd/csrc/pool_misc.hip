@@ -1,0 +1,250 @@
+// Streaming (HBM/L2-bound) helper kernels around the conv engine: input packing, max pooling,
+// global average pooling, multi-branch channel affine, ResNetCM statistics.  All NHWC, one
+// float4 (16 B) per lane wherever the channel count allows.
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+
+namespace pemp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_input_kernel(const float* __restrict__ img, const float* __restrict__ prior,
+                                  float4* __restrict__ out, int HW, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long n = i / HW;
+        int p = (int)(i - n * HW);
+        const float* b = img + n * 3 * HW + p;
+        float4 v;
+        v.x = b[0];
+        v.y = b[HW];
+        v.z = b[2 * (long long)HW];
+        v.w = prior ? prior[n * HW + p] : 0.f;
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// max pool, one thread per (pixel, 4 channels); window clipped to the input (padding never wins
+// because it is -inf in nn.MaxPool2d).
+__global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W,
+                               int C4, int ldx, int Ho, int Wo, int ldy, int k, int s, int p) {
+    long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        long long t = i / C4;
+        int wo = (int)(t % Wo);
+        t /= Wo;
+        int ho = (int)(t % Ho);
+        int n = (int)(t / Ho);
+        int h0 = ho * s - p, w0 = wo * s - p;
+        int h1 = min(h0 + k, H), w1 = min(w0 + k, W);
+        h0 = max(h0, 0);
+        w0 = max(w0, 0);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) {
+                float4 v = *(const float4*)(x + ((long long)(n * H + h) * W + w) * ldx + c4 * 4);
+                m.x = fmaxf(m.x, v.x);
+                m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z);
+                m.w = fmaxf(m.w, v.w);
+            }
+        *(float4*)(y + ((long long)(n * Ho + ho) * Wo + wo) * ldy + c4 * 4) = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// global average pool: block (n, channel group of 64): 256 threads = 4 pixel-lanes x 64 channels
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                  int HW, int C, int ldx) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int pl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C) {
+        const float* b = x + (long long)n * HW * ldx + c;
+        for (int i = pl; i < HW; i += 4) s += b[(long long)i * ldx];
+    }
+    red[pl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        y[(long long)n * C + c] = t / (float)HW;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct AffineMulti {
+    const float* scale[4];
+    const float* shift[4];
+    float* y[4];
+    int ldy[4];
+};
+
+__global__ void affine_multi_kernel(const float* __restrict__ x, int ldx, long long M, int C4, int nb,
+                                    AffineMulti a) {
+    long long total = M * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        long long m = i / C4;
+        float4 v = *(const float4*)(x + m * ldx + c4 * 4);
+        for (int b = 0; b < nb; ++b) {
+            float4 sc = *(const float4*)(a.scale[b] + c4 * 4);
+            float4 sh = *(const float4*)(a.shift[b] + c4 * 4);
+            float4 o;
+            o.x = v.x * sc.x + sh.x;
+            o.y = v.y * sc.y + sh.y;
+            o.z = v.z * sc.z + sh.z;
+            o.w = v.w * sc.w + sh.w;
+            *(float4*)(a.y[b] + m * a.ldy[b] + c4 * 4) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ResNetCM.comm statistics.  Kernel 1: mask' = max_pool2d(mask, 3, stride, 1).
+__global__ void mask_pool_kernel(const float* __restrict__ mi, float* __restrict__ mo, int N, int Hm, int Wm,
+                                 int Hx, int Wx, int s) {
+    long long total = (long long)N * Hx * Wx;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int wo = (int)(i % Wx);
+        long long t = i / Wx;
+        int ho = (int)(t % Hx);
+        int n = (int)(t / Hx);
+        int h0 = max(ho * s - 1, 0), h1 = min(ho * s + 2, Hm);
+        int w0 = max(wo * s - 1, 0), w1 = min(wo * s + 2, Wm);
+        float m = -INFINITY;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) m = fmaxf(m, mi[((long long)n * Hm + h) * Wm + w]);
+        mo[i] = m;
+    }
+}
+// Kernel 2: per (image, 64-channel group): mean over all pixels and max over pixels of x*mask'.
+__global__ __launch_bounds__(256) void cm_stat_kernel(const float* __restrict__ x, int ldx,
+                                                      const float* __restrict__ mask, float* __restrict__ stat,
+                                                      int HW, int C) {
+    __shared__ float rs[4][64], rm[4][64];
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int pl = threadIdx.x >> 6;
+    float s = 0.f, mx = -INFINITY;
+    if (c < C) {
+        const float* b = x + (long long)n * HW * ldx + c;
+        const float* mk = mask + (long long)n * HW;
+        for (int i = pl; i < HW; i += 4) {
+            float v = b[(long long)i * ldx] * mk[i];
+            s += v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    rs[pl][threadIdx.x & 63] = s;
+    rm[pl][threadIdx.x & 63] = mx;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        int t = threadIdx.x;
+        stat[((long long)n * 2 + 0) * C + c] = ((rs[0][t] + rs[1][t]) + (rs[2][t] + rs[3][t])) / (float)HW;
+        stat[((long long)n * 2 + 1) * C + c] = fmaxf(fmaxf(rm[0][t], rm[1][t]), fmaxf(rm[2][t], rm[3][t]));
+    }
+}
+
+static int grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace pemp
+
+using namespace pemp;
+
+extern "C" const char* pemp_last_error(void) { return g_err; }
+extern "C" int pemp_abi_version(void) { return PEMP_ABI_VERSION; }
+
+extern "C" int pemp_pack_input_nhwc4_f32(const float* img, const float* prior, float* out, int N, int H, int W,
+                                         void* stream) {
+    PEMP_REQUIRE(img && out && N > 0 && H > 0 && W > 0, "pack_input: bad arguments");
+    PEMP_REQUIRE(((uintptr_t)out & 15) == 0, "pack_input: out must be 16-byte aligned");
+    long long total = (long long)N * H * W;
+    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, prior,
+                       (float4*)out, H * W, total);
+    return launch_status("pack_input");
+}
+
+extern "C" int pemp_maxpool2d_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int ldx, int Ho, int Wo,
+                                       int ldy, int k, int s, int p, void* stream) {
+    PEMP_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "maxpool: bad arguments");
+    PEMP_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C, "maxpool: C/ldx/ldy must be multiples of 4");
+    PEMP_REQUIRE(k > 0 && s > 0 && p >= 0 && 2 * p <= k, "maxpool: bad window");
+    // floor and ceil_mode output sizes (ceil: last window must start inside input or left pad)
+    auto osz = [&](int in, bool ceil) {
+        int num = in + 2 * p - k;
+        int o = (ceil ? (num + s - 1) / s : num / s) + 1;
+        if (ceil && (o - 1) * s >= in + p) --o;
+        return o;
+    };
+    PEMP_REQUIRE((Ho == osz(H, false) || Ho == osz(H, true)) && (Wo == osz(W, false) || Wo == osz(W, true)),
+                 "maxpool: Ho/Wo (%d,%d) match neither floor (%d,%d) nor ceil (%d,%d) mode", Ho, Wo, osz(H, false),
+                 osz(W, false), osz(H, true), osz(W, true));
+    long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W,
+                       C / 4, ldx, Ho, Wo, ldy, k, s, p);
+    return launch_status("maxpool");
+}
+
+extern "C" int pemp_global_avgpool_nhwc_f32(const float* x, float* y, int N, int HW, int C, int ldx, void* stream) {
+    PEMP_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && ldx >= C, "global_avgpool: bad arguments");
+    hipLaunchKernelGGL(gap_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, (hipStream_t)stream, x, y, HW, C, ldx);
+    return launch_status("global_avgpool");
+}
+
+extern "C" int pemp_channel_affine_multi_f32(const float* x, int ldx, int M, int C, int nb, const float* const* scale,
+                                             const float* const* shift, float* const* y, const int* ldy,
+                                             void* stream) {
+    PEMP_REQUIRE(x && scale && shift && y && ldy, "channel_affine: null pointer");
+    PEMP_REQUIRE(nb >= 1 && nb <= 4, "channel_affine: nb=%d not in 1..4", nb);
+    PEMP_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldx >= C, "channel_affine: bad dims");
+    AffineMulti a;
+    memset(&a, 0, sizeof(a));
+    for (int b = 0; b < nb; ++b) {
+        PEMP_REQUIRE(scale[b] && shift[b] && y[b] && ldy[b] >= C && ldy[b] % 4 == 0, "channel_affine: bad branch %d", b);
+        a.scale[b] = scale[b];
+        a.shift[b] = shift[b];
+        a.y[b] = y[b];
+        a.ldy[b] = ldy[b];
+    }
+    long long total = (long long)M * (C / 4);
+    hipLaunchKernelGGL(affine_multi_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (long long)M, C / 4, nb, a);
+    return launch_status("channel_affine");
+}
+
+extern "C" int pemp_cm_reduce_f32(const float* x, int ldx, const float* mask_in, float* mask_out, float* stat, int N,
+                                  int Hm, int Wm, int Hx, int Wx, int C, int stride, void* stream) {
+    PEMP_REQUIRE(mask_in && mask_out && (stat || !x), "cm_reduce: null pointer");
+    PEMP_REQUIRE(N > 0 && (!x || (C > 0 && ldx >= C)) && (stride == 1 || stride == 2), "cm_reduce: bad dims");
+    PEMP_REQUIRE(Hx == (Hm + 2 - 3) / stride + 1 && Wx == (Wm + 2 - 3) / stride + 1,
+                 "cm_reduce: pooled mask (%d,%d)->(%d,%d) does not match feature size", Hm, Wm, Hx, Wx);
+    long long total = (long long)N * Hx * Wx;
+    hipLaunchKernelGGL(mask_pool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, mask_in,
+                       mask_out, N, Hm, Wm, Hx, Wx, stride);
+    int e = launch_status("cm_reduce/mask_pool");
+    if (e || !x) return e;
+    hipLaunchKernelGGL(cm_stat_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, (hipStream_t)stream, x, ldx, mask_out, stat,
+                       Hx * Wx, C);
+    return launch_status("cm_reduce/stat");
+}

@@ -1,0 +1,271 @@
+"""Execution engine: walks a parameter tree (pemp_amd.networks.backbones), packs it once into
+device-resident KRSC weights + folded per-channel affines, and runs the encoder as a chain of
+libpemp_hip.so launches on NHWC activations.
+
+Eval-mode arithmetic only in this round (BatchNorm folded with running statistics exactly like
+ATen's eval kernel: alpha = weight * rsqrt(var + eps), beta = bias - mean * alpha; DropBlock and
+Dropout2d are identities).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ConvParams
+
+BN_EPS = 1e-5
+
+
+def bn_affine(bn):
+    """(alpha, beta) of an eval-mode BatchNorm2d, fp32, on the BN's device."""
+    invstd = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    alpha = bn.weight.detach().float() * invstd
+    beta = bn.bias.detach().float() - bn.running_mean.detach().float() * alpha
+    return alpha.contiguous(), beta.contiguous()
+
+
+def conv_params(conv, bn=None, relu=False, stem4=False, in_slice=None):
+    """Pack one nn.Conv2d (+ following BN) for pemp_conv2d_nhwc_f32."""
+    w = conv.weight.detach()
+    if in_slice is not None:
+        w = w[:, in_slice[0]:in_slice[1]]
+    packed, kpad = ops.pack_conv_weight(w, stem4=stem4)
+    cout, cin = w.shape[0], w.shape[1]
+    scale = shift = None
+    if bn is not None:
+        scale, shift = bn_affine(bn)
+        if conv.bias is not None:
+            shift = shift + conv.bias.detach().float() * scale
+    elif conv.bias is not None:
+        shift = conv.bias.detach().float().contiguous()
+    return ConvParams(packed.contiguous(), scale, shift, 4 if stem4 else cin, cout, conv.kernel_size[0],
+                      conv.kernel_size[1], conv.stride[0], conv.padding[0], conv.dilation[0], kpad, stem4, relu)
+
+
+class Arena:
+    """Named activation buffers reused across calls (static addresses make hipGraph replay valid)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+        self.ws = {}
+
+    def get(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        return t
+
+
+class _BlockPlan:
+    def __init__(self, blk, extra_in=0):
+        # extra_in: the CM variant's two spatially-constant channels are applied as a per-image
+        # bias (see ResNetCMEngine), so the packed weights cover only the real channels.
+        sl = None
+        if extra_in:
+            sl = (0, blk.conv1.weight.shape[1] - extra_in)
+        self.c1 = conv_params(blk.conv1, blk.bn1, relu=True, in_slice=sl)
+        self.c2 = conv_params(blk.conv2, blk.bn2, relu=True)
+        self.c3 = conv_params(blk.conv3, blk.bn3, relu=True)     # relu after the residual add
+        self.ds = conv_params(blk.downsample[0], blk.downsample[1], relu=False, in_slice=sl) \
+            if blk.downsample is not None else None
+        if extra_in:
+            # weights of the extra channels, pre-multiplied by the BN alpha: [Cout, extra]
+            self.c1_extra = (blk.conv1.weight.detach()[:, sl[1]:, 0, 0].float() * self.c1.scale[:, None]).contiguous()
+            self.ds_extra = (blk.downsample[0].weight.detach()[:, sl[1]:, 0, 0].float() * self.ds.scale[:, None]).contiguous()
+
+
+class ResNetEngine:
+    """ResNet trunk (reference: networks/backbones.py:124-136)."""
+
+    def __init__(self, prm, arena):
+        self.arena = arena
+        self.stem = conv_params(prm.conv1, prm.bn1, relu=True, stem4=True)
+        self.stages = []
+        for name in ("layer1", "layer2", "layer3"):
+            self.stages.append([_BlockPlan(b) for b in getattr(prm, name)])
+
+    def _block(self, x, bp, tag, c1_shift=None, ds_shift=None):
+        a = self.arena
+        n, h, w, _ = x.shape
+        ho = ops.conv_out_size(h, 1, bp.c1.stride, 0, 1)
+        wo = ops.conv_out_size(w, 1, bp.c1.stride, 0, 1)
+        y1 = ops.conv2d(x, bp.c1, out=a.get("y1", (n, ho, wo, bp.c1.cout)),
+                        shift_override=c1_shift, per_image_shift=c1_shift is not None)
+        y2 = ops.conv2d(y1, bp.c2, out=a.get("y2", (n, ho, wo, bp.c2.cout)))
+        if bp.ds is not None:
+            res = ops.conv2d(x, bp.ds, out=a.get("res", (n, ho, wo, bp.ds.cout)),
+                             shift_override=ds_shift, per_image_shift=ds_shift is not None)
+        else:
+            res = x
+        return ops.conv2d(y2, bp.c3, out=a.get(("blk", tag), (n, ho, wo, bp.c3.cout)), residual=res)
+
+    def stem_forward(self, x4):
+        a = self.arena
+        n, h, w, _ = x4.shape
+        ho, wo = ops.conv_out_size(h, 7, 2, 3, 1), ops.conv_out_size(w, 7, 2, 3, 1)
+        y = ops.conv2d(x4, self.stem, out=a.get("stem", (n, ho, wo, 64)))
+        hp, wp = ops._pool_out(ho, 3, 2, 1, True), ops._pool_out(wo, 3, 2, 1, True)
+        return ops.maxpool2d(y, 3, 2, 1, ceil_mode=True, out=a.get("pool", (n, hp, wp, 64)))
+
+    def forward(self, x4):
+        x = self.stem_forward(x4)
+        for si, blocks in enumerate(self.stages):
+            for bi, bp in enumerate(blocks):
+                x = self._block(x, bp, (si, bi & 1))
+        return x
+
+
+class ResNetCMEngine(ResNetEngine):
+    """ResNetCM (reference: networks/backbones.py:208-247).
+
+    The communication module appends two channels that are CONSTANT over space (and over the
+    S+Q images of an episode) before each stage.  A 1x1 conv over a constant channel is a
+    per-image bias, so instead of concatenating, the first block of each stage receives
+    ``shift[img][co] = beta[co] + alpha[co] * sum_e W[co][C+e] * feat[img][e]``.
+    """
+
+    def __init__(self, prm, arena):
+        self.arena = arena
+        self.spq = prm.spq
+        self.stem = conv_params(prm.conv1, prm.bn1, relu=True, stem4=True)
+        self.stages = []
+        for name in ("layer1", "layer2", "layer3"):
+            blocks = list(getattr(prm, name))
+            self.stages.append([_BlockPlan(blocks[0], extra_in=2)] + [_BlockPlan(b) for b in blocks[1:]])
+        self.lin = [(l.weight.detach().float().contiguous(), l.bias.detach().float().contiguous())
+                    for l in (prm.linear1, prm.linear2, prm.linear3)]
+        self.group = None   # LongTensor [N]: episode id of every image (set by the caller)
+
+    def _comm(self, x, mask, lin, stride):
+        """-> (feat [N,2] per image, pooled mask).  Statistics on HIP, the 2c->2 GEMV in torch."""
+        mask, stat = ops.cm_reduce(x, mask, stride)
+        n, _, c = stat.shape
+        g = self.group
+        ng = int(g.max().item()) + 1 if g.numel() else 0
+        agg = torch.zeros((ng, 2 * c), dtype=torch.float32, device=x.device)
+        cnt = torch.zeros((ng, 1), dtype=torch.float32, device=x.device)
+        agg.index_add_(0, g, stat.reshape(n, 2 * c))
+        cnt.index_add_(0, g, torch.ones((n, 1), device=x.device))
+        feat = torch.addmm(lin[1], agg / cnt, lin[0].t())     # [episodes, 2]
+        return feat[g], mask
+
+    def forward(self, x4, prior):
+        """x4: NHWC4 input (RGB + prior); prior: [N,H,W] fp32 mask plane."""
+        mask = ops.cm_reduce(None, prior, 2)[0]                       # backbones.py:227
+        x = self.stem_forward(x4)
+        strides = (2, 1, 2)                                           # backbones.py:230,235,240
+        for si, blocks in enumerate(self.stages):
+            feat, mask = self._comm(x, mask, self.lin[si], strides[si])
+            b0 = blocks[0]
+            c1_shift = (b0.c1.shift[None, :] + feat @ b0.c1_extra.t()).contiguous()
+            ds_shift = (b0.ds.shift[None, :] + feat @ b0.ds_extra.t()).contiguous()
+            x = self._block(x, b0, (si, 0), c1_shift, ds_shift)
+            for bi, bp in enumerate(blocks[1:], start=1):
+                x = self._block(x, bp, (si, bi & 1))
+        return x
+
+
+class ASPPV2Engine:
+    """purifier.6 of stage 1 (reference: networks/backbones.py:359-369)."""
+
+    def __init__(self, prm, arena):
+        self.arena = arena
+        self.bn = [bn_affine(getattr(prm, f"aspp_{i}")[0]) for i in range(5)]
+        self.br = [conv_params(getattr(prm, f"aspp_{i}")[2], None, relu=True) for i in range(5)]
+        midc = self.br[0].cout
+        l6 = prm.layer6
+        # layer6 split: columns of the broadcast global branch -> per-image bias; the rest -> 1x1 conv
+        self.l6_global = conv_params(l6, None, relu=False, in_slice=(0, midc))
+        self.l6_main = conv_params(l6, None, relu=False, in_slice=(midc, 5 * midc))
+        self.l6_main.shift = None
+        self.midc = midc
+
+    def forward(self, x):
+        a = self.arena
+        n, h, w, c = x.shape
+        midc = self.midc
+        g = ops.global_avgpool(x, out=a.get("gap", (n, c)))
+        gb = a.get("gap_bn", (n, c))
+        ops.channel_affine_multi(g, [self.bn[0][0]], [self.bn[0][1]], [gb])
+        g2 = ops.conv2d(gb.view(n, 1, 1, c), self.br[0], out=a.get("gap_c", (n, 1, 1, midc)))
+        bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
+        xb = [a.get(("aspp_in", i), (n, h, w, c)) for i in range(4)]
+        ops.channel_affine_multi(x, [s for s, _ in self.bn[1:]], [t for _, t in self.bn[1:]], xb)
+        cat = a.get("aspp_cat", (n, h, w, 4 * midc))
+        for i in range(4):
+            ops.conv2d(xb[i], self.br[i + 1], out=cat[..., i * midc:(i + 1) * midc])
+        return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),
+                          shift_override=bias6.view(n, -1), per_image_shift=True)
+
+
+class ASPPEngine:
+    """purifier.6 of stage 2: conv -> ReLU per branch, no BN (reference: backbones.py:310-321)."""
+
+    def __init__(self, prm, arena):
+        self.arena = arena
+        self.br = [conv_params(getattr(prm, f"aspp_{i}")[0], None, relu=True) for i in range(5)]
+        midc = self.br[0].cout
+        self.l6_global = conv_params(prm.layer6, None, relu=False, in_slice=(0, midc))
+        self.l6_main = conv_params(prm.layer6, None, relu=False, in_slice=(midc, 5 * midc))
+        self.l6_main.shift = None
+        self.midc = midc
+
+    def forward(self, x):
+        a = self.arena
+        n, h, w, c = x.shape
+        midc = self.midc
+        g = ops.global_avgpool(x, out=a.get("gap", (n, c)))
+        g2 = ops.conv2d(g.view(n, 1, 1, c), self.br[0], out=a.get("gap_c", (n, 1, 1, midc)))
+        bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
+        cat = a.get("aspp_cat", (n, h, w, 4 * midc))
+        for i in range(4):
+            ops.conv2d(x, self.br[i + 1], out=cat[..., i * midc:(i + 1) * midc])
+        return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),
+                          shift_override=bias6.view(n, -1), per_image_shift=True)
+
+
+class PurifierEngine:
+    def __init__(self, seq, arena):
+        self.arena = arena
+        self.p0 = conv_params(seq[0], None, relu=True)
+        self.p3 = conv_params(seq[3], None, relu=True)
+        aspp = seq[6]
+        self.aspp = ASPPV2Engine(aspp, arena) if isinstance(aspp.aspp_0[0], nn.BatchNorm2d) else ASPPEngine(aspp, arena)
+
+    def forward(self, x):
+        a = self.arena
+        n, h, w, _ = x.shape
+        y = ops.conv2d(x, self.p0, out=a.get("pur0", (n, h, w, self.p0.cout)))
+        y = ops.conv2d(y, self.p3, out=a.get("pur3", (n, h, w, self.p3.cout)))
+        return self.aspp.forward(y)
+
+
+class VGG16Engine:
+    """VGG16 trunk (reference: networks/backbones.py:404-405)."""
+
+    def __init__(self, prm, arena):
+        from .networks.backbones import VGG_LAYOUT
+        self.arena = arena
+        self.steps = []
+        for item in VGG_LAYOUT:
+            if isinstance(item, tuple):
+                idx, _, _, _, relu = item
+                conv = prm.features[idx]
+                relu = relu or prm.last_relu
+                self.steps.append(conv_params(conv, None, relu=relu, stem4=(idx == 0)))
+            else:
+                self.steps.append(item)
+
+    def forward(self, x4):
+        a = self.arena
+        x = x4
+        for i, st in enumerate(self.steps):
+            n, h, w, _ = x.shape
+            if isinstance(st, ConvParams):
+                x = ops.conv2d(x, st, out=a.get(("vgg", i & 1, st.cout), (n, h, w, st.cout)))
+            else:
+                ho, wo = ops._pool_out(h, 3, st, 1, False), ops._pool_out(w, 3, st, 1, False)
+                x = ops.maxpool2d(x, 3, st, 1, out=a.get(("vggp", i), (n, ho, wo, x.shape[3])))
+        return x

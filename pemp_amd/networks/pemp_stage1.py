@@ -1,0 +1,188 @@
+"""PEMP stage 1 on MI355X: drop-in for the reference's ``networks/pemp_stage1.py``.
+
+Same module surface (``net_ingredient``, ``ModelClass``, ``PEMPStage1``, ``pretrained_weights``,
+``backbone_error``), same constructor / ``forward`` signature and ``state_dict`` keys
+(reference: networks/pemp_stage1.py:11-18,21-37,54-109,111-163,264); the arithmetic runs on
+libpemp_hip.so through ``pemp_amd.engine`` / ``pemp_amd.ops`` and raises if that library is
+missing or the tensors are not on the GPU.
+"""
+from collections import OrderedDict
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from .. import engine, ops
+from ..config import Ingredient
+from . import backbones
+
+net_ingredient = Ingredient("net", save_git_info=False)
+pretrained_weights = {
+    "vgg16": Path(__file__).parents[2] / "data/vgg16-397923af.pth",
+    "resnet50": Path(__file__).parents[2] / "data/resnet50-19c8e357.pth",
+    "resnet101": Path(__file__).parents[2] / "data/resnet101-5d3b4d8f.pth",
+}
+backbone_error = "Not supported backbone '{}'. [vgg16, resnet50, resnet101]"
+_RES_LAYERS = {"resnet50": (3, 4, 6), "resnet101": (3, 4, 23)}
+
+
+@net_ingredient.config
+def net_config():
+    dist_scalar = 20            # int, factor multiplied to the cosine similarity
+    init_channels = 3           # int, input channels of the model
+    out_channels = 512          # int, output channels of the feature extractor
+    backbone = "resnet50"       # str, [vgg16, resnet50, resnet101]
+    protos = 3                  # int, prototypes per class (0: plain masked average pooling)
+    drop_rate = 0.1             # float, DropBlock rate of the purifier (train only)
+    block_size = 4              # int, DropBlock block size (train only)
+
+
+@net_ingredient.config_hook
+def net_hook(config, command_name, logger):
+    if config["net"]["backbone"] not in pretrained_weights:
+        raise ValueError(backbone_error.format(config["net"]["backbone"]))
+    return {}
+
+
+def import_torchvision_trunk(trunk, path, resnet=True):
+    """Pretrained import rules of the reference: ResNet copies torchvision keys up to the first
+    ``layer4.*`` (networks/backbones.py:138-157); VGG copies the first 26 tensors (:412-421)."""
+    pre = torch.load(str(path), map_location="cpu")
+    cur = trunk.state_dict()
+    if resnet:
+        for key in pre:
+            if key.split(".")[0] in ("layer4", "fc"):
+                break
+            cur[key] = pre[key]
+    else:
+        ck, pk = list(cur.keys()), list(pre.keys())
+        for i in range(26):
+            cur[ck[i]] = pre[pk[i]]
+    trunk.load_state_dict(cur)
+
+
+class _HeadMixin:
+    """Episode head shared by stage 1 / stage 2 / baseline: prototypes -> cosine map -> upsample."""
+
+    def _engine_for(self, device):
+        eng = self.__dict__.get("_engine")
+        if eng is None or eng["device"] != device:
+            arena = engine.Arena(device)
+            eng = {"device": device, "arena": arena}
+            self._build_engine(eng, arena)
+            self.__dict__["_engine"] = eng
+        return eng
+
+    @staticmethod
+    def _require_eval_gpu(model, *tensors):
+        if model.training:
+            raise NotImplementedError(
+                "pemp_amd: the training (batch-statistics BN / DropBlock / backward) path is not built yet; "
+                "call model.eval()")
+        for t in tensors:
+            if not t.is_cuda:
+                raise RuntimeError("pemp_amd: inputs must live on the GPU; there is no CPU fallback")
+
+    def _head(self, eng, feats, sup_mask, B, S, Q, protos, dist_scalar, ret_ind, ctr):
+        """feats: NHWC [B*S + B*Q, h, w, c] (supports first).  -> pred [BQ,2,h,w] (+ resp uint8)."""
+        if Q != 1:
+            raise ValueError("query must be 1 (the reference's broadcasting requires it, pemp_stage1.py:197,257)")
+        ws = eng["arena"].ws
+        sup, qry = feats[:B * S], feats[B * S:]
+        H, W = sup_mask.shape[-2:]
+        msk = sup_mask.reshape(B * S, 2, H, W).contiguous()
+        if protos > 0:
+            pro = ops.mpm_protos(sup, msk, ctr, B, S, protos, ws_cache=ws)
+        else:
+            pro = ops.masked_avg_pool(sup, msk, B, S, full_res=False, ws_cache=ws)
+        self.__dict__["_last_protos"] = pro
+        return ops.cosine_proto_max(qry, pro, dist_scalar, want_resp=ret_ind)
+
+    @staticmethod
+    def _finish(pred, resp, out_shape):
+        out = ops.upsample_bilinear_ac(pred, out_shape)
+        if resp is None:
+            return out
+        return out, ops.upsample_nearest_u8_i64(resp, out_shape)
+
+
+class PEMPStage1(_HeadMixin, backbones.BaseModel):
+    """Stage 1 of the Prior-Enhanced network with Meta-Prototypes (reference class of the same name)."""
+
+    @net_ingredient.capture
+    def __init__(self, logger, backbone, init_channels, out_channels, protos, drop_rate, block_size):
+        super().__init__()
+        if backbone not in pretrained_weights:
+            raise ValueError(backbone_error.format(backbone))
+        pretrained = pretrained_weights[backbone]
+        self.backbone_name = backbone
+        if backbone == "vgg16":
+            trunk = backbones.VGG16Params(init_channels, last_relu=False)
+            self.encoder = nn.Sequential(OrderedDict([("backbone", trunk)]))
+            self.__class__.__name__ = "PEMP_Stage1/VGG16"
+        else:
+            trunk = backbones.ResNetParams(init_channels, _RES_LAYERS[backbone], freeze_bn=True)
+            self.encoder = nn.Sequential(OrderedDict([
+                ("backbone", trunk), ("purifier", backbones.purifier_params(out_channels, v2=True))]))
+            self.__class__.__name__ = "PEMP_Stage1/Resnet50" if backbone == "resnet50" else "PEMP_stage1/Resnet101"
+        if pretrained is not None and Path(pretrained).exists():
+            import_torchvision_trunk(trunk, pretrained, resnet=backbone != "vgg16")
+        elif logger is not None:
+            logger.info(f"           ==> pretrained file {pretrained} not found: backbone left at random init")
+        self.ctr = nn.Parameter(torch.rand(out_channels, protos * 2), requires_grad=True) if protos > 0 else None
+        if logger is not None:
+            logger.info(f"           ==> Model {self.__class__.__name__} created")
+
+    # -- engine --------------------------------------------------------------------------------
+    def _build_engine(self, eng, arena):
+        bb = self.encoder.backbone
+        if self.backbone_name == "vgg16":
+            eng["trunk"] = engine.VGG16Engine(bb, arena)
+            eng["purifier"] = None
+        else:
+            eng["trunk"] = engine.ResNetEngine(bb, arena)
+            eng["purifier"] = engine.PurifierEngine(self.encoder.purifier, arena)
+        eng["ctr"] = self.ctr.detach().float().contiguous() if self.ctr is not None else None
+
+    def encode(self, *image_groups):
+        """One or more [n_i,3,H,W] fp32 device tensors -> NHWC features [sum n_i,h,w,c] (in order)."""
+        dev = image_groups[0].device
+        eng = self._engine_for(dev)
+        n = sum(g.shape[0] for g in image_groups)
+        H, W = image_groups[0].shape[-2:]
+        x4 = eng["arena"].get("x4", (n, H, W, 4))
+        o = 0
+        for g in image_groups:
+            ops.pack_input(g.contiguous(), out=x4[o:o + g.shape[0]])
+            o += g.shape[0]
+        f = eng["trunk"].forward(x4)
+        return eng["purifier"].forward(f) if eng["purifier"] is not None else f
+
+    # -- API -----------------------------------------------------------------------------------
+    @net_ingredient.capture
+    def forward(self, sup_img, sup_mask, qry_img, out_shape=None, ret_ind=False, protos=3, dist_scalar=20):
+        """Same contract as the reference (pemp_stage1.py:111-163): returns logits [BQ,2,Ho,Wo]
+        (+ int64 response map [BQ,Ho,Wo] when ``ret_ind``)."""
+        self._require_eval_gpu(self, sup_img, sup_mask, qry_img)
+        pred, resp = self.lowres(sup_img, sup_mask, qry_img, ret_ind, protos, dist_scalar)
+        H, W = sup_img.shape[-2:]
+        return self._finish(pred, resp, out_shape if out_shape is not None else (H, W))
+
+    def lowres(self, sup_img, sup_mask, qry_img, ret_ind=False, protos=None, dist_scalar=None):
+        """Feature-resolution prediction [BQ,2,h,w] (+ uint8 response) -- everything before the
+        final F.interpolate; shape-static, so it is what gets captured into a hipGraph."""
+        cfg = net_ingredient.cfg
+        protos = cfg["protos"] if protos is None else protos
+        dist_scalar = cfg["dist_scalar"] if dist_scalar is None else dist_scalar
+        if (self.ctr is None) != (protos == 0):
+            protos = 0 if self.ctr is None else self.ctr.shape[1] // 2
+        B, S, ch, H, W = sup_img.shape
+        Q = qry_img.shape[1]
+        eng = self._engine_for(sup_img.device)
+        feats = self.encode(sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W))
+        self.__dict__["_last_feats"] = feats
+        out = self._head(eng, feats, sup_mask, B, S, Q, protos, dist_scalar, ret_ind, eng["ctr"])
+        return out if ret_ind else (out, None)
+
+
+ModelClass = PEMPStage1

@@ -1,0 +1,295 @@
+"""Tensor-level wrappers over the C ABI (include/pemp_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current stream; every function passes
+raw device pointers + the current HIP stream to libpemp_hip.so.  Activations are NHWC fp32
+tensors ``[N,H,W,C]`` whose last-dim stride is 1; a channel slice of a wider buffer is passed
+as a view (its pixel stride ``ld`` is taken from ``stride(2)``).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, CONV_RELU, CONV_SHIFT_PER_IMAGE, CONV_STEM4  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda):
+            raise _lib.PempHipError("pemp_amd ops need device (cuda/HIP) tensors; there is no CPU path")
+
+
+def _nhwc(t, name):
+    if t.dim() != 4 or t.dtype != torch.float32 or t.stride(3) != 1:
+        raise ValueError(f"{name}: expected fp32 NHWC view with unit channel stride, got {tuple(t.shape)} {t.dtype} {t.stride()}")
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    if (w > 1 and t.stride(1) != w * ld) or (h > 1 and n > 1 and t.stride(0) != h * w * ld):
+        raise ValueError(f"{name}: pixels must be densely packed with stride ld={ld}, got strides {t.stride()}")
+    return ld
+
+
+def conv_out_size(i, k, s, p, d):
+    return (i + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+class ConvParams:
+    """Device-resident, pre-packed parameters of one conv (+ folded per-channel affine)."""
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "kh", "kw", "stride", "pad", "dil", "kpad", "stem", "relu")
+
+    def __init__(self, w, scale, shift, cin, cout, kh, kw, stride, pad, dil, kpad, stem, relu):
+        self.w, self.scale, self.shift = w, scale, shift
+        self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
+        self.stride, self.pad, self.dil, self.kpad, self.stem, self.relu = stride, pad, dil, kpad, stem, relu
+
+
+def pack_conv_weight(w_oihw, stem4=False):
+    """[Cout,Cin,KH,KW] -> KRSC [Cout, Kpad] (Cin contiguous).  STEM4: Cin padded to 4, row padded x32."""
+    co, ci, kh, kw = w_oihw.shape
+    w = w_oihw.detach().permute(0, 2, 3, 1).contiguous().float()     # [co,kh,kw,ci]
+    if stem4:
+        if ci > 4:
+            raise ValueError("stem4 packing needs Cin <= 4")
+        k = kh * kw * 4
+        kpad = (k + 31) // 32 * 32
+        out = torch.zeros(co, kpad, dtype=torch.float32, device=w.device)
+        tmp = torch.zeros(co, kh, kw, 4, dtype=torch.float32, device=w.device)
+        tmp[..., :ci] = w
+        out[:, :k] = tmp.reshape(co, k)
+        return out, kpad
+    return w.reshape(co, kh * kw * ci), kh * kw * ci
+
+
+def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=False, relu=None, tile=0):
+    """y = act(scale * conv(x, w) + shift (+ residual)).  x: NHWC view, returns NHWC tensor/view ``out``."""
+    lib = _lib.load()
+    _chk_dev(x, p.w, out, residual)
+    ldx = _nhwc(x, "x")
+    n, h, w, cin = x.shape
+    if cin != p.cin:
+        raise ValueError(f"conv2d: input has {cin} channels, layer expects {p.cin}")
+    ho = conv_out_size(h, p.kh, p.stride, p.pad, p.dil)
+    wo = conv_out_size(w, p.kw, p.stride, p.pad, p.dil)
+    if out is None:
+        out = torch.empty((n, ho, wo, p.cout), dtype=torch.float32, device=x.device)
+    ldy = _nhwc(out, "out")
+    if tuple(out.shape) != (n, ho, wo, p.cout):
+        raise ValueError(f"conv2d: out shape {tuple(out.shape)} != {(n, ho, wo, p.cout)}")
+    ldr = 0
+    if residual is not None:
+        ldr = _nhwc(residual, "residual")
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError("conv2d: residual shape mismatch")
+    shift = p.shift if shift_override is None else shift_override
+    flags = 0
+    if (p.relu if relu is None else relu):
+        flags |= CONV_RELU
+    if per_image_shift:
+        flags |= CONV_SHIFT_PER_IMAGE
+    if p.stem:
+        flags |= CONV_STEM4
+    d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, flags, tile)
+    _lib.check(lib.pemp_conv2d_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift),
+                                        _p(residual), _stream()), "pemp_conv2d_nhwc_f32")
+    return out
+
+
+def pack_input(img_nchw, prior=None, out=None):
+    """[N,3,H,W] (+ [N,1,H,W] prior) -> NHWC4."""
+    lib = _lib.load()
+    _chk_dev(img_nchw, prior)
+    n, c, h, w = img_nchw.shape
+    if c != 3 or img_nchw.dtype != torch.float32 or not img_nchw.is_contiguous():
+        raise ValueError("pack_input: expected contiguous fp32 [N,3,H,W]")
+    if prior is not None and (prior.dtype != torch.float32 or not prior.is_contiguous() or prior.numel() != n * h * w):
+        raise ValueError("pack_input: prior must be contiguous fp32 [N,1,H,W]")
+    if out is None:
+        out = torch.empty((n, h, w, 4), dtype=torch.float32, device=img_nchw.device)
+    _lib.check(lib.pemp_pack_input_nhwc4_f32(_p(img_nchw), _p(prior), _p(out), n, h, w, _stream()), "pack_input")
+    return out
+
+
+def _pool_out(i, k, s, p, ceil):
+    num = i + 2 * p - k
+    o = (-(-num // s) if ceil else num // s) + 1
+    if ceil and (o - 1) * s >= i + p:
+        o -= 1
+    return o
+
+
+def maxpool2d(x, k, s, p, ceil_mode=False, out=None):
+    lib = _lib.load()
+    _chk_dev(x)
+    ldx = _nhwc(x, "x")
+    n, h, w, c = x.shape
+    ho, wo = _pool_out(h, k, s, p, ceil_mode), _pool_out(w, k, s, p, ceil_mode)
+    if out is None:
+        out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+    ldy = _nhwc(out, "out")
+    _lib.check(lib.pemp_maxpool2d_nhwc_f32(_p(x), _p(out), n, h, w, c, ldx, ho, wo, ldy, k, s, p, _stream()), "maxpool2d")
+    return out
+
+
+def global_avgpool(x, out=None):
+    lib = _lib.load()
+    _chk_dev(x)
+    ldx = _nhwc(x, "x")
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _lib.check(lib.pemp_global_avgpool_nhwc_f32(_p(x), _p(out), n, h * w, c, ldx, _stream()), "global_avgpool")
+    return out
+
+
+def channel_affine_multi(x, scales, shifts, outs):
+    """outs[b] = x * scales[b] + shifts[b] (per channel), up to 4 branches sharing one read of x."""
+    lib = _lib.load()
+    _chk_dev(x, *outs)
+    nb = len(outs)
+    if x.dim() == 2:
+        m, c, ldx = x.shape[0], x.shape[1], x.stride(0)
+        ldy = [o.stride(0) for o in outs]
+    else:
+        ldx = _nhwc(x, "x")
+        m, c = x.shape[0] * x.shape[1] * x.shape[2], x.shape[3]
+        ldy = [_nhwc(o, "out") for o in outs]
+    arr = C.c_void_p * nb
+    _lib.check(lib.pemp_channel_affine_multi_f32(
+        _p(x), ldx, m, c, nb, arr(*[s.data_ptr() for s in scales]), arr(*[s.data_ptr() for s in shifts]),
+        arr(*[o.data_ptr() for o in outs]), (C.c_int * nb)(*ldy), _stream()), "channel_affine_multi")
+    return outs
+
+
+def _ws(nbytes, device, cache=None, key=None):
+    if cache is not None:
+        t = cache.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            cache[key] = t
+        return t
+    return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+
+
+def mpm_protos(sup_feat, sup_mask, ctr, B, S, p, ws_cache=None, out=None):
+    """sup_feat [B*S,h,w,c] NHWC; sup_mask [B*S,2,H,W]; ctr [c,2p] -> protos [B,2p,c]."""
+    lib = _lib.load()
+    _chk_dev(sup_feat, sup_mask, ctr)
+    ldf = _nhwc(sup_feat, "sup_feat")
+    bs, h, w, c = sup_feat.shape
+    H, W = sup_mask.shape[-2:]
+    if bs != B * S or sup_mask.numel() != bs * 2 * H * W or not sup_mask.is_contiguous() or sup_mask.dtype != torch.float32:
+        raise ValueError("mpm_protos: sup_mask must be contiguous fp32 [B*S,2,H,W]")
+    if tuple(ctr.shape) != (c, 2 * p) or not ctr.is_contiguous():
+        raise ValueError(f"mpm_protos: ctr must be contiguous [{c},{2 * p}]")
+    nbytes = lib.pemp_mpm_workspace_bytes(B, S, h * w, c, p)
+    ws = _ws(nbytes, sup_feat.device, ws_cache, ("mpm", B, S, h, w, c, p))
+    if out is None:
+        out = torch.empty((B, 2 * p, c), dtype=torch.float32, device=sup_feat.device)
+    _lib.check(lib.pemp_mpm_protos_f32(_p(sup_feat), ldf, _p(sup_mask), _p(ctr), _p(out), _p(ws), ws.numel(),
+                                       B, S, h, w, H, W, c, p, _stream()), "mpm_protos")
+    return out
+
+
+def masked_avg_pool(sup_feat, sup_mask, B, S, full_res, ws_cache=None, out=None):
+    """-> protos [B,2,c] (row 0 fg, row 1 bg).  full_res=True is the Baseline form."""
+    lib = _lib.load()
+    _chk_dev(sup_feat, sup_mask)
+    ldf = _nhwc(sup_feat, "sup_feat")
+    bs, h, w, c = sup_feat.shape
+    H, W = sup_mask.shape[-2:]
+    if bs != B * S or sup_mask.numel() != bs * 2 * H * W or not sup_mask.is_contiguous() or sup_mask.dtype != torch.float32:
+        raise ValueError("masked_avg_pool: sup_mask must be contiguous fp32 [B*S,2,H,W]")
+    nbytes = lib.pemp_map_workspace_bytes(B, S, h * w, c)
+    ws = _ws(nbytes, sup_feat.device, ws_cache, ("map", B, S, h, w, c))
+    if out is None:
+        out = torch.empty((B, 2, c), dtype=torch.float32, device=sup_feat.device)
+    _lib.check(lib.pemp_masked_avg_pool_f32(_p(sup_feat), ldf, _p(sup_mask), _p(out), _p(ws), ws.numel(),
+                                            B, S, h, w, H, W, c, 1 if full_res else 0, _stream()), "masked_avg_pool")
+    return out
+
+
+def cosine_proto_max(qry_feat, protos, dist_scalar, want_resp=False, pred=None, resp=None):
+    """qry_feat [B,h,w,c]; protos [B,2p,c] -> pred [B,2,h,w] (+ resp uint8 [B,h,w])."""
+    lib = _lib.load()
+    _chk_dev(qry_feat, protos)
+    ldf = _nhwc(qry_feat, "qry_feat")
+    b, h, w, c = qry_feat.shape
+    if protos.shape[0] != b or protos.shape[2] != c or not protos.is_contiguous():
+        raise ValueError("cosine_proto_max: protos must be contiguous [B,2p,c]")
+    p = protos.shape[1] // 2
+    if pred is None:
+        pred = torch.empty((b, 2, h, w), dtype=torch.float32, device=qry_feat.device)
+    if want_resp and resp is None:
+        resp = torch.empty((b, h, w), dtype=torch.uint8, device=qry_feat.device)
+    _lib.check(lib.pemp_cosine_proto_max_f32(_p(qry_feat), ldf, _p(protos), _p(pred), _p(resp if want_resp else None),
+                                             b, h * w, c, p, float(dist_scalar), _stream()), "cosine_proto_max")
+    return (pred, resp) if want_resp else pred
+
+
+def upsample_bilinear_ac(pred, out_hw):
+    lib = _lib.load()
+    _chk_dev(pred)
+    b, c, h, w = pred.shape
+    ho, wo = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=pred.device)
+    _lib.check(lib.pemp_upsample_bilinear_ac_f32(_p(pred.contiguous()), _p(out), b, c, h, w, ho, wo, _stream()),
+               "upsample_bilinear_ac")
+    return out
+
+
+def upsample_nearest_u8_i64(resp, out_hw):
+    lib = _lib.load()
+    _chk_dev(resp)
+    b, h, w = resp.shape
+    ho, wo = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((b, ho, wo), dtype=torch.int64, device=resp.device)
+    _lib.check(lib.pemp_upsample_nearest_u8_i64(_p(resp.contiguous()), _p(out), b, h, w, ho, wo, _stream()),
+               "upsample_nearest")
+    return out
+
+
+def eval_tail(pred, target, want_logits=False, ws_cache=None):
+    """pred [B,2,h,w]; target int64 [B,Ho,Wo] -> (argmax uint8 [B,Ho,Wo], stats f64 [B,8], logits|None)."""
+    lib = _lib.load()
+    _chk_dev(pred, target)
+    b, c, h, w = pred.shape
+    if c != 2 or not pred.is_contiguous():
+        raise ValueError("eval_tail: pred must be contiguous [B,2,h,w]")
+    if target.dtype != torch.int64 or not target.is_contiguous() or target.shape[0] != b:
+        raise ValueError("eval_tail: target must be contiguous int64 [B,Ho,Wo]")
+    ho, wo = target.shape[-2:]
+    am = torch.empty((b, ho, wo), dtype=torch.uint8, device=pred.device)
+    stats = torch.empty((b, 8), dtype=torch.float64, device=pred.device)
+    logits = torch.empty((b, 2, ho, wo), dtype=torch.float32, device=pred.device) if want_logits else None
+    nbytes = lib.pemp_eval_tail_workspace_bytes(b, ho, wo)
+    ws = _ws(nbytes, pred.device, ws_cache, ("tail", b, ho, wo))
+    _lib.check(lib.pemp_eval_tail_f32(_p(pred), _p(target), _p(am), _p(logits), _p(stats), _p(ws), ws.numel(),
+                                      b, h, w, ho, wo, _stream()), "eval_tail")
+    return am, stats, logits
+
+
+def cm_reduce(x, mask_in, stride):
+    """ResNetCM.comm statistics: x NHWC [N,h,w,C] (or None: pool the mask only); mask_in [N,Hm,Wm]
+    -> (mask_out [N,h,w], stat [N,2,C] | None)."""
+    lib = _lib.load()
+    _chk_dev(x, mask_in)
+    hm, wm = mask_in.shape[-2:]
+    n = mask_in.shape[0]
+    if x is None:
+        h, w, c, ldx, stat = (hm + 2 - 3) // stride + 1, (wm + 2 - 3) // stride + 1, 0, 0, None
+    else:
+        ldx = _nhwc(x, "x")
+        n, h, w, c = x.shape
+        stat = torch.empty((n, 2, c), dtype=torch.float32, device=x.device)
+    mask_out = torch.empty((n, h, w), dtype=torch.float32, device=mask_in.device)
+    _lib.check(lib.pemp_cm_reduce_f32(_p(x), ldx, _p(mask_in.contiguous()), _p(mask_out), _p(stat), n, hm, wm, h, w, c,
+                                      stride, _stream()), "cm_reduce")
+    return mask_out, stat

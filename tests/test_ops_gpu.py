@@ -1,0 +1,238 @@
+"""Parity of every C-ABI entry point against plain torch fp32 ops on the CPU (the op-level oracle).
+
+Tolerances: conv outputs are sums of K exact fp32 products in a different order than oneDNN's,
+so |diff| <= 2e-5 * (1 + |ref|) * sqrt(K/64) is the bound used; streaming kernels 1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, s, p, d, tile
+    (2, 13, 13, 64, 64, 1, 1, 0, 1, 3),
+    (2, 25, 25, 256, 128, 1, 2, 0, 1, 3),
+    (1, 51, 51, 256, 256, 3, 1, 2, 2, 3),
+    (2, 51, 51, 256, 1024, 1, 1, 0, 1, 1),
+    (1, 51, 51, 256, 256, 3, 1, 18, 18, 2),
+    (2, 13, 13, 256, 256, 3, 1, 6, 6, 0),
+    (1, 17, 23, 32, 128, 3, 1, 1, 1, 1),
+    (3, 9, 7, 128, 64, 3, 2, 1, 1, 2),
+    (1, 30, 30, 1024, 256, 1, 1, 0, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_generic(hip_lib, dev, case):
+    from pemp_amd import ops
+    N, H, W, Cin, Cout, k, s, p, d, tile = case
+    x = _rand(N, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, k, k, seed=2) * (1.0 / (Cin * k * k) ** 0.5)
+    scale = _rand(Cout, seed=3, lo=0.5, hi=1.5)
+    shift = _rand(Cout, seed=4)
+    ref = F.conv2d(x, w, None, s, p, d) * scale[None, :, None, None] + shift[None, :, None, None]
+    res = _rand(*ref.shape, seed=5)
+    ref_full = F.relu(ref + res)
+    packed, kpad = ops.pack_conv_weight(w.to(dev))
+    prm = ops.ConvParams(packed, scale.to(dev), shift.to(dev), Cin, Cout, k, k, s, p, d, kpad, False, True)
+    y = ops.conv2d(_nhwc(x).to(dev), prm, residual=_nhwc(res).to(dev), tile=tile)
+    torch.cuda.synchronize()
+    got = _nchw(y.cpu())
+    tol = 2e-5 * (Cin * k * k / 64) ** 0.5
+    err = ((got - ref_full).abs() / (1 + ref_full.abs())).max().item()
+    assert err < tol, f"{case}: err {err} tol {tol}"
+    # no relu / no residual / no affine
+    prm2 = ops.ConvParams(packed, None, None, Cin, Cout, k, k, s, p, d, kpad, False, False)
+    y2 = _nchw(ops.conv2d(_nhwc(x).to(dev), prm2, tile=tile).cpu())
+    ref2 = F.conv2d(x, w, None, s, p, d)
+    assert ((y2 - ref2).abs() / (1 + ref2.abs())).max().item() < tol
+
+
+def test_conv2d_channel_slices_and_per_image_shift(hip_lib, dev):
+    from pemp_amd import ops
+    N, H, W, Cin, Cout = 3, 11, 11, 64, 128
+    wide_in = _rand(N, H, W, 96, seed=7)            # read channels 32..96 of a 96-wide buffer
+    w = _rand(Cout, Cin, 1, 1, seed=8) * 0.1
+    shift = _rand(N, Cout, seed=9)
+    ref = F.conv2d(wide_in[..., 32:].permute(0, 3, 1, 2), w) + shift[:, :, None, None]
+    packed, kpad = ops.pack_conv_weight(w.to(dev))
+    prm = ops.ConvParams(packed, None, None, Cin, Cout, 1, 1, 1, 0, 1, kpad, False, False)
+    xin = wide_in.to(dev)
+    wide_out = torch.full((N, H, W, 320), -7.0, device=dev)
+    ops.conv2d(xin[..., 32:], prm, out=wide_out[..., 64:192], shift_override=shift.to(dev).contiguous(), per_image_shift=True)
+    torch.cuda.synchronize()
+    got = wide_out.cpu()
+    assert (got[..., :64] == -7).all() and (got[..., 192:] == -7).all()
+    assert torch.allclose(got[..., 64:192].permute(0, 3, 1, 2), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,k,s,p,H", [(3, 7, 2, 3, 97), (3, 3, 1, 1, 33), (4, 7, 2, 3, 50)])
+@pytest.mark.parametrize("tile", [1 - 1, 2, 3])
+def test_conv2d_stem4(hip_lib, dev, cin, k, s, p, H, tile):
+    from pemp_amd import ops
+    N, Cout = 2, 64
+    x = _rand(N, cin, H, H, seed=11)
+    w = _rand(Cout, cin, k, k, seed=12) * 0.2
+    ref = F.relu(F.conv2d(x, w, None, s, p))
+    x4 = torch.zeros(N, H, H, 4)
+    x4[..., :cin] = x.permute(0, 2, 3, 1)
+    packed, kpad = ops.pack_conv_weight(w.to(dev), stem4=True)
+    prm = ops.ConvParams(packed, None, None, 4, Cout, k, k, s, p, 1, kpad, True, True)
+    y = _nchw(ops.conv2d(x4.to(dev), prm, tile=tile).cpu())
+    assert torch.allclose(y, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_conv2d_rejects_bad_arguments(hip_lib, dev):
+    from pemp_amd import ops, _lib
+    x = torch.zeros(1, 5, 5, 48, device=dev)
+    w = torch.zeros(64, 48, 1, 1, device=dev)
+    packed, kpad = ops.pack_conv_weight(w)
+    prm = ops.ConvParams(packed, None, None, 48, 64, 1, 1, 1, 0, 1, kpad, False, False)
+    with pytest.raises(_lib.PempHipError, match="multiple of 32"):
+        ops.conv2d(x, prm)
+    with pytest.raises(_lib.PempHipError, match="no CPU path"):
+        ops.conv2d(x.cpu(), prm)
+
+
+def test_pack_input_and_pools(hip_lib, dev):
+    from pemp_amd import ops
+    img = _rand(2, 3, 37, 41, seed=1)
+    prior = _rand(2, 1, 37, 41, seed=2)
+    x4 = ops.pack_input(img.to(dev), prior.to(dev)).cpu()
+    assert torch.equal(x4[..., :3], img.permute(0, 2, 3, 1)) and torch.equal(x4[..., 3], prior[:, 0])
+    assert (ops.pack_input(img.to(dev)).cpu()[..., 3] == 0).all()
+    x = _rand(2, 64, 49, 49, seed=3)
+    for k, s, p, ceil in ((3, 2, 1, True), (3, 2, 1, False), (3, 1, 1, False)):
+        ref = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
+        got = _nchw(ops.maxpool2d(_nhwc(x).to(dev), k, s, p, ceil_mode=ceil).cpu())
+        assert torch.equal(got, ref), (k, s, p, ceil)
+    x201 = _rand(1, 8, 201, 201, seed=4)
+    assert torch.equal(_nchw(ops.maxpool2d(_nhwc(x201).to(dev), 3, 2, 1, ceil_mode=True).cpu()),
+                       F.max_pool2d(x201, 3, 2, 1, ceil_mode=True))
+    g = ops.global_avgpool(_nhwc(x).to(dev)).cpu()
+    assert torch.allclose(g, x.mean(dim=(2, 3)), rtol=1e-5, atol=1e-6)
+
+
+def test_channel_affine_multi(hip_lib, dev):
+    from pemp_amd import ops
+    x = _rand(2, 5, 7, 64, seed=1)
+    sc = [_rand(64, seed=10 + i) for i in range(4)]
+    sh = [_rand(64, seed=20 + i) for i in range(4)]
+    outs = [torch.empty(2, 5, 7, 64, device=dev) for _ in range(4)]
+    ops.channel_affine_multi(x.to(dev), [s.to(dev) for s in sc], [s.to(dev) for s in sh], outs)
+    for i in range(4):
+        assert torch.allclose(outs[i].cpu(), x * sc[i] + sh[i], rtol=1e-6, atol=1e-7)   # GPU contracts to one FMA
+
+
+def _ref_mpm(sup, qry, fg, bg, ctr, p, ret_ind=True):
+    from oracle import ref_cpu
+    return ref_cpu.mpm(sup, qry, fg, bg, ctr, p, 20, ret_ind)
+
+
+@pytest.mark.parametrize("B,S,p,c,h,w,H,W", [(1, 1, 3, 512, 13, 13, 97, 97), (2, 5, 3, 512, 9, 11, 70, 85),
+                                            (1, 2, 2, 256, 7, 7, 50, 50), (1, 1, 1, 128, 5, 6, 40, 47)])
+def test_mpm_and_cosine(hip_lib, dev, B, S, p, c, h, w, H, W):
+    from pemp_amd import ops
+    sup = _rand(B, S, c, h, w, seed=1) * 2
+    qry = _rand(B, 1, c, h, w, seed=2) * 2
+    m = (_rand(B * S, 1, H, W, seed=3) > 0.2).float()
+    mask = torch.cat((m, 1 - m), dim=1)
+    ctr = _rand(c, 2 * p, seed=4, lo=0, hi=1)
+    mlow = F.interpolate(mask, (h, w), mode="nearest")
+    pred_ref, resp_ref, protos_ref = _ref_mpm(sup, qry, mlow[:, 0], mlow[:, 1], ctr, p)
+    supn = sup.reshape(B * S, c, h, w).permute(0, 2, 3, 1).contiguous().to(dev)
+    qryn = qry.reshape(B, c, h, w).permute(0, 2, 3, 1).contiguous().to(dev)
+    protos = ops.mpm_protos(supn, mask.to(dev), ctr.to(dev), B, S, p)
+    # protos_ref (adaptive_p) is [B,c,2p] ordered (fg0..,bg0..)
+    got = protos.cpu().permute(0, 2, 1)
+    assert torch.allclose(got, protos_ref, rtol=2e-5, atol=2e-5), (got - protos_ref).abs().max()
+    pred, resp = ops.cosine_proto_max(qryn, protos, 20.0, want_resp=True)
+    assert torch.allclose(pred.cpu(), pred_ref, rtol=0, atol=5e-5), (pred.cpu() - pred_ref).abs().max()
+    if p == 3:      # the reference hard-codes "+3" for the fg response offset (pemp_stage1.py:221)
+        # ties/near-ties aside the indices must agree
+        d = pred_ref[:, 1] - pred_ref[:, 0]
+        stable = d.abs() > 1e-3
+        assert (resp.cpu().long()[stable] == resp_ref[stable]).float().mean() > 0.999
+
+
+def test_masked_avg_pool_lowres_and_fullres(hip_lib, dev):
+    from pemp_amd import ops
+    B, S, c, h, w, H, W = 2, 2, 256, 7, 9, 50, 65
+    sup = _rand(B * S, c, h, w, seed=1)
+    m = (_rand(B * S, 1, H, W, seed=3) > 0.0).float()
+    m[1] = 0                                    # empty foreground -> zero prototype
+    mask = torch.cat((m, 1 - m), dim=1)
+    supn = sup.permute(0, 2, 3, 1).contiguous().to(dev)
+    # low-res (pemp_stage1.py:224-227)
+    ml = F.interpolate(mask, (h, w), mode="nearest").view(B * S, 2, 1, h * w)
+    f = sup.view(B * S, 1, c, h * w)
+    ref = ((f * ml).sum(-1) / (ml.sum(-1) + 1e-5)).view(B, S, 2, c).mean(dim=1)
+    got = ops.masked_avg_pool(supn, mask.to(dev), B, S, full_res=False).cpu()
+    assert torch.allclose(got, ref, rtol=2e-5, atol=1e-6)
+    # full-res (baseline.py:100-110)
+    up = F.interpolate(sup, (H, W), mode="bilinear", align_corners=True)
+    ref2 = torch.stack([(up * mask[:, g:g + 1]).sum(dim=(2, 3)) / (mask[:, g:g + 1].sum(dim=(2, 3)) + 1e-5)
+                        for g in range(2)], dim=1).view(B, S, 2, c).mean(dim=1)
+    got2 = ops.masked_avg_pool(supn, mask.to(dev), B, S, full_res=True).cpu()
+    assert torch.allclose(got2, ref2, rtol=5e-5, atol=2e-6), (got2 - ref2).abs().max()
+    assert (got2.view(B, 2, c)[0, 0].abs().max() > 0)
+
+
+@pytest.mark.parametrize("h,w,Ho,Wo", [(13, 13, 97, 97), (51, 51, 333, 500), (51, 51, 500, 333), (5, 7, 5, 7), (4, 4, 1, 9)])
+def test_upsample_and_eval_tail(hip_lib, dev, h, w, Ho, Wo):
+    from pemp_amd import ops
+    B = 2
+    pred = _rand(B, 2, h, w, seed=1) * 5 + 15
+    ref = F.interpolate(pred, (Ho, Wo), mode="bilinear", align_corners=True)
+    got = ops.upsample_bilinear_ac(pred.to(dev), (Ho, Wo)).cpu()
+    assert torch.allclose(got, ref, rtol=0, atol=2e-5), (got - ref).abs().max()
+    tgt = (_rand(B, Ho, Wo, seed=2) > 0.3).long()
+    tgt[0, : max(1, Ho // 7)] = 255
+    am, stats, logits = ops.eval_tail(pred.to(dev), tgt.to(dev), want_logits=True)
+    assert torch.equal(logits.cpu(), got)
+    assert torch.equal(am.cpu().long(), got.argmax(dim=1))
+    st = stats.cpu().numpy()
+    for b in range(B):
+        ce = F.cross_entropy(got[b:b + 1], tgt[b:b + 1], ignore_index=255, reduction="sum").item()
+        nvalid = int((tgt[b] != 255).sum())
+        assert st[b, 1] == nvalid
+        assert abs(st[b, 0] - ce) <= 1e-5 * max(1.0, abs(ce))
+        from tests.util import counts
+        cn = counts(got[b].argmax(0).numpy(), tgt[b].numpy())
+        assert (st[b, 2:].astype(np.int64) == cn.reshape(-1)).all()
+    resp = (_rand(B, h, w, seed=3) * 3 + 3).to(torch.uint8)
+    rref = F.interpolate(resp[:, None].float(), (Ho, Wo), mode="nearest")[:, 0].long()
+    assert torch.equal(ops.upsample_nearest_u8_i64(resp.to(dev), (Ho, Wo)).cpu(), rref)
+
+
+def test_cm_reduce(hip_lib, dev):
+    from pemp_amd import ops
+    N, C, Hm = 3, 64, 49
+    mask = (_rand(N, 1, Hm, Hm, seed=1) > 0.5).float()
+    for stride in (1, 2):
+        mo = F.max_pool2d(mask, 3, stride, 1)
+        h = mo.shape[-1]
+        x = _rand(N, C, h, h, seed=2)
+        masked = (x * mo).view(N, C, -1)
+        got_m, stat = ops.cm_reduce(_nhwc(x).to(dev), mask[:, 0].to(dev), stride)
+        assert torch.equal(got_m.cpu(), mo[:, 0])
+        assert torch.allclose(stat.cpu()[:, 0], masked.mean(-1), rtol=1e-5, atol=1e-6)
+        assert torch.equal(stat.cpu()[:, 1], masked.max(-1)[0])
+    only = ops.cm_reduce(None, mask[:, 0].to(dev), 2)[0]
+    assert torch.equal(only.cpu(), F.max_pool2d(mask, 3, 2, 1)[:, 0])
