@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: episodes/sec of the PEMP stage-1 evaluation step (BASELINE.json configs[1]:
+pemp_stage1, PASCAL-5i-shaped 1-shot episodes, ResNet-50, 401x401) on N MI355X.
+
+A "step" is one pass of the hot path -- Evaluator.test_step's device work (encoder, meta-prototype
+module, cosine map, upsample + argmax + CE + IoU counts; reference entry/pemp_stage1.py:48-53) --
+over ``--batch`` synthetic episodes that are already resident in HBM.  Ranks are independent
+(episodes shard; no data-path collective), scaling is weak.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel (the fp32-MFMA implicit-GEMM conv) against the 157.3 TFLOP/s
+                dense fp32 matrix peak; durations from HIP events around every conv launch of the
+                same workload, taken in bench.py on the launch stream;
+  cpu_baseline  the CPU oracle (oracle/ref_cpu.py, verified bit-equal to the reference here) timed on
+                the host cores for a bounded sample of the same episodes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PEMP_BENCH_BATCH", "8")),
+                    help="episodes per step (the reference evaluates 1 per step)")
+    ap.add_argument("--shot", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-episodes", type=int, default=12, help="bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(dev):
+    from pemp_amd.networks import pemp_stage1 as m
+    from tests import util
+    sd = util.wgen_state_dict("stage1_rn50")
+    net = m.ModelClass(None)
+    net.load_state_dict(sd)
+    return net.to(dev).eval(), sd
+
+
+def episode_pool(dev, shot, batch, rank, n_groups=5):
+    """n_groups batches of `batch` episodes; all episodes of a batch share one query size so that one
+    fused tail launch serves the batch.  Seeds follow the evaluation sampler (test_seed = 5678)."""
+    from pemp_amd import synth
+    pool = []
+    for g in range(n_groups):
+        hw = synth.QUERY_SIZES[g % len(synth.QUERY_SIZES)]
+        seeds = [5678 + 1000 * rank + g * batch + b for b in range(batch)]
+        b = synth.make_batch(seeds, shot=shot, out_hw=hw)
+        pool.append(dict(
+            sup_img=torch.from_numpy(b["sup_img"]).to(dev), sup_mask=torch.from_numpy(b["sup_mask"]).to(dev),
+            qry_img=torch.from_numpy(b["qry_img"]).to(dev), qry_mask=torch.from_numpy(b["qry_mask"][:, 0]).to(dev),
+            seeds=seeds, hw=hw))
+    return pool
+
+
+def conv_roofline(net, pool, reps=3):
+    """Per-launch HIP-event timing of every conv launch of one step (eager pass, same stream)."""
+    from pemp_amd import ops
+    records = []
+    orig = ops.conv2d
+
+    def timed(x, p, out=None, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig(x, p, out=out, **kw)
+        e1.record()
+        n, ho, wo, co = y.shape
+        cin_real = 3 if (p.stem and p.cin == 4 and not getattr(p, "real4", False)) else p.cin
+        records.append((e0, e1, 2.0 * n * ho * wo * co * p.kh * p.kw * cin_real))
+        return y
+
+    ops.conv2d = timed
+    import pemp_amd.engine as eng
+    eng.ops.conv2d = timed
+    try:
+        with torch.no_grad():
+            for r in range(reps + 1):
+                if r == 1:
+                    records.clear()
+                ep = pool[r % len(pool)]
+                net.lowres(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d = orig
+        eng.ops.conv2d = orig
+    ms = sum(a.elapsed_time(b) for a, b, _ in records)
+    flops = sum(f for _, _, f in records)
+    n = len(records)
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel (all conv launches of a step)",
+            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
+            "gflop_per_step": round(flops / reps / 1e9, 2), "conv_ms_per_step": round(ms / reps, 4)}
+
+
+def cpu_baseline(sd, shot, n_eps):
+    """Oracle test_step (forward + CE + argmax) on the host cores, bounded sample."""
+    from oracle import ref_cpu
+    from pemp_amd import synth
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    # a 1-GPU box owns a 16-core share of its host; more threads than that only oversubscribe it
+    cores = max(1, min(cores, int(os.environ.get("PEMP_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    times = []
+    with torch.no_grad():
+        for i in range(n_eps + 1):
+            ep = synth.make_episode(5678 + i, shot=shot, index=i)
+            t = lambda a: torch.from_numpy(a)[None]
+            sup, msk, qry, gt = t(ep["sup_img"]), t(ep["sup_mask"]), t(ep["qry_img"]), torch.from_numpy(ep["qry_mask"])
+            t0 = time.time()
+            fwd = lambda a, b, c, hw: ref_cpu.stage1_forward(sd, a, b, c, hw)
+            ref_cpu.test_step(fwd, (sup, msk, qry), gt)
+            dt = time.time() - t0
+            if i > 0:                      # first episode warms the allocator / oneDNN primitives
+                times.append(dt)
+            if sum(times) > 30.0:
+                break
+    tot = sum(times)
+    return {"value": round(len(times) / tot, 3), "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} episodes (seeds 5679..), oracle/ref_cpu.py test_step, torch {torch.__version__} CPU, "
+                      f"{cores} threads, median {np.median(times) * 1e3:.0f} ms/episode"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    from pemp_amd import build, ops
+    build.build()
+    net, sd = build_model(dev)
+    pool = episode_pool(dev, args.shot, args.batch, rank)
+    ws = {}
+    stats_log = torch.zeros((args.steps, args.batch, 8), dtype=torch.float64, device=dev)
+
+    def step(i, log=True):
+        ep = pool[i % len(pool)]
+        with torch.no_grad():
+            if args.no_graph:
+                pred, _ = net.lowres(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
+            else:
+                pred, _ = net.lowres_graphed(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
+            am, stats, _ = ops.eval_tail(pred, ep["qry_mask"], ws_cache=ws)
+        if log:
+            stats_log[i].copy_(stats)
+        return am
+
+    for i in range(args.warmup):
+        step(i, log=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # sanity on the logged statistics (the work really happened): finite losses, counts add up
+    st = stats_log.cpu().numpy()
+    assert np.isfinite(st).all() and (st[..., 1] > 0).all(), "eval tail produced invalid statistics"
+    mean_loss = float((st[..., 0] / st[..., 1]).mean())
+
+    out = None
+    if rank == 0:
+        eps_total = args.steps * args.batch * world
+        out = {
+            "metric": "episodes/sec (PEMP stage-1 eval step, PASCAL-5i-shaped 1-shot, ResNet-50)",
+            "value": round(eps_total / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "pemp_stage1 eval test_step, ResNet-50, %d-shot, 401x401, %d episode(s)/step, "
+                                   "synthetic E(seed) episodes + Wgen(1234) weights" % (args.shot, args.batch),
+                       "episodes_per_step": args.batch, "shot": args.shot, "hipgraph": not args.no_graph,
+                       "mean_ce_loss": round(mean_loss, 6)},
+        }
+        if not args.no_roofline:
+            out["roofline"] = conv_roofline(net, pool)
+        if world == 1 and args.cpu_episodes > 0:
+            out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in sd.items()}, args.shot, args.cpu_episodes)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -12,26 +12,36 @@ import ast
 import functools
 import inspect
 import sys
+import textwrap
 
 
-def _run_scope(fn, known):
-    """Execute a config scope and harvest its locals (Sacred does this by rewriting the source)."""
-    params = [p for p in inspect.signature(fn).parameters]
-    kwargs = {p: known[p] for p in params if p in known}
-    grabbed = {}
+def _run_scope(fn, known, fixed=None):
+    """Execute a config scope statement by statement and harvest its local variables.
 
-    def tracer(frame, event, arg):
-        if event == "return" and frame.f_code is fn.__code__:
-            grabbed.update(frame.f_locals)
-        return tracer
-
-    old = sys.getprofile()
-    sys.setprofile(tracer)
-    try:
-        fn(**kwargs)
-    finally:
-        sys.setprofile(old)
-    return {k: v for k, v in grabbed.items() if not k.startswith("_") and k not in params}
+    Like Sacred's ConfigScope: parameters of ``fn`` are filled from ``known`` (earlier entries),
+    and a top-level assignment to a name present in ``fixed`` (a ``with k=v`` update) is skipped so
+    that later statements of the same scope see the updated value.
+    """
+    fixed = fixed or {}
+    params = list(inspect.signature(fn).parameters)
+    tree = ast.parse(textwrap.dedent(inspect.getsource(fn)))
+    fdef = next(n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef)))
+    glob = dict(fn.__globals__)
+    glob.update(inspect.getclosurevars(fn).nonlocals)
+    loc = {p: known[p] for p in params if p in known}
+    seeded = set(loc)
+    fname = inspect.getsourcefile(fn) or "<config>"
+    for stmt in fdef.body:
+        if isinstance(stmt, ast.Assign) and all(isinstance(t, ast.Name) for t in stmt.targets):
+            names = [t.id for t in stmt.targets]
+            if any(n in fixed for n in names):
+                for n in names:
+                    loc[n] = fixed.get(n, loc.get(n))
+                    seeded.discard(n)
+                continue
+            seeded.difference_update(names)
+        exec(compile(ast.Module(body=[stmt], type_ignores=[]), fname, "exec"), glob, loc)
+    return {k: v for k, v in loc.items() if not k.startswith("_") and k not in seeded}
 
 
 def _parse_value(text):
@@ -82,7 +92,8 @@ class Ingredient:
         if self._cfg is None:
             cfg = {}
             for scope in self._scopes:
-                cfg.update(_run_scope(scope, {**cfg, **self._updates}))
+                flat = {k: v for k, v in self._updates.items() if "." not in k}
+                cfg.update(_run_scope(scope, {**cfg, **flat}, flat))
             for k, v in self._updates.items():
                 _set_path(cfg, k, v)
             self._cfg = cfg

@@ -28,6 +28,7 @@
 namespace pemp {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float v4f;   // first-class vector: loads/stores never become memcpy
 
 struct ConvArgs {
     const float* x;
@@ -46,12 +47,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int WGN = 4 / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int AL = BM / 32, BL = BN / 32;  // float4 loads per thread per K step
+    constexpr int AL = BM / 32, BL = BN / 32;  // v4f loads per thread per K step
     static_assert(TM >= 1 && TN >= 1, "wave tile");
 
-    extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    float4* As = smem;                    // [2][8][BM]
-    float4* Bs = smem + 2 * 8 * BM;       // [2][8][BN]
+    extern __shared__ __attribute__((aligned(16))) v4f smem[];
+    v4f* As = smem;                    // [2][8][BM]
+    v4f* Bs = smem + 2 * 8 * BM;       // [2][8][BN]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,48 +92,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < BL; ++i) wrow[i] = a.w + (size_t)(n0 + r + 32 * i) * a.Kpad + q * 4;
 
-    float4 ra[AL], rb[BL];
+    v4f ra[AL], rb[BL];
+    unsigned okmask = 0;   // bit i: ra[i] holds real data (else it must be zeroed before staging)
 
-    auto gload = [&](int kt) {
-        if constexpr (STEM) {
-            int tap = kt * 8 + q;
-            int kh = tap / a.KW, kw = tap - kh * a.KW;
-            bool tok = tap < a.ntaps;
-            int dh = kh * a.dil, dw = kw * a.dil;
-#pragma unroll
-            for (int i = 0; i < AL; ++i) {
-                int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
-                bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-                const float4* p = (const float4*)(a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * 4);
-                ra[i] = ok ? *p : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        } else {
-            int tap = kt / a.cin_steps;
-            int cb = kt - tap * a.cin_steps;
-            int kh = tap / a.KW, kw = tap - kh * a.KW;
-            int dh = kh * a.dil, dw = kw * a.dil;
-            int coff = cb * 32 + q * 4;
-#pragma unroll
-            for (int i = 0; i < AL; ++i) {
-                int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
-                bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-                const float4* p =
-                    (const float4*)(a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + coff);
-                ra[i] = ok ? *p : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < BL; ++i) rb[i] = *(const float4*)(wrow[i] + kt * 32);
-    };
+    // Global -> register loads of K step `kt`.  Out-of-image taps read a harmless valid address
+    // (the tensor base) and are zeroed at staging time, so every load is unconditional and the
+    // wave never waits on memory before its MFMAs.
+#define PEMP_GLOAD(kt_)                                                                              \
+    do {                                                                                             \
+        const int kt__ = (kt_);                                                                      \
+        okmask = 0;                                                                                  \
+        if constexpr (STEM) {                                                                        \
+            const int tap = kt__ * 8 + q;                                                            \
+            const int kh = tap / a.KW, kw = tap - kh * a.KW;                                         \
+            const bool tok = tap < a.ntaps;                                                          \
+            const int dh = kh * a.dil, dw = kw * a.dil;                                              \
+            _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
+                const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                    \
+                const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
+                const float* p = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * 4 : a.x;         \
+                ra[i] = *(const v4f*)p;                                                           \
+                okmask |= (ok ? 1u : 0u) << i;                                                       \
+            }                                                                                        \
+        } else {                                                                                     \
+            const int tap = kt__ / a.cin_steps;                                                      \
+            const int cb = kt__ - tap * a.cin_steps;                                                 \
+            const int kh = tap / a.KW, kw = tap - kh * a.KW;                                         \
+            const int dh = kh * a.dil, dw = kw * a.dil;                                              \
+            const int coff = cb * 32 + q * 4;                                                        \
+            _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
+                const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                    \
+                const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;        \
+                const float* p = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + coff : a.x; \
+                ra[i] = *(const v4f*)p;                                                           \
+                okmask |= (ok ? 1u : 0u) << i;                                                       \
+            }                                                                                        \
+        }                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < BL; ++i) rb[i] = *(const v4f*)(wrow[i] + kt__ * 32); \
+    } while (0)
 
-    auto lstore = [&](int buf) {
-        float4* Ab = As + buf * 8 * BM + q * BM;
-        float4* Bb = Bs + buf * 8 * BN + q * BN;
-#pragma unroll
-        for (int i = 0; i < AL; ++i) Ab[(r + 32 * i) ^ q] = ra[i];
-#pragma unroll
-        for (int i = 0; i < BL; ++i) Bb[(r + 32 * i) ^ q] = rb[i];
-    };
+#define PEMP_LSTORE(buf_)                                                                            \
+    do {                                                                                             \
+        v4f* Ab_ = As + (buf_) * 8 * BM + q * BM;                                                 \
+        v4f* Bb_ = Bs + (buf_) * 8 * BN + q * BN;                                                 \
+        _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                             \
+            v4f v = ra[i];                                                                        \
+            if (!((okmask >> i) & 1u)) v = v4f{0.f, 0.f, 0.f, 0.f};                          \
+            Ab_[(r + 32 * i) ^ q] = v;                                                               \
+        }                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < BL; ++i) Bb_[(r + 32 * i) ^ q] = rb[i];                \
+    } while (0)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -142,38 +151,51 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    gload(0);
-    lstore(0);
+    PEMP_GLOAD(0);
+    PEMP_LSTORE(0);
     __syncthreads();
 
+    const int arow = wm0 + lr, brow = wn0 + lr;
     for (int kt = 0; kt < a.nk; ++kt) {
         const int buf = kt & 1;
-        const bool more = kt + 1 < a.nk;
-        if (more) gload(kt + 1);
+        // the last iteration re-loads its own tile into the idle buffer: harmless, keeps the loop branch-free
+        PEMP_GLOAD(kt + 1 < a.nk ? kt + 1 : kt);
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs (hipcc sinks them to their use)
 
-        const float4* Ab = As + buf * 8 * BM;
-        const float4* Bb = Bs + buf * 8 * BN;
+        const v4f* Ab = As + buf * 8 * BM;
+        const v4f* Bb = Bs + buf * 8 * BN;
+        v4f af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af[0][mi] = Ab[lh * BM + ((arow + mi * 32) ^ lh)];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[0][ni] = Bb[lh * BN + ((brow + ni * 32) ^ lh)];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int qq = 2 * j + lh;
-            float4 af[TM], bf[TN];
+            if (j < 3) {   // prefetch the next quad pair while this one is in the matrix pipe
+                const int qq = 2 * (j + 1) + lh;
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) af[mi] = Ab[qq * BM + ((wm0 + mi * 32 + lr) ^ qq)];
+                for (int mi = 0; mi < TM; ++mi) af[(j + 1) & 1][mi] = Ab[qq * BM + ((arow + mi * 32) ^ qq)];
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) bf[ni] = Bb[qq * BN + ((wn0 + ni * 32 + lr) ^ qq)];
+                for (int ni = 0; ni < TN; ++ni) bf[(j + 1) & 1][ni] = Bb[qq * BN + ((brow + ni * 32) ^ qq)];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // reads of pair j+1 stay in front of the MFMAs of pair j
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+                    const v4f av = af[j & 1][mi], bv = bf[j & 1][ni];
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[mi][ni], 0, 0, 0);
                 }
         }
-        if (more) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        PEMP_LSTORE(buf ^ 1);
         __syncthreads();
     }
+#undef PEMP_GLOAD
+#undef PEMP_LSTORE
 
     // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel) ----
     const bool relu = a.flags & PEMP_CONV_RELU;
@@ -185,16 +207,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const float sh = (a.shift && !per_img) ? a.shift[n] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
+            const int mb = m0 + wm0 + mi * 32 + 4 * lh;
+            float add[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) add[e] = sh;
+            if (per_img) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int mc = min(mb + (e & 3) + 8 * (e >> 2), a.M - 1);
+                    add[e] += a.shift[(size_t)(mc / a.HoWo) * a.Cout + n];
+                }
+            }
+            if (a.res) {   // all 16 residual loads are independent and in flight together
+                float rv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int mc = min(mb + (e & 3) + 8 * (e >> 2), a.M - 1);
+                    rv[e] = a.res[(size_t)mc * a.ldr + n];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) add[e] += rv[e];
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < a.M) {
-                    float v = acc[mi][ni][e] * sc + sh;
-                    if (per_img) v += a.shift[(size_t)(m / a.HoWo) * a.Cout + n];
-                    if (a.res) v += a.res[(size_t)m * a.ldr + n];
-                    if (relu) v = fmaxf(v, 0.f);
-                    a.y[(size_t)m * a.ldy + n] = v;
-                }
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                float v = acc[mi][ni][e] * sc + add[e];
+                if (relu) v = fmaxf(v, 0.f);
+                if (m < a.M) a.y[(size_t)m * a.ldy + n] = v;
             }
         }
     }
@@ -202,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
 template <int BM, int BN, int WGM, bool STEM>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(float4);
+    const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
     auto kern = conv_igemm_kernel<BM, BN, WGM, STEM>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -260,12 +299,10 @@ extern "C" int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, con
 
     int tile = d->tile;
     if (tile == 0) {
-        // largest tile that still yields >= ~1.25 blocks per CU; else the small tile
-        const long long b128 = (long long)cdiv(a.M, 128) * (a.Cout / 128 > 0 ? a.Cout / 128 : 0);
-        const long long b12864 = (long long)cdiv(a.M, 128) * (a.Cout / 64);
-        if (a.Cout % 128 == 0 && b128 >= 320) tile = 1;
-        else if (b12864 >= 320) tile = 2;
-        else tile = 3;
+        // Measured on MI355X (scratch/conv_tune.py): at these problem sizes (M <= ~80k rows) the 64x64
+        // tile wins or ties everywhere -- waves per SIMD matter more than operand reuse for the
+        // 64-cycle fp32 MFMA.  Callers that know better (engine autotune) pass an explicit tile.
+        tile = 3;
     }
     hipStream_t st = (hipStream_t)stream;
     if (tile == 1) {

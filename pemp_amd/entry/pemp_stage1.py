@@ -1,0 +1,160 @@
+"""Evaluation harness of PEMP stage 1 on MI355X (counterpart of the reference's
+entry/pemp_stage1.py:47-53,116-167 and core/base_trainer.py:59-102).
+
+``Evaluator.test_step`` keeps the reference contract -- forward at the ground truth's size,
+cross-entropy, argmax -- but the whole tail (upsample + argmax + CE + tp/fp/fn) is one fused
+launch and nothing has to reach the host per episode: ``test_step_device`` leaves the
+prediction and an 8-double statistics row on the GPU, and ``start_eval_loop`` fetches the rows
+once per round.  Episodes shard over ranks as ``tasks[rank::world]``; the integer metric table
+and the loss sum are all-reduced (SUM) once per round over RCCL, so mIoU does not depend on the
+number of GPUs.
+"""
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import ops, synth
+from ..config import Experiment
+from ..core.metrics import Accumulator, FewShotMetric
+from ..networks.pemp_stage1 import ModelClass, net_ingredient
+
+NAME = "PEMP"
+ex = Experiment(name=NAME, ingredients=[net_ingredient])
+
+
+@ex.config
+def ex_config():
+    tag = "pemp_stage1"         # str, configuration tag
+    shot = 1                    # int, support samples per episode
+    query = 1                   # int, query samples per episode (must stay 1)
+    split = -1                  # int, split number [0, 1, 2, 3], required
+    seed = 1234                 # int, random seed
+    ckpt = "bestckpt.pth"       # str, checkpoint file
+    exp_id = -1                 # experiment id to load checkpoint
+    loss = "ce"                 # str, loss type [ce/cedt]
+    sigma = 5.                  # float, sigma of the DT loss
+    test_n = 1000               # int, episodes per evaluation round (data.test_n in the reference)
+    test_seed = 5678            # int, evaluation sampler seed (data.test_seed)
+    te_epochs = 5               # int, evaluation rounds (te.epochs)
+
+
+def get_val_labels(split, dataset="PASCAL"):
+    """reference: data_kits/datasets.py:83-104."""
+    n = 5 if dataset == "PASCAL" else 20
+    return list(range(split * n + 1, split * n + n + 1))
+
+
+class SyntheticEpisodes:
+    """Stand-in for the PASCAL-5i test loader (no dataset on either box): episode ``i`` of a round is
+    ``E(test_seed + round * test_n + i)`` (pemp_amd.synth), yielded in the reference's batch layout
+    ``((sup_img, sup_mask, qry_img), qry_mask, cls)`` with a leading batch dim of 1."""
+
+    def __init__(self, test_n, test_seed, shot, split=0, height=401, width=401):
+        self.test_n, self.test_seed, self.shot, self.split = test_n, test_seed, shot, split
+        self.height, self.width = height, width
+        self.round = -1
+
+    def reset_sampler(self):
+        self.round = -1
+
+    def sample_tasks(self):
+        self.round += 1
+
+    def __len__(self):
+        return self.test_n
+
+    def task(self, i):
+        seed = self.test_seed + self.round * self.test_n + i
+        ep = synth.make_episode(seed, self.shot, self.height, self.width, index=i, split=self.split)
+        t = lambda a: torch.from_numpy(a)[None]
+        return (t(ep["sup_img"]), t(ep["sup_mask"]), t(ep["qry_img"])), t(ep["qry_mask"]), torch.tensor([ep["cls"]])
+
+
+class Evaluator:
+    def __init__(self, model, device=None, use_graph=True):
+        self.model = model
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.use_graph = use_graph
+        self._ws = {}
+
+    def test_step_device(self, inputs, qry_msk):
+        """-> (argmax uint8 [B,Ho,Wo], stats f64 [B,8]) both on the GPU, no host synchronisation."""
+        dev_in = [x.to(self.device, non_blocking=True) for x in inputs]
+        tgt = qry_msk.view(-1, *qry_msk.shape[-2:]).to(self.device, non_blocking=True)
+        with torch.no_grad():
+            if self.use_graph:
+                pred, _ = self.model.lowres_graphed(*dev_in)
+            else:
+                pred, _ = self.model.lowres(*dev_in)
+            am, stats, _ = ops.eval_tail(pred, tgt, ws_cache=self._ws)
+        return am, stats
+
+    def test_step(self, inputs, qry_msk, **kwargs):
+        """Reference contract (entry/pemp_stage1.py:48-53): -> (qry_pred numpy [B,H,W], loss float)."""
+        am, stats = self.test_step_device(inputs, qry_msk)
+        st = stats.cpu().numpy()
+        loss = float(st[:, 0].sum() / max(st[:, 1].sum(), 1.0))
+        return am.cpu().numpy(), loss
+
+    def start_eval_loop(self, dataset, num_classes, split, te_epochs=5, logger=None):
+        """Reference loop (core/base_trainer.py:59-102), sharded over ranks."""
+        self.model.eval()
+        dataset.reset_sampler()
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        accum = Accumulator(loss=[], miou=[], biou=[])
+        val_labels = get_val_labels(split)
+        timed, calls = 0.0, 0
+        for epoch in range(1, te_epochs + 1):
+            metric = FewShotMetric(num_classes)
+            dataset.sample_tasks()
+            rows, classes = [], []
+            for i in range(rank, len(dataset), world):
+                inputs, qry_msk, cls = dataset.task(i)
+                t0 = time.time()
+                _, stats = self.test_step_device(inputs, qry_msk)
+                timed += time.time() - t0
+                calls += 1
+                rows.append(stats)
+                classes += [int(c) for c in cls]
+            t0 = time.time()
+            st = torch.cat(rows).cpu().numpy() if rows else np.zeros((0, 8))
+            timed += time.time() - t0
+            metric.update_counts(st[:, 2:], classes)
+            # per-episode losses are averaged like the reference: mean over episodes of (CE mean)
+            loss_sum = float((st[:, 0] / np.maximum(st[:, 1], 1.0)).sum())
+            pack = torch.from_numpy(np.concatenate([metric.stat.reshape(-1), [loss_sum, float(len(classes))]]))
+            if world > 1:
+                pack = pack.to(self.device)
+                dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+                pack = pack.cpu()
+            metric.stat = pack[:-2].numpy().reshape(metric.stat.shape)
+            miou_c, miou = metric.mIoU(val_labels)
+            biou_c, biou = metric.mIoU(val_labels, binary=True)
+            if logger is not None and rank == 0:
+                logger.info(f"[round {epoch}/{te_epochs}] mIoU: {miou * 100:5.2f}  |  bIoU: {biou * 100:5.2f}")
+            accum.update(loss=float(pack[-2] / pack[-1]), miou=miou_c, biou=biou_c)
+        self.cps = calls / timed if timed > 0 else 0.0
+        return accum.mean(["loss", "miou", "biou"])
+
+
+@ex.command
+def test(_config, split, shot, seed, test_n, test_seed, te_epochs):
+    """``python -m pemp_amd.entry.pemp_stage1 test with split=0`` on synthetic episodes."""
+    import logging
+    logging.basicConfig(level=logging.INFO, format="%(message)s")
+    logger = logging.getLogger(NAME)
+    if split < 0:
+        raise ValueError("Argument `split` is required! For example: `python -m pemp_amd.entry.pemp_stage1 test with split=0`")
+    torch.manual_seed(seed)
+    model = ModelClass(logger).cuda().eval()
+    data = SyntheticEpisodes(test_n, test_seed, shot, split)
+    ev = Evaluator(model)
+    loss, miou, biou = ev.start_eval_loop(data, 20, split, te_epochs, logger)
+    return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
+
+
+if __name__ == "__main__":
+    print(ex.run_commandline())

@@ -1,0 +1,236 @@
+"""CPU-only checks (run with -m "not gpu"): the oracle against the reference's golden vectors, the
+synthetic generators, the host-side mirrors (config layer, metrics, state_dict layout) and the
+C-ABI library's export table.  No GPU compute is issued here."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------------
+# generators
+# ---------------------------------------------------------------------------------------------
+def test_synth_is_pinned():
+    """Bit-exact generators: digests recorded when the golden vectors were made."""
+    from pemp_amd import synth
+    ep = synth.make_episode(5678, shot=1, height=97, width=97, out_hw=(80, 120))
+    h = hashlib.sha256()
+    for k in ("sup_img", "sup_mask", "qry_img", "qry_mask"):
+        h.update(np.ascontiguousarray(ep[k]).tobytes())
+    w = synth.gen_tensor(1234, "encoder.backbone.conv1.weight", (64, 3, 7, 7), "conv_w")
+    h.update(w.tobytes())
+    assert ep["sup_img"].dtype == np.float32 and ep["qry_mask"].dtype == np.int64
+    assert ep["sup_mask"].shape == (1, 2, 97, 97) and (ep["sup_mask"].sum(axis=1) == 1).all()
+    assert 0.03 < ep["sup_mask"][0, 0].mean() < 0.6
+    assert h.hexdigest() == open(os.path.join(util.GOLD, "synth_digest.txt")).read().strip()
+
+
+def test_episode_batch_layout():
+    from pemp_amd import synth
+    b = synth.make_batch([1, 2], shot=2, height=33, width=33, out_hw=(20, 30))
+    assert b["sup_img"].shape == (2, 2, 3, 33, 33) and b["qry_mask"].shape == (2, 1, 20, 30)
+    assert set(np.unique(b["qry_mask"])) <= {0, 1} and b["cls"].tolist() == [2, 3]
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle vs the reference's own outputs
+# ---------------------------------------------------------------------------------------------
+def _check_case(fixture, keyname, fwd, tol=0.0, max_eps=None):
+    from oracle import ref_cpu
+    g = util.gold(fixture)
+    sd = util.wgen_state_dict(keyname, seed=4321 if keyname.startswith("stage2") else 1234)
+    shot, H = int(g["shot"]), int(g["H"])
+    for e, seed in enumerate(g["seeds"][:max_eps]):
+        hw = tuple(int(v) for v in g[f"e{e}_out_hw"])
+        t = util.episode_tensors(seed, shot, H, hw)
+        with torch.no_grad():
+            logits = fwd(ref_cpu, sd, t, hw, g, e)
+        assert (logits[0, :, ::7, ::7].numpy() - g[f"e{e}_logits_s7"]).__abs__().max() <= tol
+        bits = np.packbits(logits.argmax(1).numpy().astype(np.uint8).reshape(-1))
+        assert (bits == g[f"e{e}_argmax_bits"]).all()
+        loss = float(ref_cpu.ce_loss(logits, t["qry_mask"]))
+        assert abs(loss - float(g[f"e{e}_loss"])) <= 1e-6
+        am = logits.argmax(1).numpy()[0]
+        assert (util.counts(am, t["qry_mask"][0].numpy()) == g[f"e{e}_counts"]).all()
+
+
+def _s1(backbone):
+    def f(R, sd, t, hw, g, e):
+        out, resp = R.stage1_forward(sd, t["sup_img"], t["sup_mask"], t["qry_img"], hw, ret_ind=True, backbone=backbone)
+        assert (resp[0, ::7, ::7].numpy() == g[f"e{e}_resp_s7"]).all()
+        return out
+    return f
+
+
+@pytest.mark.parametrize("fixture", ["stage1_rn50_small", "stage1_rn50_small5"])
+def test_oracle_stage1_rn50(fixture):
+    _check_case(fixture, "stage1_rn50", _s1("resnet50"))
+
+
+def test_oracle_stage1_rn50_full_size():
+    _check_case("stage1_rn50_full", "stage1_rn50", _s1("resnet50"), max_eps=1)
+
+
+def test_oracle_stage1_vgg16():
+    _check_case("stage1_vgg16_small", "stage1_vgg16", _s1("vgg16"))
+
+
+def test_oracle_stage1_plain_map_branch():
+    from oracle import ref_cpu
+    g = util.gold("stage1_rn50_map_small")
+    sd = util.wgen_state_dict("stage1_rn50")
+    t = util.episode_tensors(11, 2, 97, (80, 120))
+    with torch.no_grad():
+        out = ref_cpu.stage1_forward(sd, t["sup_img"], t["sup_mask"], t["qry_img"], (80, 120), protos=0)
+    assert np.array_equal(out[0].numpy(), g["e0_logits"])
+
+
+@pytest.mark.parametrize("fixture,keys,bb", [("baseline_vgg16_small", "baseline_vgg16", "vgg16"),
+                                             ("baseline_vgg16_small5", "baseline_vgg16", "vgg16"),
+                                             ("baseline_rn50_small", "baseline_rn50", "resnet50")])
+def test_oracle_baseline(fixture, keys, bb):
+    _check_case(fixture, keys, lambda R, sd, t, hw, g, e: R.baseline_forward(sd, t["sup_img"], t["sup_mask"], t["qry_img"], hw, backbone=bb))
+
+
+@pytest.mark.parametrize("fixture", ["stage2_rn50cm_small", "stage2_rn50cm_small5"])
+def test_oracle_stage2(fixture):
+    def f(R, sd, t, hw, g, e):
+        H = t["sup_img"].shape[-1]
+        prior = torch.from_numpy(np.unpackbits(g[f"e{e}_prior_bits"])[: H * H].reshape(1, 1, H, H).astype(np.int64))
+        out, resp = R.stage2_forward(sd, t["sup_img"], t["sup_mask"], t["qry_img"], prior, hw, ret_ind=True)
+        assert (resp[0, ::7, ::7].numpy() == g[f"e{e}_resp_s7"]).all()
+        return out
+    _check_case(fixture, "stage2_rn50cm", f)
+
+
+def test_index_facts():
+    """G8: geometry facts of the stock ops that the kernels hard-code."""
+    g = util.gold("index_facts")
+    for i, o in ((401, 51), (97, 13)):
+        scale = np.float32(i) / np.float32(o)
+        mine = np.minimum(np.floor(np.arange(o, dtype=np.float32) * scale).astype(np.int64), i - 1)
+        assert (mine == g[f"nearest_{i}_{o}"]).all()
+    from pemp_amd import ops
+    assert ops._pool_out(201, 3, 2, 1, True) == int(g["pool_ceil_201"]) == 101
+    assert ops._pool_out(49, 3, 2, 1, True) == int(g["pool_ceil_49"]) == 25
+    s, sizes = 401, []
+    for st in (2, 2, 2, 1):
+        s = ops._pool_out(s, 3, st, 1, False)
+        sizes.append(s)
+    assert sizes == g["vgg_sizes_401"].tolist() == [201, 101, 51, 51]
+
+
+def test_oracle_metric_matches_reference_formulas():
+    from oracle import ref_cpu
+    from pemp_amd.core.metrics import FewShotMetric
+    rng = np.random.RandomState(0)
+    a, b = ref_cpu.FewShotMetric(20), FewShotMetric(20)
+    for cls in (1, 3, 3, 5):
+        pred = rng.randint(0, 2, (1, 40, 50))
+        ref = rng.randint(0, 2, (1, 40, 50))
+        ref[0, :3] = 255
+        a.update(pred, ref, [cls])
+        b.update(pred, ref, [cls])
+        c = util.counts(pred[0], ref[0])
+    assert np.array_equal(a.stat, b.stat)
+    assert np.allclose(a.miou([1, 3, 5])[1], b.mIoU([1, 3, 5])[1])
+    assert np.allclose(a.miou([1, 3, 5], binary=True)[0], b.mIoU([1, 3, 5], binary=True)[0])
+    m = FewShotMetric(20)
+    m.update_counts(c.reshape(1, 6), [5])
+    assert m.stat[0].tolist() == c[0].tolist() and m.stat[5].tolist() == c[1].tolist()
+
+
+# ---------------------------------------------------------------------------------------------
+# host mirrors
+# ---------------------------------------------------------------------------------------------
+def test_state_dict_layout_matches_reference_keys():
+    from pemp_amd.networks import pemp_stage1 as m
+    for backbone, name in (("resnet50", "stage1_rn50"), ("vgg16", "stage1_vgg16")):
+        net = m.PEMPStage1(None, backbone=backbone)
+        mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+        assert mine == util.key_spec(name), name
+    net = m.ModelClass(None)
+    trainable = [p for p in net.parameters() if p.requires_grad]
+    assert len(list(net.parameters())) == 156 and len(trainable) == 148
+    assert sum(p.numel() for p in trainable) == 11955392
+
+
+def test_stage1_rejects_unknown_backbone_and_cpu_inputs():
+    from pemp_amd.networks import pemp_stage1 as m
+    with pytest.raises(ValueError, match="Not supported backbone 'alexnet'"):
+        m.PEMPStage1(None, backbone="alexnet")
+    net = m.ModelClass(None).eval()
+    x = torch.zeros(1, 1, 3, 33, 33)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(x, torch.zeros(1, 1, 2, 33, 33), x)
+
+
+def test_config_layer_sacred_subset():
+    from pemp_amd.config import Ingredient, Experiment
+    ing = Ingredient("net")
+
+    @ing.config
+    def cfg():
+        a = 1            # noqa: F841
+        b = a + 1        # noqa: F841
+
+    @ing.config
+    def cfg2(b):
+        c = b * 10       # noqa: F841
+
+    @ing.capture
+    def f(x, a, c, z=5):
+        return x, a, c, z
+
+    assert ing.cfg == {"a": 1, "b": 2, "c": 20}
+    assert f(0) == (0, 1, 20, 5) and f(0, c=7) == (0, 1, 7, 5) and f(0, 9) == (0, 9, 20, 5)
+    ex = Experiment("t", ingredients=[ing])
+
+    @ex.config
+    def excfg():
+        split = -1       # noqa: F841
+
+    @ex.command
+    def show(_config, split):
+        return split, _config["net"]["a"], _config["net"]["c"]
+
+    assert ex.run_commandline(["prog", "show", "with", "split=2", "net.a=4"]) == (2, 4, 50)
+
+
+def test_entry_config_surface():
+    from pemp_amd.entry import pemp_stage1 as e
+    cfg = e.ex.full_config()
+    for k, v in dict(tag="pemp_stage1", shot=1, query=1, split=-1, seed=1234, ckpt="bestckpt.pth", exp_id=-1,
+                     loss="ce", sigma=5.0).items():
+        assert cfg[k] == v
+    assert cfg["net"] == dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
+                              drop_rate=0.1, block_size=4)
+    assert e.get_val_labels(0) == [1, 2, 3, 4, 5] and e.get_val_labels(1, "COCO") == list(range(21, 41))
+
+
+# ---------------------------------------------------------------------------------------------
+# C ABI
+# ---------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(hip_lib):
+    from pemp_amd import _lib
+    header = open(os.path.join(ROOT, "include", "pemp_hip.h")).read()
+    declared = set(re.findall(r"\b(pemp_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+    assert hip_lib.pemp_abi_version() == 1
+    assert ctypes.sizeof(_lib.ConvDesc) == 18 * 4
+    # argument validation happens before any device work
+    d = _lib.ConvDesc()
+    assert hip_lib.pemp_conv2d_nhwc_f32(ctypes.byref(d), None, None, None, None, None, None, None) == -1
+    assert b"null pointer" in hip_lib.pemp_last_error()
+    assert hip_lib.pemp_mpm_workspace_bytes(1, 1, 2601, 512, 3) > 6 * 2601 * 4
