@@ -72,6 +72,23 @@ class SyntheticEpisodes:
         return (t(ep["sup_img"]), t(ep["sup_mask"]), t(ep["qry_img"])), t(ep["qry_mask"]), torch.tensor([ep["cls"]])
 
 
+def shard_indices(n, rank, world):
+    """Episode indices of one rank: every rank builds the same task list and takes tasks[rank::world]."""
+    return range(rank, n, world)
+
+
+def allreduce_round(stat, loss_sum, count, device=None):
+    """SUM over ranks of the (integer-valued) tp/fp/fn table, the per-episode loss sum and the episode
+    count -- the only collective of the evaluation path.  Works on any backend (RCCL on GPU, gloo on CPU)."""
+    pack = torch.from_numpy(np.concatenate([np.asarray(stat, np.float64).reshape(-1), [loss_sum, float(count)]]))
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if device is not None and dist.get_backend() == "nccl":
+            pack = pack.to(device)
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+        pack = pack.cpu()
+    return pack[:-2].numpy().reshape(np.shape(stat)), float(pack[-2]), float(pack[-1])
+
+
 class Evaluator:
     def __init__(self, model, device=None, use_graph=True):
         self.model = model
@@ -111,7 +128,7 @@ class Evaluator:
             metric = FewShotMetric(num_classes)
             dataset.sample_tasks()
             rows, classes = [], []
-            for i in range(rank, len(dataset), world):
+            for i in shard_indices(len(dataset), rank, world):
                 inputs, qry_msk, cls = dataset.task(i)
                 t0 = time.time()
                 _, stats = self.test_step_device(inputs, qry_msk)
@@ -125,17 +142,12 @@ class Evaluator:
             metric.update_counts(st[:, 2:], classes)
             # per-episode losses are averaged like the reference: mean over episodes of (CE mean)
             loss_sum = float((st[:, 0] / np.maximum(st[:, 1], 1.0)).sum())
-            pack = torch.from_numpy(np.concatenate([metric.stat.reshape(-1), [loss_sum, float(len(classes))]]))
-            if world > 1:
-                pack = pack.to(self.device)
-                dist.all_reduce(pack, op=dist.ReduceOp.SUM)
-                pack = pack.cpu()
-            metric.stat = pack[:-2].numpy().reshape(metric.stat.shape)
+            metric.stat, loss_tot, n_tot = allreduce_round(metric.stat, loss_sum, len(classes), self.device)
             miou_c, miou = metric.mIoU(val_labels)
             biou_c, biou = metric.mIoU(val_labels, binary=True)
             if logger is not None and rank == 0:
                 logger.info(f"[round {epoch}/{te_epochs}] mIoU: {miou * 100:5.2f}  |  bIoU: {biou * 100:5.2f}")
-            accum.update(loss=float(pack[-2] / pack[-1]), miou=miou_c, biou=biou_c)
+            accum.update(loss=loss_tot / max(n_tot, 1.0), miou=miou_c, biou=biou_c)
         self.cps = calls / timed if timed > 0 else 0.0
         return accum.mean(["loss", "miou", "biou"])
 

@@ -1,0 +1,63 @@
+"""N > 1 evaluation path on CPU: two gloo ranks shard a round of episodes, reduce the metric table
+once, and must reproduce the single-process mIoU bit for bit."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _episode_counts(i):
+    rng = np.random.RandomState(1000 + i)
+    tp, fp, fn = rng.randint(0, 50000, 3)
+    tp2, fp2, fn2 = rng.randint(0, 50000, 3)
+    return np.array([tp, fp, fn, tp2, fp2, fn2], np.float64), 1 + i % 5, rng.rand()
+
+
+def _round(n, rank, world):
+    from pemp_amd.core.metrics import FewShotMetric
+    from pemp_amd.entry.pemp_stage1 import allreduce_round, shard_indices
+    m = FewShotMetric(20)
+    loss, cnt = 0.0, 0
+    for i in shard_indices(n, rank, world):
+        c, cls, l = _episode_counts(i)
+        m.update_counts(c[None], [cls])
+        loss += l
+        cnt += 1
+    m.stat, loss, cnt = allreduce_round(m.stat, loss, cnt)
+    return m.mIoU([1, 2, 3, 4, 5])[1], m.mIoU([1, 2, 3, 4, 5], binary=True)[1], m.stat.copy(), loss, cnt
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _round(n, rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_eval_round_equals_single_process():
+    n = 37                                   # ragged: ranks get 19 and 18 episodes
+    single = _round(n, 0, 1)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        miou, biou, stat, loss, cnt = got[r]
+        assert miou == single[0] and biou == single[1]          # integer tables: exact
+        assert np.array_equal(stat, single[2]) and cnt == n
+        assert abs(loss - single[3]) < 1e-9
