@@ -143,7 +143,7 @@ class ResNetCMEngine(ResNetEngine):
         mask, stat = ops.cm_reduce(x, mask, stride)
         n, _, c = stat.shape
         g = self.group
-        ng = int(g.max().item()) + 1 if g.numel() else 0
+        ng = self.n_groups
         agg = torch.zeros((ng, 2 * c), dtype=torch.float32, device=x.device)
         cnt = torch.zeros((ng, 1), dtype=torch.float32, device=x.device)
         agg.index_add_(0, g, stat.reshape(n, 2 * c))

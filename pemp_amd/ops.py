@@ -256,16 +256,20 @@ def upsample_nearest_u8_i64(resp, out_hw):
     return out
 
 
-def eval_tail(pred, target, want_logits=False, ws_cache=None):
-    """pred [B,2,h,w]; target int64 [B,Ho,Wo] -> (argmax uint8 [B,Ho,Wo], stats f64 [B,8], logits|None)."""
+def eval_tail(pred, target, want_logits=False, ws_cache=None, out_hw=None):
+    """pred [B,2,h,w]; target int64 [B,Ho,Wo] (or None with ``out_hw``: argmax only, statistics are zero)
+    -> (argmax uint8 [B,Ho,Wo], stats f64 [B,8], logits|None)."""
     lib = _lib.load()
     _chk_dev(pred, target)
     b, c, h, w = pred.shape
     if c != 2 or not pred.is_contiguous():
         raise ValueError("eval_tail: pred must be contiguous [B,2,h,w]")
-    if target.dtype != torch.int64 or not target.is_contiguous() or target.shape[0] != b:
-        raise ValueError("eval_tail: target must be contiguous int64 [B,Ho,Wo]")
-    ho, wo = target.shape[-2:]
+    if target is None:
+        ho, wo = int(out_hw[0]), int(out_hw[1])
+    else:
+        if target.dtype != torch.int64 or not target.is_contiguous() or target.shape[0] != b:
+            raise ValueError("eval_tail: target must be contiguous int64 [B,Ho,Wo]")
+        ho, wo = target.shape[-2:]
     am = torch.empty((b, ho, wo), dtype=torch.uint8, device=pred.device)
     stats = torch.empty((b, 8), dtype=torch.float64, device=pred.device)
     logits = torch.empty((b, 2, ho, wo), dtype=torch.float32, device=pred.device) if want_logits else None

@@ -1,5 +1,5 @@
 import sys, torch, collections
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pemp_amd import ops
 import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1

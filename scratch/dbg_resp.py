@@ -1,5 +1,5 @@
 import sys, torch, numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import util
 from oracle import ref_cpu
 from pemp_amd.networks import pemp_stage1 as m

@@ -234,3 +234,17 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert hip_lib.pemp_conv2d_nhwc_f32(ctypes.byref(d), None, None, None, None, None, None, None) == -1
     assert b"null pointer" in hip_lib.pemp_last_error()
     assert hip_lib.pemp_mpm_workspace_bytes(1, 1, 2601, 512, 3) > 6 * 2601 * 4
+
+
+def test_state_dict_layout_baseline_and_stage2():
+    from pemp_amd.networks import baseline as b, pemp_stage2 as s2
+    spec = lambda net: [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+    assert spec(b.Baseline(None, backbone="vgg16")) == util.key_spec("baseline_vgg16")
+    assert spec(b.Baseline(None, backbone="resnet50")) == util.key_spec("baseline_rn50")
+    net = s2.PEMPStage2(1, 1, None)
+    assert spec(net) == util.key_spec("stage2_rn50cm")
+    assert net.encoder.backbone.conv1.weight.shape == (64, 4, 7, 7)
+    assert tuple(net.encoder.backbone.linear3.weight.shape) == (2, 1024)
+    with pytest.raises(NotImplementedError, match="VGG16CM is broken"):
+        s2.PEMPStage2(1, 1, None, backbone2="vgg16")
+    assert s2.PriorNet.__name__ in ("PEMPStage1", "PEMP_Stage1/Resnet50", "PEMP_Stage1/VGG16")

@@ -1,0 +1,117 @@
+"""End-to-end parity of the other models of the hot path (Baseline VGG16 / ResNet-50, stage-1 VGG16,
+stage-1 plain-MAP branch, stage-2 ResNet-50+CM) against the reference's golden vectors.
+Tolerances as in test_stage1_gpu.py (VGG accumulates K = 4608 products per output, 13 layers deep)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(g, e, logits, tgt, feats=None, H=97, ltol=5e-3, agree_min=0.998):
+    logits = logits.cpu()
+    lref = torch.from_numpy(g[f"e{e}_logits_s7"])
+    lerr = (logits[0, :, ::7, ::7] - lref).abs().max().item()
+    assert lerr < ltol, f"logit err {lerr}"
+    am = logits.argmax(1).numpy().astype(np.uint8)
+    ref_bits = np.unpackbits(g[f"e{e}_argmax_bits"])[: am.size].reshape(am.shape)
+    agree = (am == ref_bits).mean()
+    assert agree >= agree_min, f"argmax agreement {agree}"
+    loss = torch.nn.functional.cross_entropy(logits, tgt.cpu(), ignore_index=255).item()
+    assert abs(loss - float(g[f"e{e}_loss"])) < 2e-4
+    if feats is not None:
+        f = feats.cpu().permute(0, 3, 1, 2)
+        fref = torch.from_numpy(g[f"e{e}_feat_c8"])
+        fgot = f[:, ::8] if H <= 97 else f[:, ::8, ::5, ::5]
+        ferr = ((fgot - fref).abs() / (1 + fref.abs())).max().item()
+        assert ferr < 2e-3, f"feature err {ferr}"
+    return lerr, agree
+
+
+@pytest.mark.parametrize("backbone,keys,fixtures", [
+    ("vgg16", "baseline_vgg16", ["baseline_vgg16_small", "baseline_vgg16_small5", "baseline_vgg16_full"]),
+    ("resnet50", "baseline_rn50", ["baseline_rn50_small"])])
+def test_baseline_matches_reference_golden(hip_lib, dev, backbone, keys, fixtures):
+    from pemp_amd.networks import baseline as m
+    net = m.Baseline(None, backbone=backbone)
+    net.load_state_dict(util.wgen_state_dict(keys))
+    net = net.to(dev).eval()
+    for fx in fixtures:
+        g = util.gold(fx)
+        shot, H = int(g["shot"]), int(g["H"])
+        for e, seed in enumerate(g["seeds"]):
+            hw = tuple(int(v) for v in g[f"e{e}_out_hw"])
+            t = util.episode_tensors(seed, shot, H, hw, dev)
+            with torch.no_grad():
+                out = net(t["sup_img"], t["sup_mask"], t["qry_img"], hw)
+            _compare(g, e, out, t["qry_mask"], net._last_feats, H)
+
+
+def test_stage1_vgg16_matches_reference_golden(hip_lib, dev):
+    from pemp_amd.networks import pemp_stage1 as m
+    net = m.PEMPStage1(None, backbone="vgg16")
+    net.load_state_dict(util.wgen_state_dict("stage1_vgg16"))
+    net = net.to(dev).eval()
+    g = util.gold("stage1_vgg16_small")
+    for e, seed in enumerate(g["seeds"]):
+        hw = tuple(int(v) for v in g[f"e{e}_out_hw"])
+        t = util.episode_tensors(seed, 1, 97, hw, dev)
+        with torch.no_grad():
+            out = net(t["sup_img"], t["sup_mask"], t["qry_img"], hw)
+        _compare(g, e, out, t["qry_mask"], net._last_feats)
+
+
+def test_stage1_plain_map_branch_matches_reference_golden(hip_lib, dev):
+    from pemp_amd.networks import pemp_stage1 as m
+    net = m.PEMPStage1(None, protos=0)
+    sd = util.wgen_state_dict("stage1_rn50")
+    sd.pop("ctr")
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    g = util.gold("stage1_rn50_map_small")
+    t = util.episode_tensors(11, 2, 97, (80, 120), dev)
+    with torch.no_grad():
+        out = net(t["sup_img"], t["sup_mask"], t["qry_img"], (80, 120), protos=0)
+    assert (out[0].cpu() - torch.from_numpy(g["e0_logits"])).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("fixture", ["stage2_rn50cm_small", "stage2_rn50cm_small5"])
+def test_stage2_matches_reference_golden(hip_lib, dev, fixture):
+    from pemp_amd.networks import pemp_stage2 as m
+    g = util.gold(fixture)
+    shot, H = int(g["shot"]), int(g["H"])
+    net = m.PEMPStage2(shot, 1, None)
+    net.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+    net = net.to(dev).eval()
+    for e, seed in enumerate(g["seeds"]):
+        hw = tuple(int(v) for v in g[f"e{e}_out_hw"])
+        t = util.episode_tensors(seed, shot, H, hw, dev)
+        prior = torch.from_numpy(np.unpackbits(g[f"e{e}_prior_bits"])[: H * H].reshape(1, 1, H, H).astype(np.int64)).to(dev)
+        with torch.no_grad():
+            out, resp = net(t["sup_img"], t["sup_mask"], t["qry_img"], prior, hw, ret_ind=True)
+        _compare(g, e, out, t["qry_mask"], net._last_feats, H)
+        ap = net.adaptive_p.cpu()
+        ref = torch.from_numpy(g[f"e{e}_adaptive_p"])
+        assert ((ap - ref).abs() / (1 + ref.abs())).max().item() < 2e-3
+        assert ((resp[0, ::7, ::7].cpu().numpy() >= 3) == (g[f"e{e}_resp_s7"] >= 3)).mean() > 0.99
+
+
+def test_stage2_prior_from_stage1_pipeline(hip_lib, dev):
+    """Evaluator.test_step of stage 2 (entry/pemp_stage2.py:58-65): stage-1 argmax at 401-style full size
+    feeds stage 2; the device-side argmax (eval_tail without target) must equal the logits' argmax."""
+    from pemp_amd import ops
+    from pemp_amd.networks import pemp_stage1 as m1
+    s1 = m1.ModelClass(None)
+    s1.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    s1 = s1.to(dev).eval()
+    t = util.episode_tensors(3, 1, 97, (80, 120), dev)
+    with torch.no_grad():
+        logits = s1(t["sup_img"], t["sup_mask"], t["qry_img"])
+        pred, _ = s1.lowres(t["sup_img"], t["sup_mask"], t["qry_img"])
+        am, _, _ = ops.eval_tail(pred, None, out_hw=(97, 97))
+    assert torch.equal(am.long(), logits.argmax(1))
+    g = util.gold("stage2_rn50cm_small")
+    ref_prior = np.unpackbits(g["e0_prior_bits"])[: 97 * 97].reshape(1, 97, 97)
+    assert (am.cpu().numpy() == ref_prior).mean() > 0.998
