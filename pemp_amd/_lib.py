@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime our .so binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpemp_hip.so")
+LIB_PATH = os.environ.get("PEMP_HIP_LIB", os.path.join(_HERE, "libpemp_hip.so"))   # override: kernel experiments only
 
 c_fp = C.c_void_p          # device pointers travel as integers
 c_int = C.c_int

@@ -1,0 +1,253 @@
+// Implicit-GEMM convolution, LDS-DMA staging variant (global_load_lds_dwordx4): operand tiles go
+// HBM/L2 -> LDS without passing through VGPRs, so the K loop has no staging registers and no
+// ds_write at all.  Same GEMM view, same MFMA order and therefore bit-identical results to
+// conv_igemm.hip; only the LDS image differs:
+//
+//   A tile  As[buf][row][8 quads] (row-major, 128 B per row; B tile alike).  One DMA
+//   wave-instruction moves 8 rows x 128 B: lane (rl = lane>>3, p = lane&7) lands at
+//   row*128 + p*16, i.e. the image is lane-linear as the hardware requires (dst = M0 + lane*16).
+//   To keep the MFMA fragment reads (32 rows x one quad per ds_read_b128) conflict-free the quad
+//   order inside a row is XOR-swizzled ON THE SOURCE SIDE: position p of row r holds quad
+//   p ^ ((r>>1)&7); the lane simply fetches that quad of its row (same 128-B line, so coalescing
+//   is untouched) and the reader looks quad Q up at position Q ^ ((r>>1)&7).
+//
+//   Out-of-image taps (zero padding) are fetched from a 16-byte zero block.
+#include "conv_common.h"
+
+namespace pemp {
+
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WGM, bool STEM>
+__global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
+    constexpr int WGN = 4 / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AL = BM / 32, BL = BN / 32;   // DMA wave-instructions per thread per K step
+    constexpr int NBUF = 2;
+
+    extern __shared__ __attribute__((aligned(16))) v4f smem[];
+    v4f* As = smem;                      // [NBUF][BM][8]
+    v4f* Bs = smem + NBUF * BM * 8;      // [NBUF][BN][8]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WGN) * WM;
+    const int wn0 = (wave % WGN) * WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const int ntn = a.Cout / BN;
+    const int tile_id = xcd_tile_order(blockIdx.x, gridDim.x);
+    const int bm = tile_id / ntn;
+    const int bn = tile_id % ntn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // loader role: thread (r, p) fetches, for rows r + 32 i, the quad that belongs at position p
+    const int p = tid & 7;
+    const int r = tid >> 3;
+    const int sq = p ^ ((r >> 1) & 7);          // source quad (same for every i: 32 i >> 1 = 0 mod 8)
+    const float* zero = g_zero16;
+
+    int a_pix[AL], a_hi0[AL], a_wi0[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        int m = m0 + r + 32 * i;
+        bool ok = m < a.M;
+        int mm = ok ? m : 0;
+        int img = mm / a.HoWo;
+        int rem = mm - img * a.HoWo;
+        int ho = rem / a.Wo;
+        int wo = rem - ho * a.Wo;
+        int hi0 = ho * a.stride - a.pad;
+        int wi0 = wo * a.stride - a.pad;
+        a_hi0[i] = ok ? hi0 : -(1 << 28);
+        a_wi0[i] = wi0;
+        a_pix[i] = img * a.H * a.W + hi0 * a.W + wi0;
+    }
+    const float* pa[AL];
+    const float* pb[BL];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) pb[i] = a.w + (size_t)(n0 + r + 32 * i) * a.Kpad + sq * 4;
+    int cur_tap = 0, cur_cb = 0;
+
+#define PEMP_SET_TAP(tap_)                                                                           \
+    do {                                                                                             \
+        const int tap__ = (tap_);                                                                    \
+        const int kh = tap__ / a.KW, kw = tap__ - kh * a.KW;                                         \
+        const int dh = kh * a.dil, dw = kw * a.dil;                                                  \
+        const bool tok = tap__ < a.ntaps;                                                            \
+        _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                             \
+            const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                        \
+            const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;     \
+            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + sq * 4 : zero;        \
+        }                                                                                            \
+    } while (0)
+
+    // issue the DMA of the cursor's K step (generic) / of K step kt_ (stem) into buffer buf_
+#define PEMP_DMA(kt_, buf_)                                                                          \
+    do {                                                                                             \
+        v4f* Ad_ = As + (buf_) * BM * 8 + wave * 64;                                                 \
+        v4f* Bd_ = Bs + (buf_) * BN * 8 + wave * 64;                                                 \
+        if constexpr (STEM) {                                                                        \
+            const int tap = (kt_) * 8 + sq;                                                          \
+            const int kh = tap / a.KW, kw = tap - kh * a.KW;                                         \
+            const bool tok = tap < a.ntaps;                                                          \
+            const int dh = kh * a.dil, dw = kw * a.dil;                                              \
+            _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
+                const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                    \
+                const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
+                const float* s_ = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * 4 : zero;       \
+                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(Ad_ + i * 256), 16, 0, 0);    \
+            }                                                                                        \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < AL; ++i)                                           \
+                __builtin_amdgcn_global_load_lds((gptr_t)pa[i], (lptr_t)(Ad_ + i * 256), 16, 0, 0); \
+        }                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < BL; ++i)                                               \
+            __builtin_amdgcn_global_load_lds((gptr_t)pb[i], (lptr_t)(Bd_ + i * 256), 16, 0, 0);     \
+    } while (0)
+
+#define PEMP_ADVANCE()                                                                               \
+    do {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] += 32;                                  \
+        if constexpr (!STEM) {                                                                       \
+            if (++cur_cb == a.cin_steps) {                                                           \
+                cur_cb = 0;                                                                          \
+                ++cur_tap;                                                                           \
+                PEMP_SET_TAP(cur_tap);                                                               \
+            } else {                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < AL; ++i) pa[i] = pa[i] == zero ? zero : pa[i] + 32; \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    if constexpr (!STEM) PEMP_SET_TAP(0);
+    PEMP_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment read positions: quad Q of row (.. + lr) sits at position Q ^ ((lr>>1)&7)
+    const int rsw = (lr >> 1) & 7;
+    const int arow = (wm0 + lr) * 8, brow = (wn0 + lr) * 8;
+    for (int kt = 0; kt < a.nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < a.nk) {      // wave-uniform
+            PEMP_ADVANCE();
+            PEMP_DMA(kt + 1, buf ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        const v4f* Ab = As + buf * BM * 8;
+        const v4f* Bb = Bs + buf * BN * 8;
+        v4f af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) af[0][mi] = Ab[arow + mi * 256 + (lh ^ rsw)];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[0][ni] = Bb[brow + ni * 256 + (lh ^ rsw)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < 3) {
+                const int pos = (2 * (j + 1) + lh) ^ rsw;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) af[(j + 1) & 1][mi] = Ab[arow + mi * 256 + pos];
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) bf[(j + 1) & 1][ni] = Bb[brow + ni * 256 + pos];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const v4f av = af[j & 1][mi], bv = bf[j & 1][ni];
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of step kt+1 have landed
+        __syncthreads();                                    // ... and everybody's; all reads of `buf` are done
+    }
+#undef PEMP_DMA
+#undef PEMP_ADVANCE
+#undef PEMP_SET_TAP
+
+    // ---- epilogue (identical to conv_igemm.hip) ----
+    const bool relu = a.flags & PEMP_CONV_RELU;
+    const bool per_img = a.flags & PEMP_CONV_SHIFT_PER_IMAGE;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = n0 + wn0 + ni * 32 + lr;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        const float sh = (a.shift && !per_img) ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int mb = m0 + wm0 + mi * 32 + 4 * lh;
+            float add[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) add[e] = sh;
+            if (per_img) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int mc = min(mb + (e & 3) + 8 * (e >> 2), a.M - 1);
+                    add[e] += a.shift[(size_t)(mc / a.HoWo) * a.Cout + n];
+                }
+            }
+            if (a.res) {
+                float rv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int mc = min(mb + (e & 3) + 8 * (e >> 2), a.M - 1);
+                    rv[e] = a.res[(size_t)mc * a.ldr + n];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) add[e] += rv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                float v = acc[mi][ni][e] * sc + add[e];
+                if (relu) v = fmaxf(v, 0.f);
+                if (m < a.M) a.y[(size_t)m * a.ldy + n] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, bool STEM>
+static int launch_dma(const ConvArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
+    auto kern = conv_dma_kernel<BM, BN, WGM, STEM>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    const int grid = cdiv(a.M, BM) * (a.Cout / BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    return launch_status("conv_dma");
+}
+
+int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st) {
+    const bool stem = a.flags & PEMP_CONV_STEM4;
+    if (tile == 1) return stem ? launch_dma<128, 128, 2, true>(a, st) : launch_dma<128, 128, 2, false>(a, st);
+    if (tile == 2) return stem ? launch_dma<128, 64, 2, true>(a, st) : launch_dma<128, 64, 2, false>(a, st);
+    return stem ? launch_dma<64, 64, 2, true>(a, st) : launch_dma<64, 64, 2, false>(a, st);
+}
+
+}  // namespace pemp

@@ -23,24 +23,10 @@
 //
 //   Staging: global -> registers (issued before the MFMAs of the current step) -> LDS buffer
 //   b^1 after them; one __syncthreads per K step.
-#include "common.h"
+#include "conv_common.h"
 
 namespace pemp {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float v4f;   // first-class vector: loads/stores never become memcpy
-
-struct ConvArgs {
-    const float* x;
-    const float* w;
-    float* y;
-    const float* scale;
-    const float* shift;
-    const float* res;
-    int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, KH, KW, stride, pad, dil, ldr, Kpad;
-    unsigned flags;
-    int M, HoWo, cin_steps, nk, ntaps;
-};
 
 template <int BM, int BN, int WGM, bool STEM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -63,8 +49,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     // n tiles vary fastest so that consecutive blocks reuse one A row-panel from L2
     const int ntn = a.Cout / BN;
-    const int bm = blockIdx.x / ntn;
-    const int bn = blockIdx.x % ntn;
+    const int tile_id = xcd_tile_order(blockIdx.x, gridDim.x);
+    const int bm = tile_id / ntn;
+    const int bn = tile_id % ntn;
     const int m0 = bm * BM, n0 = bn * BN;
 
     // ---- staging roles: thread (q, r) moves quad q of rows r + 32 i --------------------------
@@ -93,42 +80,68 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < BL; ++i) wrow[i] = a.w + (size_t)(n0 + r + 32 * i) * a.Kpad + q * 4;
 
     v4f ra[AL], rb[BL];
-    unsigned okmask = 0;   // bit i: ra[i] holds real data (else it must be zeroed before staging)
+    unsigned okmask = 0;   // bit i: ra[i] holds real data (else it is zeroed before staging)
 
-    // Global -> register loads of K step `kt`.  Out-of-image taps read a harmless valid address
-    // (the tensor base) and are zeroed at staging time, so every load is unconditional and the
-    // wave never waits on memory before its MFMAs.
+    // Source cursor of the generic path: K steps walk (tap outer, 32-channel chunk inner).  Inside
+    // a tap every row pointer just advances by 32 floats; only a tap change re-derives pointers and
+    // bounds (that keeps the per-step VALU/SALU work next to nothing).  Out-of-image taps point at
+    // the tensor base (a harmless valid address) and are zeroed at staging time, so no load is
+    // conditional per lane and the wave never waits on memory before its MFMAs.
+    const float* pa[AL];
+    const float* pb[BL];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) pb[i] = wrow[i];
+    int cur_tap = 0, cur_cb = 0;
+#define PEMP_SET_TAP(tap_)                                                                           \
+    do {                                                                                             \
+        const int tap__ = (tap_);                                                                    \
+        const int kh = tap__ / a.KW, kw = tap__ - kh * a.KW;                                         \
+        const int dh = kh * a.dil, dw = kw * a.dil;                                                  \
+        const bool tok = tap__ < a.ntaps;                                                            \
+        okmask = 0;                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                             \
+            const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                        \
+            const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;     \
+            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + q * 4 : a.x;          \
+            okmask |= (ok ? 1u : 0u) << i;                                                           \
+        }                                                                                            \
+    } while (0)
+
+    // loads of the CURRENT cursor position (generic) / of K step kt_ (stem)
 #define PEMP_GLOAD(kt_)                                                                              \
     do {                                                                                             \
-        const int kt__ = (kt_);                                                                      \
-        okmask = 0;                                                                                  \
         if constexpr (STEM) {                                                                        \
-            const int tap = kt__ * 8 + q;                                                            \
+            const int tap = (kt_) * 8 + q;                                                           \
             const int kh = tap / a.KW, kw = tap - kh * a.KW;                                         \
             const bool tok = tap < a.ntaps;                                                          \
             const int dh = kh * a.dil, dw = kw * a.dil;                                              \
+            okmask = 0;                                                                              \
             _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
                 const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                    \
                 const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
                 const float* p = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * 4 : a.x;         \
-                ra[i] = *(const v4f*)p;                                                           \
+                ra[i] = *(const v4f*)p;                                                              \
                 okmask |= (ok ? 1u : 0u) << i;                                                       \
             }                                                                                        \
         } else {                                                                                     \
-            const int tap = kt__ / a.cin_steps;                                                      \
-            const int cb = kt__ - tap * a.cin_steps;                                                 \
-            const int kh = tap / a.KW, kw = tap - kh * a.KW;                                         \
-            const int dh = kh * a.dil, dw = kw * a.dil;                                              \
-            const int coff = cb * 32 + q * 4;                                                        \
-            _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                         \
-                const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                    \
-                const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;        \
-                const float* p = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + coff : a.x; \
-                ra[i] = *(const v4f*)p;                                                           \
-                okmask |= (ok ? 1u : 0u) << i;                                                       \
+            _Pragma("unroll") for (int i = 0; i < AL; ++i) ra[i] = *(const v4f*)pa[i];              \
+        }                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < BL; ++i) rb[i] = *(const v4f*)pb[i];                   \
+    } while (0)
+
+    // move the cursor one K step forward
+#define PEMP_ADVANCE()                                                                               \
+    do {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] += 32;                                  \
+        if constexpr (!STEM) {                                                                       \
+            if (++cur_cb == a.cin_steps) {                                                           \
+                cur_cb = 0;                                                                          \
+                ++cur_tap;                                                                           \
+                PEMP_SET_TAP(cur_tap);                                                               \
+            } else {                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < AL; ++i) pa[i] += 32;                          \
             }                                                                                        \
         }                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < BL; ++i) rb[i] = *(const v4f*)(wrow[i] + kt__ * 32); \
     } while (0)
 
 #define PEMP_LSTORE(buf_)                                                                            \
@@ -151,15 +164,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
+    if constexpr (!STEM) PEMP_SET_TAP(0);
     PEMP_GLOAD(0);
     PEMP_LSTORE(0);
     __syncthreads();
 
     const int arow = wm0 + lr, brow = wn0 + lr;
+#ifndef PEMP_ABLATE
+#define PEMP_ABLATE 0   // 1: no global loads in the loop, 2: + no LDS staging/barrier, 3: + no LDS reads (timing builds only)
+#endif
     for (int kt = 0; kt < a.nk; ++kt) {
-        const int buf = kt & 1;
-        // the last iteration re-loads its own tile into the idle buffer: harmless, keeps the loop branch-free
-        PEMP_GLOAD(kt + 1 < a.nk ? kt + 1 : kt);
+        const int buf = (PEMP_ABLATE >= 2) ? 0 : (kt & 1);
+        if (PEMP_ABLATE < 1 && kt + 1 < a.nk) {   // wave-uniform branch; the last step re-stages stale registers (unused)
+            PEMP_ADVANCE();
+            PEMP_GLOAD(kt + 1);
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs (hipcc sinks them to their use)
 
         const v4f* Ab = As + buf * 8 * BM;
@@ -191,10 +210,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        PEMP_LSTORE(buf ^ 1);
-        __syncthreads();
+        if (PEMP_ABLATE < 2) {
+            PEMP_LSTORE(buf ^ 1);
+            __syncthreads();
+        }
     }
 #undef PEMP_GLOAD
+#undef PEMP_ADVANCE
+#undef PEMP_SET_TAP
 #undef PEMP_LSTORE
 
     // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel) ----
@@ -305,6 +328,10 @@ extern "C" int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, con
         tile = 3;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (tile >= 11 && tile <= 13) {      // LDS-DMA staging variants (conv_dma.hip)
+        PEMP_REQUIRE(tile != 11 || a.Cout % 128 == 0, "conv2d: tile 128x128 needs Cout %% 128 == 0");
+        return launch_conv_dma(tile - 10, a, st);
+    }
     if (tile == 1) {
         PEMP_REQUIRE(a.Cout % 128 == 0, "conv2d: tile 128x128 needs Cout %% 128 == 0");
         return stem ? launch_conv<128, 128, 2, true>(a, st) : launch_conv<128, 128, 2, false>(a, st);

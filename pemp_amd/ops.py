@@ -43,12 +43,41 @@ def conv_out_size(i, k, s, p, d):
 
 class ConvParams:
     """Device-resident, pre-packed parameters of one conv (+ folded per-channel affine)."""
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "kh", "kw", "stride", "pad", "dil", "kpad", "stem", "relu")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "kh", "kw", "stride", "pad", "dil", "kpad", "stem", "relu",
+                 "tiles")
 
     def __init__(self, w, scale, shift, cin, cout, kh, kw, stride, pad, dil, kpad, stem, relu):
         self.w, self.scale, self.shift = w, scale, shift
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.stride, self.pad, self.dil, self.kpad, self.stem, self.relu = stride, pad, dil, kpad, stem, relu
+        self.tiles = {}          # autotuned kernel variant per input shape (n, h, w)
+
+
+#: kernel variants the autotuner may pick: id -> (BM, BN); ids >= 11 stage through LDS-DMA.  All variants
+#: accumulate in the same K order, so they are bit-identical and the choice only affects speed.
+TILE_VARIANTS = {13: (64, 64), 12: (128, 64), 11: (128, 128), 3: (64, 64)}
+AUTOTUNE = True
+DEFAULT_TILE = 13
+
+
+def _pick_tile(launch, p, key, cout):
+    """Time the candidate variants once for this (layer, input shape) and remember the fastest."""
+    best, best_ms = DEFAULT_TILE, None
+    for t, (bm, bn) in TILE_VARIANTS.items():
+        if cout % bn:
+            continue
+        launch(t)                                   # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            launch(t)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if best_ms is None or ms < best_ms * 0.98:  # prefer earlier (default) variants on ties
+            best, best_ms = t, ms
+    p.tiles[key] = best
+    return best
 
 
 def pack_conv_weight(w_oihw, stem4=False):
@@ -96,9 +125,19 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
         flags |= CONV_SHIFT_PER_IMAGE
     if p.stem:
         flags |= CONV_STEM4
-    d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, flags, tile)
-    _lib.check(lib.pemp_conv2d_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift),
-                                        _p(residual), _stream()), "pemp_conv2d_nhwc_f32")
+    def launch(t):
+        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, flags, t)
+        _lib.check(lib.pemp_conv2d_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift),
+                                            _p(residual), _stream()), "pemp_conv2d_nhwc_f32")
+
+    if tile == 0:
+        tile = p.tiles.get((n, h, w))
+        if tile is None:
+            if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():
+                tile = _pick_tile(launch, p, (n, h, w), p.cout)
+            else:
+                tile = DEFAULT_TILE
+    launch(tile)
     return out
 
 
