@@ -38,6 +38,33 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Sum 8 per-lane values over the wave with 10 shuffles instead of 48: three "keep half, send half"
+// exchanges (8 -> 4 -> 2 -> 1 value per lane) followed by a butterfly over the remaining lane bits.
+// Returns, in every lane l, the wave-wide sum of v[l & 7].  Fixed order -> deterministic.
+__device__ __forceinline__ float wave_sum8(const float (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+    float a[4], b[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float keep = (lane & 1) ? v[2 * k + 1] : v[2 * k];
+        const float send = (lane & 1) ? v[2 * k] : v[2 * k + 1];
+        a[k] = keep + __shfl_xor(send, 1, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float keep = (lane & 2) ? a[2 * k + 1] : a[2 * k];
+        const float send = (lane & 2) ? a[2 * k] : a[2 * k + 1];
+        b[k] = keep + __shfl_xor(send, 2, 64);
+    }
+    const float keep = (lane & 4) ? b[1] : b[0];
+    const float send = (lane & 4) ? b[0] : b[1];
+    float c = keep + __shfl_xor(send, 4, 64);
+    c += __shfl_xor(c, 8, 64);
+    c += __shfl_xor(c, 16, 64);
+    c += __shfl_xor(c, 32, 64);
+    return c;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace pemp

@@ -80,8 +80,11 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ f
                     }
             }
         }
+        {
+            const float tot = wave_sum8(d);          // lane l holds the total of d[l & 7]
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) d[j] = -wave_sum(d[j]);
+            for (int j = 0; j < MAXJ; ++j) d[j] = -__shfl(tot, j, 64);
+        }
         if (lane == 0) {
             for (int g = 0; g < 2; ++g) {
                 float mx = -INFINITY;
@@ -205,13 +208,13 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
 }
 
 // protos[b][j][c] = mean_s ( sum_chunks part / (denominator + eps) )
-__global__ __launch_bounds__(256) void pool_final_kernel(const float* __restrict__ part,
-                                                         const float* __restrict__ asum,
-                                                         const float* __restrict__ den_override,
-                                                         float* __restrict__ protos, int S, int c, int J, int nchunks,
-                                                         float eps) {
+__global__ __launch_bounds__(64) void pool_final_kernel(const float* __restrict__ part,
+                                                        const float* __restrict__ asum,
+                                                        const float* __restrict__ den_override,
+                                                        float* __restrict__ protos, int S, int c, int J, int nchunks,
+                                                        float eps) {
     const int b = blockIdx.y, j = blockIdx.x;
-    for (int ch = threadIdx.x; ch < c; ch += 256) {
+    for (int ch = blockIdx.z * 64 + threadIdx.x; ch < c; ch += gridDim.z * 64) {
         float tot = 0.f;
         for (int s = 0; s < S; ++s) {
             const int bs = b * S + s;
@@ -284,8 +287,11 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ q
                 }
             }
         }
+        {
+            const float tot = wave_sum8(dot);
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) dot[j] = wave_sum(dot[j]) * scalar;
+            for (int j = 0; j < MAXJ; ++j) dot[j] = __shfl(tot, j, 64) * scalar;
+        }
         if (lane == 0) {
             float best[2];
             int bi[2];
@@ -407,13 +413,13 @@ __global__ __launch_bounds__(256) void eval_tail_kernel(const float* __restrict_
         part[((size_t)b * gridDim.x + blockIdx.x) * 8 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
     }
 }
+// one wave per (episode, statistic): lane-strided partial sums then a fixed butterfly -> deterministic
 __global__ void eval_tail_final_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
-    const int b = blockIdx.x, k = threadIdx.x;
-    if (k < 8) {
-        double s = 0.0;
-        for (int i = 0; i < nblk; ++i) s += part[((size_t)b * nblk + i) * 8 + k];
-        stats[b * 8 + k] = s;
-    }
+    const int b = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
+    double s = 0.0;
+    for (int i = lane; i < nblk; i += 64) s += part[((size_t)b * nblk + i) * 8 + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) stats[b * 8 + k] = s;
 }
 
 static inline int tail_blocks(int Ho, int Wo) {
@@ -454,7 +460,8 @@ static int pooled_protos(int mode, const float* feat, int ldf, const float* mask
     float* part = A + (size_t)BS * J * n;
     float* asum = part + (size_t)BS * nck * J * c;
     float* msum = asum + (size_t)BS * nck * J;
-    const int ablk = min(cdiv(n, 4), 1024);
+    // few, long-lived blocks: every block first loads its lanes' slice of ctr (48 values per lane)
+    const int ablk = min(cdiv(n, 4), max(1, 512 / BS));
     if (mode == 0) {
         PEMP_REQUIRE(ctr, "protos: ctr is null");
         hipLaunchKernelGGL(assign_kernel<0>, dim3(ablk, BS), dim3(256), 0, st, feat, ldf, mask, ctr, A, n, h, w, H, W, c, p);
@@ -467,7 +474,7 @@ static int pooled_protos(int mode, const float* feat, int ldf, const float* mask
     int e = launch_status("protos/assign");
     if (e) return e;
     hipLaunchKernelGGL(pool_partial_kernel, dim3(nck, BS), dim3(256), 0, st, feat, ldf, A, part, asum, n, c, J, nck);
-    hipLaunchKernelGGL(pool_final_kernel, dim3(J, B), dim3(256), 0, st, part, asum, mode == 2 ? msum : (const float*)nullptr,
+    hipLaunchKernelGGL(pool_final_kernel, dim3(J, B, cdiv(c, 64)), dim3(64), 0, st, part, asum, mode == 2 ? msum : (const float*)nullptr,
                        protos, S, c, J, nck, mode == 0 ? 1e-6f : 1e-5f);
     return launch_status("protos/pool");
 }
@@ -492,7 +499,7 @@ extern "C" int pemp_cosine_proto_max_f32(const float* qry, int ldf, const float*
     PEMP_REQUIRE(B > 0 && n > 0 && p >= 1 && 2 * p <= MAXJ, "cosine: bad dims");
     PEMP_REQUIRE(c > 0 && c % 4 == 0 && c <= 64 * MAXCL && ldf >= c && ldf % 4 == 0, "cosine: c=%d must be a multiple of 4 and <= %d", c, 64 * MAXCL);
     PEMP_REQUIRE(((uintptr_t)qry & 15) == 0, "cosine: qry must be 16-byte aligned");
-    hipLaunchKernelGGL(cosine_kernel, dim3(min(cdiv(n, 4), 1024), B), dim3(256), 0, (hipStream_t)stream, qry, ldf, protos,
+    hipLaunchKernelGGL(cosine_kernel, dim3(min(cdiv(n, 4), max(1, 4096 / B)), B), dim3(256), 0, (hipStream_t)stream, qry, ldf, protos,
                        pred, resp, n, c, p, dist_scalar);
     return launch_status("cosine");
 }
@@ -528,6 +535,6 @@ extern "C" int pemp_eval_tail_f32(const float* pred, const int64_t* target, uint
     const int nb = tail_blocks(Ho, Wo);
     hipLaunchKernelGGL(eval_tail_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, pred, target, pred_out,
                        logits_out, (double*)ws, h, w, Ho, Wo);
-    hipLaunchKernelGGL(eval_tail_final_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const double*)ws, stats, nb);
+    hipLaunchKernelGGL(eval_tail_final_kernel, dim3(B, 8), dim3(64), 0, (hipStream_t)stream, (const double*)ws, stats, nb);
     return launch_status("eval_tail");
 }

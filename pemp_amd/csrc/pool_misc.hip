@@ -65,23 +65,37 @@ __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// global average pool: block (n, channel group of 64): 256 threads = 4 pixel-lanes x 64 channels
-__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                  int HW, int C, int ldx) {
-    __shared__ float red[4][64];
+// global average pool: block = (image, 64 channels); 1024 threads = 64 pixel lanes x 16 float4 channel
+// lanes, so every load is 16 B and a wave reads 4 pixels x 256 contiguous bytes.  Fixed summation
+// order (lane-strided partial sums, then a tree over the 64 lanes) -> deterministic.
+__global__ __launch_bounds__(1024) void gap_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                   int HW, int C, int ldx) {
+    __shared__ float4 red[64][16];
     const int n = blockIdx.y;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int pl = threadIdx.x >> 6;
-    float s = 0.f;
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cl * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C) {
         const float* b = x + (long long)n * HW * ldx + c;
-        for (int i = pl; i < HW; i += 4) s += b[(long long)i * ldx];
+        for (int i = pl; i < HW; i += 64) {
+            float4 v = *(const float4*)(b + (long long)i * ldx);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    red[pl][threadIdx.x & 63] = s;
+    red[pl][cl] = s;
     __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        if (pl < o) {
+            float4 a = red[pl][cl], b2 = red[pl + o][cl];
+            a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+            red[pl][cl] = a;
+        }
+        __syncthreads();
+    }
     if (pl == 0 && c < C) {
-        float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        y[(long long)n * C + c] = t / (float)HW;
+        float4 t = red[0][cl];
+        const float inv = (float)HW;
+        *(float4*)(y + (long long)n * C + c) = make_float4(t.x / inv, t.y / inv, t.z / inv, t.w / inv);
     }
 }
 
@@ -208,7 +222,9 @@ extern "C" int pemp_maxpool2d_nhwc_f32(const float* x, float* y, int N, int H, i
 
 extern "C" int pemp_global_avgpool_nhwc_f32(const float* x, float* y, int N, int HW, int C, int ldx, void* stream) {
     PEMP_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && ldx >= C, "global_avgpool: bad arguments");
-    hipLaunchKernelGGL(gap_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, (hipStream_t)stream, x, y, HW, C, ldx);
+    PEMP_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0,
+                 "global_avgpool: C/ldx must be multiples of 4 and x/y 16-byte aligned");
+    hipLaunchKernelGGL(gap_kernel, dim3(cdiv(C, 64), N), dim3(1024), 0, (hipStream_t)stream, x, y, HW, C, ldx);
     return launch_status("global_avgpool");
 }
 
