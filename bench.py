@@ -33,9 +33,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PEMP_BENCH_BATCH", "8")),
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PEMP_BENCH_BATCH", "16")),
                     help="episodes per step (the reference evaluates 1 per step)")
     ap.add_argument("--shot", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
@@ -103,7 +103,7 @@ def conv_roofline(net, pool, reps=3):
     flops = sum(f for _, _, f in records)
     n = len(records)
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel (all conv launches of a step)",
+    return {"bound": "mfma", "kernel": "conv_dma_kernel + conv_igemm_kernel (all conv launches of a step)",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
             "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
