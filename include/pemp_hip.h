@@ -143,6 +143,55 @@ int pemp_eval_tail_f32(const float* pred, const int64_t* target, uint8_t* pred_o
 int pemp_cm_reduce_f32(const float* x, int ldx, const float* mask_in, float* mask_out, float* stat,
                        int N, int Hm, int Wm, int Hx, int Wx, int C, int stride, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training path (Trainer.train_step, entry/pemp_stage1.py:57-65; model.train() at
+ * core/base_trainer.py:189).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Weight gradient of pemp_conv2d_nhwc_f32 (autograd of nn.Conv2d, same call sites):
+ *   dw[co][kh][kw][ci] (+)= sum_m g[m][co] * x[pix(m,kh,kw)][ci]      dw is KRSC with row length d->Kpad
+ * `d` describes the FORWARD conv (d->ldy = per-pixel stride of g).  STEM4 needs Kpad % 64 == 0. */
+size_t pemp_conv2d_wgrad_workspace_bytes(const pemp_conv_desc* d);
+int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* g, float* dw,
+                               int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* nn.BatchNorm2d in train mode (networks/backbones.py:48-52; batch statistics, momentum update
+ * of the running statistics with the unbiased variance): per-channel mean / 1/sqrt(var+eps).  */
+size_t pemp_colsum_workspace_bytes(int M, int C);
+int pemp_bn_stats_f32(const float* z, int ldz, int M, int C, float eps, float momentum,
+                      float* mean, float* invstd, float* run_mean, float* run_var,
+                      void* ws, size_t ws_bytes, void* stream);
+/* y = relu?((z-mean)*invstd*gamma + beta (+ residual))  (BottleNeck.forward, backbones.py:66-75) */
+int pemp_bn_apply_f32(const float* z, int ldz, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, const float* residual, int ldr,
+                      float* y, int ldy, int M, int C, int relu, void* stream);
+/* backward of the above: g = dy*(y>0 if relu) [optionally stored to gout = gradient of the residual
+ * branch]; dgamma = sum g*xhat, dbeta = sum g, dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).     */
+int pemp_bn_bwd_f32(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,
+                    const float* mean, const float* invstd, const float* gamma,
+                    float* dz, int lddz, float* gout, int ldg, float* dgamma, float* dbeta,
+                    int M, int C, int relu, void* ws, size_t ws_bytes, void* stream);
+/* g = (dy (+ add)) * (y>0 if relu); dbias[c] = sum_m g[m][c] (NULL: skip).  Backward of conv bias + ReLU
+ * (networks/pemp_stage1.py:74-78, backbones.py:330-357).                                           */
+int pemp_relu_bias_bwd_f32(const float* dy, int lddy, const float* y, int ldy, const float* add, int lda,
+                           float* g, int ldg, float* dbias, int M, int C, int relu,
+                           void* ws, size_t ws_bytes, void* stream);
+/* backward of nn.MaxPool2d (first maximum in scan order wins, as ATen).                           */
+int pemp_maxpool2d_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
+                                int Ho, int Wo, int k, int s, int p, void* stream);
+/* dst[n,hs*s,ws*s,:] = src[n,hs,ws,:], zero elsewhere: input gradient of a stride-s 1x1 conv.     */
+int pemp_scatter_strided_nhwc_f32(const float* src, float* dst, int N, int H, int W, int Hs, int Ws,
+                                  int C, int s, void* stream);
+/* dst[n][i][c] += v[n][c] / HW : backward of F.adaptive_avg_pool2d(x,(1,1)).                      */
+int pemp_gap_bwd_add_nhwc_f32(const float* v, float* dst, int ld, int N, int HW, int C, void* stream);
+/* nn.utils.clip_grad_norm_(params, max_norm) + SGD(momentum, weight_decay).step() on flat buffers
+ * (entry/pemp_stage1.py:63-64, core/solver.py:87-91).  grad_scale multiplies the gradients first
+ * (1/world after a SUM all-reduce); max_norm <= 0 disables clipping; grad_norm_out[0] = ||g||_2.  */
+size_t pemp_sgd_workspace_bytes(void);
+int pemp_sgd_clip_step_f32(float* params, const float* grads, float* momentum_buf, long long n,
+                           float max_norm, float lr, float momentum, float weight_decay, int first_step,
+                           float grad_scale, float* grad_norm_out, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,10 +25,16 @@ BN_EPS = 1e-5
 # ------------------------------------------------------------------------------------------
 # building blocks
 # ------------------------------------------------------------------------------------------
+TRAIN = False     # module switch: True = model.train() semantics for BatchNorm (batch statistics,
+                  # running-stat update with momentum 0.1); DropBlock/Dropout2d stay identities, i.e.
+                  # drop_rate = 0 (their random streams cannot be pinned: dropblock's source is absent)
+
+
 def _bn(x, sd, p):
-    """nn.BatchNorm2d in eval mode (networks/backbones.py:48-52,90,111,328)."""
+    """nn.BatchNorm2d (networks/backbones.py:48-52,90,111,328): eval -> running statistics;
+    train (core/base_trainer.py:189) -> batch statistics, running stats updated in place."""
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
-                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS)
+                        sd[p + ".weight"], sd[p + ".bias"], TRAIN, 0.1 if TRAIN else 0.0, BN_EPS)
 
 
 def _conv(x, sd, p, stride=1, padding=0, dilation=1):

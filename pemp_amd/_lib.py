@@ -49,6 +49,24 @@ SYMBOLS = {
     "pemp_eval_tail_workspace_bytes": (c_size, [c_int] * 3),
     "pemp_eval_tail_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size] + [c_int] * 5 + [c_fp]),
     "pemp_cm_reduce_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp]),
+    # training path
+    "pemp_conv2d_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
+    "pemp_conv2d_wgrad_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_int, c_fp, c_size, c_fp]),
+    "pemp_colsum_workspace_bytes": (c_size, [c_int, c_int]),
+    "pemp_bn_stats_f32": (c_int, [c_fp, c_int, c_int, c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp,
+                                  c_fp, c_size, c_fp]),
+    "pemp_bn_apply_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int,
+                                  c_int, c_fp]),
+    "pemp_bn_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int,
+                                c_fp, c_fp, c_int, c_int, c_int, c_fp, c_size, c_fp]),
+    "pemp_relu_bias_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int,
+                                       c_int, c_fp, c_size, c_fp]),
+    "pemp_maxpool2d_bwd_nhwc_f32": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp]),
+    "pemp_scatter_strided_nhwc_f32": (c_int, [c_fp, c_fp] + [c_int] * 7 + [c_fp]),
+    "pemp_gap_bwd_add_nhwc_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "pemp_sgd_workspace_bytes": (c_size, []),
+    "pemp_sgd_clip_step_f32": (c_int, [c_fp, c_fp, c_fp, C.c_longlong, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, c_int, C.c_float, c_fp, c_fp, c_size, c_fp]),
 }
 
 _lib = None

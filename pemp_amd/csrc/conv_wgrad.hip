@@ -1,0 +1,220 @@
+// Weight gradient of the convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32:
+//
+//     dW[co][tap][ci] = sum_m  g[m][co] * x[pix(m, tap)][ci]          (m = output pixel)
+//
+//   GEMM view: rows = co, columns = (tap, ci) (the KRSC weight row), reduction = m.
+//   Block = 256 threads = 2x2 waves, output tile 64 co x 64 columns (one tap, 64 input channels;
+//   for the NHWC4 stem: 16 taps x 4 channels).  One reduction step = 32 pixels: the g tile
+//   [32 px][64 co] and the gathered x tile [32 px][64 ci] go global -> LDS by LDS-DMA in their
+//   natural (pixel-major) layout -- the MFMA contracts over pixels, so lane (r = l&31, k = l>>5)
+//   reads ONE float g[px 2t+k][co r] / x[px 2t+k][ci r] per MFMA: 32 consecutive dwords per half
+//   wave, conflict-free ds_read_b32, no transpose anywhere.
+//
+//   The reduction over M is split over blockIdx.z; partial tiles go to a workspace and a second
+//   kernel adds them in a fixed order (deterministic, no atomics).
+#include "conv_common.h"
+
+namespace pemp {
+
+static __device__ __attribute__((aligned(16))) float w_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct WgradArgs {
+    const float* x;    // input activations  [N,H,W,ldx]
+    const float* g;    // output gradient    [M][ldg]
+    float* out;        // dW (nsplit == 1) or workspace [nsplit][Cout][Kpad]
+    int N, H, W, Cin, ldx, Ho, Wo, Cout, ldg, KH, KW, stride, pad, dil, Kpad;
+    int M, HoWo, ntaps, cin_tiles, steps_total, steps_per_split, nsplit, stem;
+};
+
+template <bool STEM>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) v4f smem[];
+    v4f* Gs = smem;                 // [2][32 px][16 quads]
+    v4f* Xs = smem + 2 * 32 * 16;   // [2][32 px][16 quads]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;       // wave's 32x32 sub-tile: rows co, cols k
+
+    const int co0 = blockIdx.x * 64;
+    const int ky = blockIdx.y;                     // 64-column tile of the weight row
+    const int split = blockIdx.z;
+    const int s_begin = split * a.steps_per_split;
+    const int s_end = min(s_begin + a.steps_per_split, a.steps_total);
+
+    // loader role: thread fetches quad q of rows rowA and rowA + 4 (per tile)
+    const int q = lane & 15;
+    const int rloc = 8 * wave + (lane >> 4);       // + 4 i
+    const float* zero = w_zero16;
+
+    int tap, ci0;
+    if (STEM) {
+        tap = ky * 16 + q;                         // each quad is one tap (4 channels)
+        ci0 = 0;
+    } else {
+        tap = ky / a.cin_tiles;
+        ci0 = (ky - tap * a.cin_tiles) * 64;
+    }
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int dh = kh * a.dil - a.pad, dw = kw * a.dil - a.pad;
+    const bool tap_ok = tap < a.ntaps;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+#define PEMP_WG_DMA(step_, buf_)                                                                       \
+    do {                                                                                               \
+        v4f* Gd_ = Gs + (buf_) * 512 + wave * 128;                                                     \
+        v4f* Xd_ = Xs + (buf_) * 512 + wave * 128;                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+            const int m = (step_) * 32 + rloc + 4 * i;                                                 \
+            const bool mok = m < a.M;                                                                  \
+            const float* gs = mok ? a.g + (size_t)m * a.ldg + co0 + q * 4 : zero;                      \
+            __builtin_amdgcn_global_load_lds((gptr_t)gs, (lptr_t)(Gd_ + i * 64), 16, 0, 0);           \
+            const int mm = mok ? m : 0;                                                                \
+            const int img = mm / a.HoWo;                                                               \
+            const int rem = mm - img * a.HoWo;                                                         \
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;                                           \
+            const int hi = ho * a.stride + dh, wi = wo * a.stride + dw;                                \
+            const bool ok = mok && tap_ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
+            const float* xs = ok ? a.x + ((size_t)(img * a.H + hi) * a.W + wi) * a.ldx + ci0 + (STEM ? 0 : q * 4) \
+                                 : zero;                                                               \
+            __builtin_amdgcn_global_load_lds((gptr_t)xs, (lptr_t)(Xd_ + i * 64), 16, 0, 0);           \
+        }                                                                                              \
+    } while (0)
+
+    if (s_begin < s_end) {
+        PEMP_WG_DMA(s_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    const float* Gf = (const float*)Gs;
+    const float* Xf = (const float*)Xs;
+    const int gcol = wr * 32 + lr, xcol = wc * 32 + lr;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) PEMP_WG_DMA(s + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Gb = Gf + buf * 2048 + lh * 64 + gcol;
+        const float* Xb = Xf + buf * 2048 + lh * 64 + xcol;
+        float ga[2], xa[2];
+        ga[0] = Gb[0];
+        xa[0] = Xb[0];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t < 15) {
+                ga[(t + 1) & 1] = Gb[(t + 1) * 128];
+                xa[(t + 1) & 1] = Xb[(t + 1) * 128];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[t & 1], xa[t & 1], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef PEMP_WG_DMA
+
+    // D[i][j]: i = co (rows), j = lane&31 = column
+    float* out = a.out + (size_t)split * a.Cout * a.Kpad;
+    const int col = ky * 64 + wc * 32 + lr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (co < a.Cout && col < a.Kpad) out[(size_t)co * a.Kpad + col] = acc[e];
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int nsplit,
+                                    int accumulate) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n / 4; i += (long long)gridDim.x * blockDim.x) {
+        float4 s = ((const float4*)ws)[i];
+        for (int k = 1; k < nsplit; ++k) {
+            const float4 v = ((const float4*)(ws + (size_t)k * n))[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (accumulate) {
+            const float4 o = ((float4*)dw)[i];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        ((float4*)dw)[i] = s;
+    }
+}
+
+}  // namespace pemp
+
+using namespace pemp;
+
+static int pick_split(int tiles, int steps) {
+    // aim for ~1536 blocks with at least 8 reduction steps each
+    int s = cdiv(1536, tiles);
+    if (s > steps / 8) s = steps / 8;
+    if (s < 1) s = 1;
+    if (s > 512) s = 512;
+    return s;
+}
+
+extern "C" size_t pemp_conv2d_wgrad_workspace_bytes(const pemp_conv_desc* d) {
+    if (!d) return 0;
+    const int M = d->N * d->Ho * d->Wo;
+    const int tiles = cdiv(d->Cout, 64) * (d->Kpad / 64 > 0 ? cdiv(d->Kpad, 64) : 1);
+    const int split = pick_split(tiles, cdiv(M, 32));
+    return (size_t)split * d->Cout * d->Kpad * sizeof(float) + 256;
+}
+
+extern "C" int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* g, float* dw,
+                                          int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    PEMP_REQUIRE(d && x && g && dw, "wgrad: null pointer");
+    const bool stem = d->flags & PEMP_CONV_STEM4;
+    const int ntaps = d->KH * d->KW;
+    PEMP_REQUIRE(d->Cout % 64 == 0, "wgrad: Cout=%d must be a multiple of 64", d->Cout);
+    PEMP_REQUIRE(d->ldy >= d->Cout && d->ldy % 4 == 0, "wgrad: ldy (gradient stride) must be >= Cout and x4");
+    PEMP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)dw & 15) == 0, "wgrad: pointers must be 16-byte aligned");
+    if (stem) {
+        PEMP_REQUIRE(d->Cin == 4 && d->ldx == 4 && d->Kpad % 64 == 0 && d->Kpad >= ntaps * 4, "wgrad: STEM4 needs NHWC4 input and Kpad %% 64 == 0");
+    } else {
+        PEMP_REQUIRE(d->Cin % 64 == 0 && d->ldx >= d->Cin && d->ldx % 4 == 0, "wgrad: Cin=%d must be a multiple of 64", d->Cin);
+        PEMP_REQUIRE(d->Kpad == ntaps * d->Cin, "wgrad: Kpad must equal KH*KW*Cin");
+    }
+    const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+    const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+    PEMP_REQUIRE(ho == d->Ho && wo == d->Wo, "wgrad: Ho/Wo do not match geometry");
+    WgradArgs a;
+    a.x = x; a.g = g;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+    a.ldg = d->ldy; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.Kpad = d->Kpad;
+    a.HoWo = d->Ho * d->Wo;
+    a.M = d->N * a.HoWo;
+    a.ntaps = ntaps;
+    a.cin_tiles = stem ? 1 : d->Cin / 64;
+    a.steps_total = cdiv(a.M, 32);
+    a.stem = stem;
+    const int tiles_k = d->Kpad / 64;
+    const int tiles = (d->Cout / 64) * tiles_k;
+    a.nsplit = pick_split(tiles, a.steps_total);
+    a.steps_per_split = cdiv(a.steps_total, a.nsplit);
+    a.nsplit = cdiv(a.steps_total, a.steps_per_split);
+    const bool direct = a.nsplit == 1 && !accumulate;
+    if (!direct) {
+        PEMP_REQUIRE(ws && ws_bytes >= (size_t)a.nsplit * d->Cout * d->Kpad * sizeof(float), "wgrad: workspace too small");
+        PEMP_REQUIRE(((uintptr_t)ws & 15) == 0, "wgrad: workspace must be 16-byte aligned");
+    }
+    a.out = direct ? dw : (float*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = 2 * 2 * 32 * 16 * sizeof(v4f);
+    dim3 grid(d->Cout / 64, tiles_k, a.nsplit);
+    if (stem) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), lds, st, a);
+    int e = launch_status("conv_wgrad");
+    if (e || direct) return e;
+    const long long n = (long long)d->Cout * d->Kpad;
+    int rg = (int)std::min<long long>((n / 4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, st, (const float*)ws, dw, n, a.nsplit, accumulate);
+    return launch_status("conv_wgrad/reduce");
+}

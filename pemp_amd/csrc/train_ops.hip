@@ -1,0 +1,481 @@
+// Training-path streaming kernels (HBM-bound): train-mode BatchNorm forward/backward with batch
+// statistics, ReLU / bias backward, max-pool backward, strided scatter for stride-2 dgrad, and the
+// fused clip-norm + SGD-momentum update on flat parameter/gradient buffers.
+//
+// All reductions are two-stage with a fixed order (per-chunk partials in double, then a serial
+// sum over chunks), so every result is deterministic and independent of launch geometry.
+#include "common.h"
+
+namespace pemp {
+
+constexpr int RCHUNK = 256;   // rows per partial in the per-channel reductions
+
+// -----------------------------------------------------------------------------------------------
+// per-channel sums over rows:  out[chunk][0][c] = sum_r a(r,c),  out[chunk][1][c] = sum_r b(r,c)
+//   MODE 0 (BN stats):      a = z,            b = z*z
+//   MODE 1 (BN backward):   a = g,            b = g * xhat      g = dy * (y > 0 if relu)
+//   MODE 2 (bias backward): a = g,            b unused
+// block = 16 float4-lanes (64 channels) x 16 row-lanes.
+template <int MODE>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p0, int ld0,
+                                                     const float* __restrict__ p1, int ld1,
+                                                     const float* __restrict__ p2, int ld2,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, double* __restrict__ part,
+                                                     int M, int C, int relu) {
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cl * 4;
+    const int r0 = blockIdx.x * RCHUNK;
+    const int r1 = min(r0 + RCHUNK, M);
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        float mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
+        if (MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mu[e] = mean[c + e];
+                is[e] = invstd[c + e];
+            }
+        }
+        for (int r = r0 + rl; r < r1; r += 16) {
+            float4 a = *(const float4*)(p0 + (size_t)r * ld0 + c);
+            float av[4] = {a.x, a.y, a.z, a.w};
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sa[e] += av[e];
+                    sb[e] += av[e] * av[e];
+                }
+            } else {
+                if (relu) {
+                    float4 y = *(const float4*)(p1 + (size_t)r * ld1 + c);
+                    float yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = yv[e] > 0.f ? av[e] : 0.f;
+                }
+                if (MODE == 1) {
+                    float4 z = *(const float4*)(p2 + (size_t)r * ld2 + c);
+                    float zv[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sa[e] += av[e];
+                        sb[e] += av[e] * ((zv[e] - mu[e]) * is[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sa[e] += av[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][rl][cl * 4 + e] = (double)sa[e];
+        red[1][rl][cl * 4 + e] = (double)sb[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int k = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[k][i][ch];
+        if (blockIdx.y * 64 + ch < C) part[((size_t)blockIdx.x * 2 + k) * C + blockIdx.y * 64 + ch] = s;
+    }
+}
+
+// stage 2 of BN statistics: mean, invstd, running-stat update (momentum form of nn.BatchNorm2d)
+__global__ void bn_stats_final_kernel(const double* __restrict__ part, int nchunk, int M, int C, float eps,
+                                      float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                      float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s += part[((size_t)k * 2 + 0) * C + c];
+        ss += part[((size_t)k * 2 + 1) * C + c];
+    }
+    const double mu = s / M;
+    double var = ss / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unbiased);
+    }
+}
+
+// stage 2 of the backward sums: out[0][c] = sum a, out[1][c] = sum b  (fp32 results)
+__global__ void colsum_final_kernel(const double* __restrict__ part, int nchunk, int C, float* __restrict__ out0,
+                                    float* __restrict__ out1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s += part[((size_t)k * 2 + 0) * C + c];
+        ss += part[((size_t)k * 2 + 1) * C + c];
+    }
+    if (out0) out0[c] = (float)s;
+    if (out1) out1[c] = (float)ss;
+}
+
+// y = relu?( (z - mean) * invstd * gamma + beta (+ residual) )   -- ATen's alpha/beta form
+__global__ void bn_apply_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ res, int ldr,
+                                float* __restrict__ y, int ldy, long long M, int C4, int relu) {
+    const long long total = M * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long m = i / C4;
+        const float4 v = *(const float4*)(z + m * ldz + c);
+        float zv[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float alpha = invstd[c + e] * gamma[c + e];
+            const float bt = beta[c + e] - mean[c + e] * alpha;
+            o[e] = zv[e] * alpha + bt;
+        }
+        if (res) {
+            const float4 rv = *(const float4*)(res + m * ldr + c);
+            o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        *(float4*)(y + m * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dz = gamma*invstd * (g - sum_g/M - xhat * sum_gx/M), g = dy * (y>0 if relu); optionally also writes g
+// (the gradient flowing into the residual branch).
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                    const float* __restrict__ z, int ldz, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+                                    float* __restrict__ dz, int lddz, float* __restrict__ gout, int ldg, long long M,
+                                    int C4, int relu) {
+    const long long total = M * C4;
+    const float invM = 1.f / (float)M;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long m = i / C4;
+        const float4 d4 = *(const float4*)(dy + m * lddy + c);
+        float g[4] = {d4.x, d4.y, d4.z, d4.w};
+        if (relu) {
+            const float4 y4 = *(const float4*)(y + m * ldy + c);
+            const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+        }
+        const float4 z4 = *(const float4*)(z + m * ldz + c);
+        const float zv[4] = {z4.x, z4.y, z4.z, z4.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float is = invstd[c + e];
+            const float xh = (zv[e] - mean[c + e]) * is;
+            o[e] = (g[e] - sum_g[c + e] * invM - xh * (sum_gx[c + e] * invM)) * (is * gamma[c + e]);
+        }
+        *(float4*)(dz + m * lddz + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (gout) *(float4*)(gout + m * ldg + c) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
+// g = dy * (y > 0) (+ add)   -- ReLU backward, optionally accumulating a second gradient stream
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                const float* __restrict__ add, int lda, float* __restrict__ g, int ldg, long long M,
+                                int C4, int relu) {
+    const long long total = M * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long m = i / C4;
+        float4 d = *(const float4*)(dy + m * lddy + c);
+        if (add) {
+            const float4 a = *(const float4*)(add + m * lda + c);
+            d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+        }
+        if (relu) {
+            const float4 yv = *(const float4*)(y + m * ldy + c);
+            d.x = yv.x > 0.f ? d.x : 0.f;
+            d.y = yv.y > 0.f ? d.y : 0.f;
+            d.z = yv.z > 0.f ? d.z : 0.f;
+            d.w = yv.w > 0.f ? d.w : 0.f;
+        }
+        *(float4*)(g + m * ldg + c) = d;
+    }
+}
+
+// max-pool backward as a gather: dx[p] = sum over the output windows that contain p and whose
+// (first, scan-order) maximum is p.
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                   int N, int H, int W, int C4, int Ho, int Wo, int k, int s, int p) {
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        long long t = i / C4;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const int C = C4 * 4;
+        const float4 xv4 = *(const float4*)(x + (((long long)n * H + h) * W + w) * C + c);
+        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // output windows (ho, wo) with ho*s - p <= h < ho*s - p + k
+        const int ho_lo = max(0, (h + p - k + s) / s), ho_hi = min(Ho - 1, (h + p) / s);
+        const int wo_lo = max(0, (w + p - k + s) / s), wo_hi = min(Wo - 1, (w + p) / s);
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const int h0 = max(ho * s - p, 0), h1 = min(ho * s - p + k, H);
+                const int w0 = max(wo * s - p, 0), w1 = min(wo * s - p + k, W);
+                const float4 g4 = *(const float4*)(dy + (((long long)n * Ho + ho) * Wo + wo) * C + c);
+                const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // is (h,w) the first maximum of this window for channel c+e ?
+                    bool win = true;
+                    for (int hh = h0; hh < h1 && win; ++hh)
+                        for (int ww = w0; ww < w1; ++ww) {
+                            const float v = x[(((long long)n * H + hh) * W + ww) * C + c + e];
+                            const bool before = hh < h || (hh == h && ww < w);
+                            if (v > xv[e] || (before && v == xv[e])) {
+                                win = false;
+                                break;
+                            }
+                        }
+                    if (win) acc[e] += gv[e];
+                }
+            }
+        *(float4*)(dx + (((long long)n * H + h) * W + w) * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// dst[n, hs*s, ws*s, :] = src[n, hs, ws, :], zero elsewhere (dgrad of a stride-s 1x1 convolution)
+__global__ void scatter_strided_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W,
+                                       int Hs, int Ws, int C4, int s) {
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h % s == 0 && w % s == 0 && h / s < Hs && w / s < Ws)
+            v = ((const float4*)src)[(((long long)n * Hs + h / s) * Ws + w / s) * C4 + c4];
+        ((float4*)dst)[i] = v;
+    }
+}
+
+// y[n][i][c] = v[n][c] / HW  (backward of the global average pool) added into dst
+__global__ void gap_bwd_add_kernel(const float* __restrict__ v, float* __restrict__ dst, int ld, int HW, int C4,
+                                   long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long m = i / C4;
+        const long long n = m / HW;
+        const float4 g = ((const float4*)v)[n * C4 + c4];
+        float4* d = (float4*)(dst + m * ld + c4 * 4);
+        float4 o = *d;
+        const float inv = 1.f / (float)HW;
+        o.x += g.x * inv; o.y += g.y * inv; o.z += g.z * inv; o.w += g.w * inv;
+        *d = o;
+    }
+}
+
+// ---- optimizer ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restrict__ g, long long n,
+                                                            double* __restrict__ part) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long b0 = blockIdx.x * per, b1 = min(b0 + per, n);
+    float acc = 0.f;
+    int cnt = 0;
+    for (long long i = b0 + threadIdx.x; i < b1; i += 256) {
+        const float v = g[i];
+        acc += v * v;
+        if (++cnt == 64) {
+            s += (double)acc;
+            acc = 0.f;
+            cnt = 0;
+        }
+    }
+    s += (double)acc;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sqsum_final_kernel(const double* __restrict__ part, int nb, float* __restrict__ norm_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nb; ++i) s += part[i];
+        norm_out[0] = (float)sqrt(s);
+    }
+}
+// torch.nn.utils.clip_grad_norm_ + torch.optim.SGD (momentum, weight decay, no nesterov) in one pass
+__global__ void sgd_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                long long n, const float* __restrict__ norm, float max_norm, float lr, float mom,
+                                float wd, int first_step, float grad_scale) {
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (norm[0] * grad_scale + 1e-6f), 1.f);
+    coef *= grad_scale;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float w = p[i];
+        float d = g[i] * coef + wd * w;
+        const float b = first_step ? d : mom * buf[i] + d;
+        buf[i] = b;
+        p[i] = w - lr * b;
+    }
+}
+
+static int grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace pemp
+
+using namespace pemp;
+
+static inline int nchunks_rows(int M) { return cdiv(M, RCHUNK); }
+
+extern "C" size_t pemp_colsum_workspace_bytes(int M, int C) {
+    return (size_t)nchunks_rows(M) * 2 * C * sizeof(double);
+}
+
+#define CHK_VEC(ptr, ld, C, what)                                                                         \
+    PEMP_REQUIRE((ptr) && (C) % 4 == 0 && (ld) % 4 == 0 && (ld) >= (C) && (((uintptr_t)(ptr)) & 15) == 0, \
+                 what ": pointer must be 16-byte aligned and C/ld multiples of 4")
+
+extern "C" int pemp_bn_stats_f32(const float* z, int ldz, int M, int C, float eps, float momentum, float* mean,
+                                 float* invstd, float* run_mean, float* run_var, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    CHK_VEC(z, ldz, C, "bn_stats");
+    PEMP_REQUIRE(M > 0 && mean && invstd && ws && ws_bytes >= pemp_colsum_workspace_bytes(M, C), "bn_stats: bad arguments");
+    PEMP_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "bn_stats: running stats must both be given or both NULL");
+    const int nck = nchunks_rows(M);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_kernel<0>, dim3(nck, cdiv(C, 64)), dim3(256), 0, st, z, ldz, (const float*)nullptr, 0,
+                       (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (double*)ws, M, C, 0);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const double*)ws, nck, M, C, eps,
+                       momentum, mean, invstd, run_mean, run_var);
+    return launch_status("bn_stats");
+}
+
+extern "C" int pemp_bn_apply_f32(const float* z, int ldz, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, const float* residual, int ldr, float* y, int ldy, int M, int C,
+                                 int relu, void* stream) {
+    CHK_VEC(z, ldz, C, "bn_apply");
+    CHK_VEC(y, ldy, C, "bn_apply");
+    PEMP_REQUIRE(M > 0 && mean && invstd && gamma && beta, "bn_apply: null pointer");
+    if (residual) CHK_VEC(residual, ldr, C, "bn_apply");
+    const long long total = (long long)M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz, mean,
+                       invstd, gamma, beta, residual, ldr, y, ldy, (long long)M, C / 4, relu);
+    return launch_status("bn_apply");
+}
+
+extern "C" int pemp_bn_bwd_f32(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,
+                               const float* mean, const float* invstd, const float* gamma, float* dz, int lddz,
+                               float* gout, int ldg, float* dgamma, float* dbeta, int M, int C, int relu, void* ws,
+                               size_t ws_bytes, void* stream) {
+    CHK_VEC(dy, lddy, C, "bn_bwd");
+    CHK_VEC(z, ldz, C, "bn_bwd");
+    CHK_VEC(dz, lddz, C, "bn_bwd");
+    if (relu) CHK_VEC(y, ldy, C, "bn_bwd");
+    if (gout) CHK_VEC(gout, ldg, C, "bn_bwd");
+    PEMP_REQUIRE(M > 0 && mean && invstd && gamma && dgamma && dbeta && ws, "bn_bwd: null pointer");
+    PEMP_REQUIRE(ws_bytes >= pemp_colsum_workspace_bytes(M, C), "bn_bwd: workspace too small");
+    const int nck = nchunks_rows(M);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_kernel<1>, dim3(nck, cdiv(C, 64)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean, invstd,
+                       (double*)ws, M, C, relu);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const double*)ws, nck, C, dbeta, dgamma);
+    const long long total = (long long)M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean,
+                       invstd, gamma, dbeta, dgamma, dz, lddz, gout, ldg, (long long)M, C / 4, relu);
+    return launch_status("bn_bwd");
+}
+
+extern "C" int pemp_relu_bias_bwd_f32(const float* dy, int lddy, const float* y, int ldy, const float* add, int lda,
+                                      float* g, int ldg, float* dbias, int M, int C, int relu, void* ws,
+                                      size_t ws_bytes, void* stream) {
+    CHK_VEC(dy, lddy, C, "relu_bias_bwd");
+    CHK_VEC(g, ldg, C, "relu_bias_bwd");
+    if (relu) CHK_VEC(y, ldy, C, "relu_bias_bwd");
+    if (add) CHK_VEC(add, lda, C, "relu_bias_bwd");
+    PEMP_REQUIRE(M > 0, "relu_bias_bwd: M <= 0");
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)M * (C / 4);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, lddy, y, ldy, add, lda, g, ldg,
+                       (long long)M, C / 4, relu);
+    if (dbias) {
+        PEMP_REQUIRE(ws && ws_bytes >= pemp_colsum_workspace_bytes(M, C), "relu_bias_bwd: workspace too small");
+        const int nck = nchunks_rows(M);
+        hipLaunchKernelGGL(colsum_kernel<2>, dim3(nck, cdiv(C, 64)), dim3(256), 0, st, (const float*)g, ldg,
+                           (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)nullptr,
+                           (const float*)nullptr, (double*)ws, M, C, 0);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const double*)ws, nck, C, dbias,
+                           (float*)nullptr);
+    }
+    return launch_status("relu_bias_bwd");
+}
+
+extern "C" int pemp_maxpool2d_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
+                                           int Ho, int Wo, int k, int s, int p, void* stream) {
+    PEMP_REQUIRE(x && dy && dx && N > 0 && C % 4 == 0, "maxpool_bwd: bad arguments");
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H,
+                       W, C / 4, Ho, Wo, k, s, p);
+    return launch_status("maxpool_bwd");
+}
+
+extern "C" int pemp_scatter_strided_nhwc_f32(const float* src, float* dst, int N, int H, int W, int Hs, int Ws, int C,
+                                             int s, void* stream) {
+    PEMP_REQUIRE(src && dst && N > 0 && C % 4 == 0 && s >= 1, "scatter_strided: bad arguments");
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(scatter_strided_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, N,
+                       H, W, Hs, Ws, C / 4, s);
+    return launch_status("scatter_strided");
+}
+
+extern "C" int pemp_gap_bwd_add_nhwc_f32(const float* v, float* dst, int ld, int N, int HW, int C, void* stream) {
+    PEMP_REQUIRE(v && dst && N > 0 && HW > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C, "gap_bwd: bad arguments");
+    const long long total = (long long)N * HW * (C / 4);
+    hipLaunchKernelGGL(gap_bwd_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, v, dst, ld, HW,
+                       C / 4, total);
+    return launch_status("gap_bwd");
+}
+
+extern "C" size_t pemp_sgd_workspace_bytes(void) { return 1024 * sizeof(double) + 16; }
+
+// grad_norm_out[0] = ||g||_2 ; then p/buf updated.  max_norm <= 0 disables clipping.  grad_scale
+// multiplies every gradient first (1/world after a SUM all-reduce).
+extern "C" int pemp_sgd_clip_step_f32(float* params, const float* grads, float* momentum_buf, long long n,
+                                      float max_norm, float lr, float momentum, float weight_decay, int first_step,
+                                      float grad_scale, float* grad_norm_out, void* ws, size_t ws_bytes, void* stream) {
+    PEMP_REQUIRE(params && grads && momentum_buf && grad_norm_out && ws && n > 0, "sgd_clip_step: bad arguments");
+    PEMP_REQUIRE(ws_bytes >= pemp_sgd_workspace_bytes(), "sgd_clip_step: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = 1024;
+    hipLaunchKernelGGL(sqsum_partial_kernel, dim3(nb), dim3(256), 0, st, grads, n, (double*)ws);
+    hipLaunchKernelGGL(sqsum_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, grad_norm_out);
+    hipLaunchKernelGGL(sgd_clip_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, params, grads, momentum_buf, n,
+                       (const float*)grad_norm_out, max_norm, lr, momentum, weight_decay, first_step, grad_scale);
+    return launch_status("sgd_clip_step");
+}

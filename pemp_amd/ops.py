@@ -31,8 +31,16 @@ def _nhwc(t, name):
     if t.dim() != 4 or t.dtype != torch.float32 or t.stride(3) != 1:
         raise ValueError(f"{name}: expected fp32 NHWC view with unit channel stride, got {tuple(t.shape)} {t.dtype} {t.stride()}")
     n, h, w, c = t.shape
-    ld = t.stride(2)
-    if (w > 1 and t.stride(1) != w * ld) or (h > 1 and n > 1 and t.stride(0) != h * w * ld):
+    # strides of size-1 dims are arbitrary in torch: take the pixel stride from the first dim that moves
+    if w > 1:
+        ld = t.stride(2)
+    elif h > 1:
+        ld = t.stride(1)
+    elif n > 1:
+        ld = t.stride(0)
+    else:
+        ld = c
+    if (w > 1 and h > 1 and t.stride(1) != w * ld) or (h * w > 1 and n > 1 and t.stride(0) != h * w * ld):
         raise ValueError(f"{name}: pixels must be densely packed with stride ld={ld}, got strides {t.stride()}")
     return ld
 

@@ -1,0 +1,165 @@
+"""Tensor-level wrappers over the training entry points of the C ABI (include/pemp_hip.h, "Training path").
+
+Activations/gradients are NHWC fp32 views as in ``pemp_amd.ops``; 2-D ``[M, C]`` tensors are accepted
+wherever the kernel only needs rows x channels.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .ops import ConvDesc, CONV_STEM4, _p, _stream, _chk_dev, _ws, conv_out_size
+
+
+def _rows(t, name):
+    """-> (M, C, ld) of an NHWC view or a [M, C] matrix with unit channel stride."""
+    if t.dtype != torch.float32 or t.stride(-1) != 1:
+        raise ValueError(f"{name}: expected fp32 with unit channel stride")
+    if t.dim() == 2:
+        return t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+    if t.dim() == 4:
+        from .ops import _nhwc
+        n, h, w, c = t.shape
+        return n * h * w, c, _nhwc(t, name)
+    raise ValueError(f"{name}: expected 2-D or NHWC 4-D tensor")
+
+
+def bn_stats(z, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, ws_cache=None):
+    """Batch mean and 1/sqrt(var+eps) per channel; updates running stats in place when given."""
+    lib = _lib.load()
+    _chk_dev(z, run_mean, run_var)
+    m, c, ld = _rows(z, "z")
+    mean = torch.empty(c, dtype=torch.float32, device=z.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=z.device)
+    ws = _ws(lib.pemp_colsum_workspace_bytes(m, c), z.device, ws_cache, ("colsum", m, c))
+    _lib.check(lib.pemp_bn_stats_f32(_p(z), ld, m, c, eps, momentum, _p(mean), _p(invstd), _p(run_mean), _p(run_var),
+                                     _p(ws), ws.numel(), _stream()), "bn_stats")
+    return mean, invstd
+
+
+def bn_apply(z, mean, invstd, gamma, beta, out, residual=None, relu=True):
+    lib = _lib.load()
+    _chk_dev(z, out, residual)
+    m, c, ldz = _rows(z, "z")
+    _, _, ldy = _rows(out, "out")
+    ldr = _rows(residual, "residual")[2] if residual is not None else 0
+    _lib.check(lib.pemp_bn_apply_f32(_p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), ldr,
+                                     _p(out), ldy, m, c, 1 if relu else 0, _stream()), "bn_apply")
+    return out
+
+
+def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=None):
+    """-> (dgamma, dbeta); writes dz (and gout = dy*(y>0), the gradient of the residual branch)."""
+    lib = _lib.load()
+    _chk_dev(dy, y, z, dz, gout)
+    m, c, lddy = _rows(dy, "dy")
+    ldy = _rows(y, "y")[2] if y is not None else 0
+    ldz = _rows(z, "z")[2]
+    lddz = _rows(dz, "dz")[2]
+    ldg = _rows(gout, "gout")[2] if gout is not None else 0
+    dgamma = torch.empty(c, dtype=torch.float32, device=dy.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
+    ws = _ws(lib.pemp_colsum_workspace_bytes(m, c), dy.device, ws_cache, ("colsum", m, c))
+    _lib.check(lib.pemp_bn_bwd_f32(_p(dy), lddy, _p(y), ldy, _p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(dz), lddz,
+                                   _p(gout), ldg, _p(dgamma), _p(dbeta), m, c, 1 if relu else 0, _p(ws), ws.numel(),
+                                   _stream()), "bn_bwd")
+    return dgamma, dbeta
+
+
+def relu_bias_bwd(dy, y, g, add=None, relu=True, want_dbias=True, ws_cache=None):
+    """g = (dy (+ add)) * (y > 0 if relu); returns dbias = column sums of g (or None)."""
+    lib = _lib.load()
+    _chk_dev(dy, y, g, add)
+    m, c, lddy = _rows(dy, "dy")
+    ldy = _rows(y, "y")[2] if y is not None else 0
+    lda = _rows(add, "add")[2] if add is not None else 0
+    ldg = _rows(g, "g")[2]
+    dbias = torch.empty(c, dtype=torch.float32, device=dy.device) if want_dbias else None
+    ws = _ws(lib.pemp_colsum_workspace_bytes(m, c), dy.device, ws_cache, ("colsum", m, c)) if want_dbias else None
+    _lib.check(lib.pemp_relu_bias_bwd_f32(_p(dy), lddy, _p(y), ldy, _p(add), lda, _p(g), ldg, _p(dbias), m, c,
+                                          1 if relu else 0, _p(ws), ws.numel() if ws is not None else 0, _stream()),
+               "relu_bias_bwd")
+    return dbias
+
+
+def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None):
+    """dw (KRSC [Cout, Kpad_w]) (+)= wgrad of the conv described by ConvParams ``p`` (geometry only).
+    For the stem ``dw`` has row length ceil(KH*KW*4 / 64) * 64."""
+    lib = _lib.load()
+    _chk_dev(x, g, dw)
+    from .ops import _nhwc
+    n, h, w, cin = x.shape
+    ldx = _nhwc(x, "x")
+    ho = conv_out_size(h, p.kh, p.stride, p.pad, p.dil)
+    wo = conv_out_size(w, p.kw, p.stride, p.pad, p.dil)
+    m, cout, ldg = _rows(g, "g")
+    if m != n * ho * wo or cout != p.cout:
+        raise ValueError(f"conv_wgrad: gradient has shape ({m},{cout}), expected ({n * ho * wo},{p.cout})")
+    kpad = dw.shape[1]
+    if dw.shape[0] != cout or not dw.is_contiguous():
+        raise ValueError("conv_wgrad: dw must be contiguous [Cout, Kpad]")
+    d = ConvDesc(n, h, w, cin, ldx, ho, wo, cout, ldg, p.kh, p.kw, p.stride, p.pad, p.dil, 0, kpad,
+                 CONV_STEM4 if p.stem else 0, 0)
+    nbytes = lib.pemp_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = _ws(nbytes, x.device, ws_cache, ("wgrad", nbytes))
+    _lib.check(lib.pemp_conv2d_wgrad_nhwc_f32(C.byref(d), _p(x), _p(g), _p(dw), 1 if accumulate else 0, _p(ws),
+                                              ws.numel(), _stream()), "conv_wgrad")
+    return dw
+
+
+def dgrad_weight(w_krsc, kh, kw):
+    """KRSC forward weight [Cout, KH*KW*Cin] -> the KRSC weight of the input-gradient conv
+    [Cin, KH*KW*Cout] (taps flipped, channels transposed)."""
+    cout = w_krsc.shape[0]
+    cin = w_krsc.shape[1] // (kh * kw)
+    w = w_krsc.view(cout, kh, kw, cin)
+    return w.flip(1, 2).permute(3, 1, 2, 0).contiguous().view(cin, kh * kw * cout)
+
+
+def maxpool_bwd(x, dy, k, s, p):
+    lib = _lib.load()
+    _chk_dev(x, dy)
+    n, h, w, c = x.shape
+    _, ho, wo, _ = dy.shape
+    if not (x.is_contiguous() and dy.is_contiguous()):
+        raise ValueError("maxpool_bwd: contiguous NHWC tensors required")
+    dx = torch.empty_like(x)
+    _lib.check(lib.pemp_maxpool2d_bwd_nhwc_f32(_p(x), _p(dy), _p(dx), n, h, w, c, ho, wo, k, s, p, _stream()), "maxpool_bwd")
+    return dx
+
+
+def scatter_strided(src, out_hw, s):
+    lib = _lib.load()
+    _chk_dev(src)
+    n, hs, ws_, c = src.shape
+    h, w = out_hw
+    if not src.is_contiguous():
+        raise ValueError("scatter_strided: contiguous NHWC source required")
+    dst = torch.empty((n, h, w, c), dtype=torch.float32, device=src.device)
+    _lib.check(lib.pemp_scatter_strided_nhwc_f32(_p(src), _p(dst), n, h, w, hs, ws_, c, s, _stream()), "scatter_strided")
+    return dst
+
+
+def gap_bwd_add(v, dst):
+    """dst[n,i,:] += v[n,:] / HW."""
+    lib = _lib.load()
+    _chk_dev(v, dst)
+    n, h, w, c = dst.shape
+    _lib.check(lib.pemp_gap_bwd_add_nhwc_f32(_p(v.contiguous()), _p(dst), dst.stride(2), n, h * w, c, _stream()), "gap_bwd_add")
+    return dst
+
+
+def sgd_clip_step(params, grads, buf, max_norm, lr, momentum, weight_decay, first_step, grad_scale=1.0,
+                  ws_cache=None):
+    """Flat-buffer clip_grad_norm_ + SGD step.  Returns the 1-element tensor holding ||grads||_2."""
+    lib = _lib.load()
+    _chk_dev(params, grads, buf)
+    n = params.numel()
+    if grads.numel() != n or buf.numel() != n or not (params.is_contiguous() and grads.is_contiguous() and buf.is_contiguous()):
+        raise ValueError("sgd_clip_step: flat contiguous buffers of equal length required")
+    norm = torch.empty(1, dtype=torch.float32, device=params.device)
+    ws = _ws(lib.pemp_sgd_workspace_bytes(), params.device, ws_cache, ("sgd",))
+    _lib.check(lib.pemp_sgd_clip_step_f32(_p(params), _p(grads), _p(buf), n, float(max_norm), float(lr), float(momentum),
+                                          float(weight_decay), 1 if first_step else 0, float(grad_scale), _p(norm),
+                                          _p(ws), ws.numel(), _stream()), "sgd_clip_step")
+    return norm

@@ -74,9 +74,7 @@ def _install_standins():
             super().__init__()
 
         def forward(self, x):
-            if self.training:
-                raise RuntimeError("stand-in DropBlock2D is eval-only")
-            return x
+            return x        # eval behaviour; in train mode this equals drop_prob = 0
 
     dropblock.DropBlock2D = DropBlock2D
     sys.modules["dropblock"] = dropblock
@@ -235,6 +233,41 @@ def gen_stage2(tmp, stage1_model, cases):
         print("wrote stage2", cname)
 
 
+def gen_train_step(tmp):
+    """G9: one training step's loss and gradients of the reference in train() mode (batch-stat BN;
+    DropBlock = identity, i.e. drop_rate 0), B=2 episodes, 97x97, CE loss (entry/pemp_stage1.py:57-65)."""
+    from networks import pemp_stage1 as m
+    cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
+               drop_rate=0.0, block_size=4)
+    model = _build(m, "PEMPStage1", cfg, (), tmp)
+    _load_wgen(model)
+    model.train()
+    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    sup, msk, qry = _t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"])
+    gt = _t(b["qry_mask"][:, 0])
+    logits = model(sup, msk, qry, (97, 97))
+    loss = torch.nn.functional.cross_entropy(logits, gt, ignore_index=255)
+    loss.backward()
+    res = {"loss": np.array(float(loss), np.float64), "logits_s7": logits.detach()[:, :, ::7, ::7].numpy()}
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+    res["grad_names"] = np.array(names)
+    res["grad_norms"] = np.array(norms, np.float64)
+    for k in ("ctr", "encoder.backbone.conv1.weight", "encoder.purifier.6.layer6.bias",
+              "encoder.backbone.layer3.5.bn3.weight", "encoder.backbone.layer1.0.downsample.0.weight",
+              "encoder.purifier.6.aspp_3.2.weight", "encoder.backbone.layer2.0.conv1.weight"):
+        g = dict(model.named_parameters())[k].grad
+        res["grad__" + k] = g.numpy() if g.numel() <= 40000 else g.reshape(-1)[::37].numpy()
+    sd = model.state_dict()
+    for k in ("encoder.backbone.bn1.running_mean", "encoder.backbone.layer3.5.bn3.running_var",
+              "encoder.purifier.6.aspp_0.0.running_var", "encoder.backbone.bn1.num_batches_tracked"):
+        res["buf__" + k] = sd[k].numpy()
+    np.savez_compressed(OUT / "stage1_rn50_trainstep.npz", **res)
+    print("wrote train step; loss", float(loss))
+
+
 def gen_index_facts():
     """G8: index-map facts of the stock ops."""
     import torch.nn.functional as F
@@ -280,6 +313,8 @@ def main():
             gen_baseline(tmp, "resnet50", "baseline_rn50", {"small": small["small"]})
         if only in ("", "stage2"):
             gen_stage2(tmp, s1, {"small": ([3], 1, 97, [(80, 120)]), "small5": ([5], 5, 97, [(64, 90)])})
+        if only in ("", "train"):
+            gen_train_step(tmp)
         if only in ("", "facts"):
             gen_index_facts()
 

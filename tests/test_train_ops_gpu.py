@@ -1,0 +1,169 @@
+"""Parity of the training entry points of the C ABI against torch autograd on the CPU.
+
+Tolerances: contractions over K (dgrad) or M (wgrad) terms are compared with
+|d| <= 3e-5 * sqrt(terms/64) * (1 + |ref|); streaming kernels 1e-5 relative."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def _close(got, ref, tol):
+    return ((got - ref).abs() / (1 + ref.abs())).max().item() < tol
+
+
+WG_CASES = [  # N, H, W, Cin, Cout, k, s, p, d
+    (2, 13, 13, 64, 64, 1, 1, 0, 1),
+    (2, 25, 25, 256, 128, 1, 2, 0, 1),
+    (2, 13, 13, 128, 128, 3, 1, 2, 2),
+    (1, 21, 17, 64, 256, 3, 1, 6, 6),
+    (3, 9, 11, 128, 64, 3, 1, 1, 1),
+    (8, 1, 1, 256, 256, 1, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_wgrad_and_dgrad(hip_lib, dev, case):
+    from pemp_amd import ops, train_ops as T
+    N, H, W, Cin, Cout, k, s, p, d = case
+    x = _rand(N, Cin, H, W, seed=1).requires_grad_()
+    w = (_rand(Cout, Cin, k, k, seed=2) * (1.0 / (Cin * k * k) ** 0.5)).requires_grad_()
+    y = F.conv2d(x, w, None, s, p, d)
+    g = _rand(*y.shape, seed=3)
+    y.backward(g)
+    prm = ops.ConvParams(None, None, None, Cin, Cout, k, k, s, p, d, k * k * Cin, False, False)
+    dw = torch.full((Cout, k * k * Cin), 7.0, device=dev)
+    T.conv_wgrad(_nhwc(x.detach()).to(dev), _nhwc(g).to(dev), prm, dw)
+    got = dw.cpu().view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    terms = N * y.shape[2] * y.shape[3]
+    assert _close(got, w.grad, 3e-5 * max(1.0, (terms / 64) ** 0.5)), (got - w.grad).abs().max()
+    # accumulate=True adds on top
+    T.conv_wgrad(_nhwc(x.detach()).to(dev), _nhwc(g).to(dev), prm, dw, accumulate=True)
+    assert _close(dw.cpu().view(Cout, k, k, Cin).permute(0, 3, 1, 2), 2 * w.grad, 6e-5 * max(1.0, (terms / 64) ** 0.5))
+    # dgrad through the forward kernel with the flipped/transposed weight (stride 1) or + scatter (stride 2)
+    wk, _ = ops.pack_conv_weight(w.detach().to(dev))
+    wd = T.dgrad_weight(wk, k, k)
+    pd = ops.ConvParams(wd, None, None, Cout, Cin, k, k, 1, d * (k - 1) - p, d, k * k * Cout, False, False)
+    gd = _nhwc(g).to(dev)
+    if s == 1:
+        dx = ops.conv2d(gd, pd)
+    else:
+        dx = T.scatter_strided(ops.conv2d(gd, pd), (H, W), s)
+    assert _close(_nchw(dx.cpu()), x.grad, 3e-5 * max(1.0, (Cout * k * k / 64) ** 0.5))
+
+
+def test_conv_wgrad_stem(hip_lib, dev):
+    from pemp_amd import ops, train_ops as T
+    N, H, Cout, k = 2, 37, 64, 7
+    x = _rand(N, 3, H, H, seed=1)
+    w = (_rand(Cout, 3, k, k, seed=2) * 0.1).requires_grad_()
+    y = F.conv2d(x, w, None, 2, 3)
+    g = _rand(*y.shape, seed=3)
+    y.backward(g)
+    x4 = torch.zeros(N, H, H, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    prm = ops.ConvParams(None, None, None, 4, Cout, k, k, 2, 3, 1, 256, True, False)
+    dw = torch.empty((Cout, 256), device=dev)
+    T.conv_wgrad(x4.to(dev), _nhwc(g).to(dev), prm, dw)
+    got = dw.cpu()[:, :196].view(Cout, k, k, 4)[..., :3].permute(0, 3, 1, 2)
+    assert _close(got, w.grad, 2e-4)
+    assert dw.cpu()[:, 196:].abs().max() == 0 and dw.cpu()[:, :196].view(Cout, 49, 4)[..., 3].abs().max() == 0
+
+
+@pytest.mark.parametrize("M,C,relu,res", [(700, 64, True, False), (2601, 256, True, True), (300, 128, False, False), (5, 256, False, False)])
+def test_bn_train_forward_backward(hip_lib, dev, M, C, relu, res):
+    from pemp_amd import train_ops as T
+    z = (_rand(M, C, seed=1) * 3 + 0.5).requires_grad_()
+    gamma = _rand(C, seed=2, lo=0.5, hi=1.5).requires_grad_()
+    beta = _rand(C, seed=3).requires_grad_()
+    r = _rand(M, C, seed=4).requires_grad_() if res else None
+    rm, rv = _rand(C, seed=5), _rand(C, seed=6, lo=0.5, hi=1.5)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    zz = z.t().reshape(1, C, M, 1)
+    y = F.batch_norm(zz, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5).reshape(C, M).t()
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    dy = _rand(M, C, seed=7)
+    y.backward(dy)
+    zd = z.detach().to(dev)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    mean, invstd = T.bn_stats(zd, 1e-5, 0.1, rmd, rvd)
+    assert torch.allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rvd.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
+    out = torch.empty(M, C, device=dev)
+    T.bn_apply(zd, mean, invstd, gamma.detach().to(dev), beta.detach().to(dev), out, residual=r.detach().to(dev) if res else None, relu=relu)
+    assert torch.allclose(out.cpu(), y.detach(), rtol=1e-5, atol=2e-5)
+    dz = torch.empty(M, C, device=dev)
+    gout = torch.empty(M, C, device=dev) if res else None
+    dgamma, dbeta = T.bn_bwd(dy.to(dev), out, zd, mean, invstd, gamma.detach().to(dev), dz, gout=gout, relu=relu)
+    assert torch.allclose(dz.cpu(), z.grad, rtol=1e-4, atol=2e-5), (dz.cpu() - z.grad).abs().max()
+    assert torch.allclose(dgamma.cpu(), gamma.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(dbeta.cpu(), beta.grad, rtol=1e-4, atol=1e-4)
+    if res:
+        assert torch.allclose(gout.cpu(), r.grad, rtol=1e-6, atol=1e-7)
+
+
+def test_relu_bias_bwd_and_pools(hip_lib, dev):
+    from pemp_amd import ops, train_ops as T
+    M, C = 1000, 256
+    pre = _rand(M, C, seed=1).requires_grad_()
+    b = _rand(C, seed=2).requires_grad_()
+    y = F.relu(pre + b)
+    dy, add = _rand(M, C, seed=3), _rand(M, C, seed=4)
+    y.backward(dy + add)
+    g = torch.empty(M, C, device=dev)
+    db = T.relu_bias_bwd(dy.to(dev), y.detach().to(dev), g, add=add.to(dev))
+    assert torch.allclose(g.cpu(), pre.grad, rtol=1e-6, atol=1e-7) and torch.allclose(db.cpu(), b.grad, rtol=1e-4, atol=1e-4)
+    # max pool backward (ceil mode, overlapping windows, ties)
+    x = (_rand(2, 8, 49, 49, seed=5) * 4).round().requires_grad_()      # many exact ties
+    yp = F.max_pool2d(x, 3, 2, 1, ceil_mode=True)
+    gp = _rand(*yp.shape, seed=6)
+    yp.backward(gp)
+    dx = T.maxpool_bwd(_nhwc(x.detach()).to(dev), _nhwc(gp).to(dev), 3, 2, 1)
+    assert torch.allclose(_nchw(dx.cpu()), x.grad, rtol=1e-6, atol=1e-6)
+    # global average pool backward
+    xg = _rand(3, 64, 5, 7, seed=7).requires_grad_()
+    v = _rand(3, 64, seed=8)
+    F.adaptive_avg_pool2d(xg, (1, 1)).flatten(1).backward(v)
+    dst = torch.zeros(3, 5, 7, 64, device=dev)
+    T.gap_bwd_add(v.to(dev), dst)
+    assert torch.allclose(_nchw(dst.cpu()), xg.grad, rtol=1e-6, atol=1e-7)
+    src = _rand(2, 4, 5, 8, seed=9)
+    sc = T.scatter_strided(src.to(dev), (7, 9), 2).cpu()
+    assert torch.equal(sc[:, ::2, ::2], src) and sc.sum() == src.sum()
+
+
+def test_sgd_clip_step_matches_torch(hip_lib, dev):
+    from pemp_amd import train_ops as T
+    n = 100003
+    p0, g1, g2 = _rand(n, seed=1), _rand(n, seed=2) * 0.01, _rand(n, seed=3) * 3
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    pd, buf = p0.clone().to(dev), torch.zeros(n, device=dev)
+    for step, g in enumerate((g1, g2)):
+        ref.grad = g.clone()
+        tot = torch.nn.utils.clip_grad_norm_([ref], 1.1)
+        opt.step()
+        norm = T.sgd_clip_step(pd, g.to(dev), buf, 1.1, 1e-3, 0.9, 5e-4, first_step=(step == 0))
+        assert abs(norm.item() - tot.item()) <= 1e-5 * tot.item()
+        assert torch.allclose(pd.cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+    # grad_scale = 1/world on summed gradients equals averaging first
+    pa, pb = p0.clone().to(dev), p0.clone().to(dev)
+    T.sgd_clip_step(pa, (g2 * 4).to(dev), torch.zeros(n, device=dev), 1.1, 1e-3, 0.9, 5e-4, True, grad_scale=0.25)
+    T.sgd_clip_step(pb, g2.to(dev), torch.zeros(n, device=dev), 1.1, 1e-3, 0.9, 5e-4, True)
+    assert torch.allclose(pa.cpu(), pb.cpu(), rtol=1e-6, atol=1e-7)
