@@ -1,0 +1,442 @@
+"""Training step of PEMP stage 1 (ResNet-50) on MI355X: explicit forward/backward over the HIP
+kernels, flat parameter/gradient buffers, fused clip-norm + SGD, RCCL gradient all-reduce.
+
+Counterpart of ``Trainer.train_step`` (reference entry/pemp_stage1.py:57-65) with the model in
+``train()`` mode (core/base_trainer.py:189): BatchNorm normalises with BATCH statistics and updates
+its running statistics (momentum 0.1), DropBlock is active (networks/pemp_stage1.py:76,79;
+backbones.py:329-353), gradients are clipped to norm 1.1 and SGD(momentum 0.9, wd 5e-4) steps
+(core/solver.py:87-91).
+
+Data layout: every trainable parameter lives in ONE flat fp32 buffer (conv weights in KRSC order,
+exposed to ``state_dict`` as channels_last views of the reference's [Cout,Cin,KH,KW] shape), every
+gradient in a second flat buffer of the same layout -- that buffer is the single all-reduce bucket
+(47.8 MB for stage 1) and the operand of the fused optimizer kernel.
+
+The encoder (99.9 % of the flops) runs entirely on libpemp_hip.so: raw conv -> batch statistics ->
+normalise(+residual)(+ReLU) forward; BN backward -> MFMA wgrad -> dgrad (the forward kernel with
+flipped/transposed weights) backward.  The prototype head (MPM / cosine / upsample / CE; 0.1 % of
+the flops) is evaluated with torch ops on the GPU and differentiated by autograd in this round.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops, train_ops as T
+from .ops import ConvParams
+
+BN_MOM = 0.1
+
+
+# ---------------------------------------------------------------------------------------------
+# flat parameter storage
+# ---------------------------------------------------------------------------------------------
+class FlatParams:
+    """Re-homes the trainable parameters of ``model`` into one flat buffer (+ one for gradients)."""
+
+    def __init__(self, model, device):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.n = n
+        self.data = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        self.mom = torch.zeros(n, dtype=torch.float32, device=device)
+        self.offs = offs
+        self.first_step = True
+        for p, o in zip(self.params, offs):
+            src = p.detach().to(device)
+            if p.dim() == 4:
+                co, ci, kh, kw = p.shape
+                self.data[o:o + p.numel()].view(co, kh, kw, ci).copy_(src.permute(0, 2, 3, 1))
+                p.data = self.data[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+                p.grad = self.grad[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            else:
+                self.data[o:o + p.numel()].view(p.shape).copy_(src)
+                p.data = self.data[o:o + p.numel()].view(p.shape)
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def krsc(self, p):
+        """[Cout, KH*KW*Cin] KRSC matrix view of a conv weight (no copy)."""
+        co, ci, kh, kw = p.shape
+        return p.data.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+
+    def krsc_grad(self, p):
+        co, ci, kh, kw = p.shape
+        return p.grad.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+
+
+# ---------------------------------------------------------------------------------------------
+# layer records
+# ---------------------------------------------------------------------------------------------
+class _Conv:
+    """Geometry + parameter handles of one conv; packed views are refreshed every step."""
+
+    def __init__(self, flat, conv, stem=False):
+        self.flat, self.conv, self.stem = flat, conv, stem
+        w = conv.weight
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        self.stride, self.pad, self.dil = conv.stride[0], conv.padding[0], conv.dilation[0]
+        self.trainable = w.requires_grad
+
+    def fwd_params(self, relu=False, with_bias=True):
+        w = self.conv.weight
+        if self.stem:
+            packed, kpad = ops.pack_conv_weight(w.data, stem4=True)
+            cin = 4
+        else:
+            packed = self.flat.krsc(w) if self.trainable else w.data.permute(0, 2, 3, 1).reshape(self.cout, -1).contiguous()
+            kpad, cin = packed.shape[1], self.cin
+        bias = self.conv.bias.data if (with_bias and self.conv.bias is not None) else None
+        return ConvParams(packed, None, bias, cin, self.cout, self.kh, self.kw, self.stride, self.pad, self.dil, kpad,
+                          self.stem, relu)
+
+    def dgrad_params(self):
+        wd = T.dgrad_weight(self.flat.krsc(self.conv.weight), self.kh, self.kw)
+        return ConvParams(wd, None, None, self.cout, self.cin, self.kh, self.kw, 1, self.dil * (self.kh - 1) - self.pad,
+                          self.dil, wd.shape[1], False, False)
+
+    def wgrad(self, x, g, ws):
+        """Writes conv.weight.grad (and nothing else)."""
+        w = self.conv.weight
+        if self.stem:
+            dw = torch.empty((self.cout, 256), dtype=torch.float32, device=x.device)
+            prm = ConvParams(None, None, None, 4, self.cout, self.kh, self.kw, self.stride, self.pad, self.dil, 256, True, False)
+            T.conv_wgrad(x, g, prm, dw, ws_cache=ws)
+            k = self.kh * self.kw
+            w.grad.copy_(dw[:, :k * 4].view(self.cout, self.kh, self.kw, 4)[..., :self.cin].permute(0, 3, 1, 2))
+            return
+        prm = ConvParams(None, None, None, self.cin, self.cout, self.kh, self.kw, self.stride, self.pad, self.dil,
+                         self.kh * self.kw * self.cin, False, False)
+        T.conv_wgrad(x, g, prm, self.flat.krsc_grad(w), ws_cache=ws)
+
+
+class _BN:
+    def __init__(self, bn):
+        self.bn = bn
+
+    def stats(self, z, ws):
+        self.bn.num_batches_tracked += 1
+        return T.bn_stats(z, self.bn.eps, BN_MOM, self.bn.running_mean, self.bn.running_var, ws_cache=ws)
+
+    def write_grads(self, dgamma, dbeta):
+        if self.bn.weight.requires_grad:
+            self.bn.weight.grad.copy_(dgamma)
+            self.bn.bias.grad.copy_(dbeta)
+
+
+# ---------------------------------------------------------------------------------------------
+# DropBlock (dropblock==0.3.0 semantics; train only).  The random seed map comes from torch's device
+# RNG; its stream cannot match the reference's (third-party source absent) -- parity unpinned.
+# ---------------------------------------------------------------------------------------------
+def dropblock_rowscale(n, h, w, drop_prob, block_size, device, generator=None):
+    """-> per-pixel multiplier [n*h*w] = block_mask * numel / sum(block_mask), or None if drop_prob == 0."""
+    if drop_prob <= 0.0:
+        return None
+    gamma = drop_prob / (block_size ** 2)
+    seed = (torch.rand((n, 1, h, w), device=device, generator=generator) < gamma).float()
+    bm = F.max_pool2d(seed, kernel_size=block_size, stride=1, padding=block_size // 2)
+    if block_size % 2 == 0:
+        bm = bm[:, :, :-1, :-1]
+    bm = 1.0 - bm
+    return (bm * (bm.numel() / bm.sum())).reshape(-1).contiguous()
+
+
+class Stage1TrainEngine:
+    """Forward + backward of the stage-1 ResNet-50 encoder in train mode on HIP kernels."""
+
+    def __init__(self, model, device):
+        if model.backbone_name == "vgg16":
+            raise NotImplementedError("training engine: ResNet backbones only in this round")
+        self.model, self.device = model, device
+        self.flat = FlatParams(model, device)
+        for b in model.buffers():
+            b.data = b.data.to(device)
+        for p in model.parameters():
+            if not p.requires_grad:
+                p.data = p.data.to(device)
+        bb, pur = model.encoder.backbone, model.encoder.purifier
+        f = self.flat
+        self.stem = (_Conv(f, bb.conv1, stem=True), _BN(bb.bn1))
+        self.blocks = []
+        for name in ("layer1", "layer2", "layer3"):
+            for blk in getattr(bb, name):
+                self.blocks.append(dict(
+                    c1=_Conv(f, blk.conv1), b1=_BN(blk.bn1), c2=_Conv(f, blk.conv2), b2=_BN(blk.bn2),
+                    c3=_Conv(f, blk.conv3), b3=_BN(blk.bn3),
+                    ds=(_Conv(f, blk.downsample[0]), _BN(blk.downsample[1])) if blk.downsample is not None else None))
+        self.p0, self.p3 = _Conv(f, pur[0]), _Conv(f, pur[3])
+        aspp = pur[6]
+        self.aspp_bn = [_BN(getattr(aspp, f"aspp_{i}")[0]) for i in range(5)]
+        self.aspp_conv = [_Conv(f, getattr(aspp, f"aspp_{i}")[2]) for i in range(5)]
+        self.l6 = aspp.layer6
+        self.midc = self.aspp_conv[0].cout
+        self.ws = {}
+        self.drop_rate, self.block_size = 0.0, 4
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _cbn_fwd(self, x, conv, bn, relu, residual=None):
+        z = ops.conv2d(x, conv.fwd_params(relu=False, with_bias=False))
+        mean, invstd = bn.stats(z, self.ws)
+        y = T.bn_apply(z, mean, invstd, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(z), residual=residual, relu=relu)
+        return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu)
+
+    def _cbn_bwd(self, dy, rec, conv, bn, want_gout=False, need_dx=True, add_to=None):
+        """-> (dx [compact for stride-2], gout).  ``add_to`` is added to dx inside the dgrad epilogue."""
+        dz = torch.empty_like(rec["z"])
+        gout = torch.empty_like(rec["z"]) if want_gout else None
+        dgamma, dbeta = T.bn_bwd(dy, rec["y"], rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, dz, gout=gout,
+                                 relu=rec["relu"], ws_cache=self.ws)
+        bn.write_grads(dgamma, dbeta)
+        conv.wgrad(rec["x"], dz, self.ws)
+        dx = ops.conv2d(dz, conv.dgrad_params(), residual=add_to) if need_dx else None
+        return dx, gout
+
+    # -- forward ------------------------------------------------------------------------------
+    def forward(self, images_list):
+        """images_list: [n_i,3,H,W] tensors -> NHWC features; keeps what backward needs in self.tape."""
+        tape = {}
+        n = sum(t.shape[0] for t in images_list)
+        H, W = images_list[0].shape[-2:]
+        x4 = self._new(n, H, W, 4)
+        o = 0
+        for t in images_list:
+            ops.pack_input(t.contiguous(), out=x4[o:o + t.shape[0]])
+            o += t.shape[0]
+        y, tape["stem"] = self._cbn_fwd(x4, *self.stem, relu=True)
+        x = ops.maxpool2d(y, 3, 2, 1, ceil_mode=True)
+        tape["pool_in"], tape["blocks"] = y, []
+        for b in self.blocks:
+            rec = {}
+            y1, rec["r1"] = self._cbn_fwd(x, b["c1"], b["b1"], True)
+            y2, rec["r2"] = self._cbn_fwd(y1, b["c2"], b["b2"], True)
+            if b["ds"] is not None:
+                res, rec["rd"] = self._cbn_fwd(x, b["ds"][0], b["ds"][1], False)
+            else:
+                res = x
+            out, rec["r3"] = self._cbn_fwd(y2, b["c3"], b["b3"], True, residual=res)
+            rec["x"] = x
+            tape["blocks"].append(rec)
+            x = out
+        # purifier: conv+bias+ReLU (+DropBlock) twice
+        nimg, h, w, _ = x.shape
+        ya = ops.conv2d(x, self.p0.fwd_params(relu=True))
+        da = dropblock_rowscale(nimg, h, w, self.drop_rate, self.block_size, self.device)
+        xa = ya if da is None else ya * da.view(nimg, h, w, 1)
+        yb = ops.conv2d(xa, self.p3.fwd_params(relu=True))
+        db = dropblock_rowscale(nimg, h, w, self.drop_rate, self.block_size, self.device)
+        xb = yb if db is None else yb * db.view(nimg, h, w, 1)
+        tape.update(p0_in=x, ya=ya, da=da, xa=xa, yb=yb, db=db, xb=xb)
+        # ASPPV2: five BNs share the statistics of xb (branch 0: of its global average)
+        midc = self.midc
+        gap = ops.global_avgpool(xb)
+        m0, i0 = self.aspp_bn[0].stats(gap, self.ws)
+        t0 = T.bn_apply(gap, m0, i0, self.aspp_bn[0].bn.weight.data, self.aspp_bn[0].bn.bias.data, torch.empty_like(gap), relu=False)
+        d0 = dropblock_rowscale(nimg, 1, 1, self.drop_rate, self.block_size, self.device)
+        t0d = t0 if d0 is None else t0 * d0.view(nimg, 1)
+        g0 = ops.conv2d(t0d.view(nimg, 1, 1, -1), self.aspp_conv[0].fwd_params(relu=True))
+        l6w = self.l6.weight
+        w6 = self.flat.krsc(l6w)                                   # [512, 1280]
+        w6g = ConvParams(w6[:, :midc].contiguous(), None, self.l6.bias.data, midc, l6w.shape[0], 1, 1, 1, 0, 1, midc, False, False)
+        bias6 = ops.conv2d(g0, w6g)
+        cat = self._new(nimg, h, w, 4 * midc)
+        ts, ds_ = [], []
+        mean_x = invstd_x = None
+        for i in range(1, 5):
+            bn = self.aspp_bn[i]
+            # the four BNs see the same input, hence the same batch statistics; each call also moves
+            # that BN's own running statistics
+            mean_x, invstd_x = bn.stats(xb, self.ws)
+            t = T.bn_apply(xb, mean_x, invstd_x, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(xb), relu=False)
+            d = dropblock_rowscale(nimg, h, w, self.drop_rate, self.block_size, self.device)
+            td = t if d is None else t * d.view(nimg, h, w, 1)
+            ops.conv2d(td, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
+            ts.append(td)
+            ds_.append(d)
+        w6m = ConvParams(w6[:, midc:].contiguous(), None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False)
+        feat = ops.conv2d(cat, w6m, shift_override=bias6.view(nimg, -1), per_image_shift=True)
+        tape.update(gap=gap, m0=m0, i0=i0, t0d=t0d, d0=d0, g0=g0, cat=cat, ts=ts, ds=ds_, mean_x=mean_x, invstd_x=invstd_x,
+                    w6=w6, hw=(nimg, h, w), x4=x4)
+        self.tape = tape
+        return feat
+
+    # -- backward -----------------------------------------------------------------------------
+    def backward(self, dfeat):
+        tp, midc = self.tape, self.midc
+        nimg, h, w = tp["hw"]
+        hw = h * w
+        l6w = self.l6.weight
+        w6 = tp["w6"]
+        dw6 = self.flat.krsc_grad(l6w)                              # [512, 1280] view of the gradient
+        # layer6: main 1x1 conv over the 4 concatenated branches + per-image bias from the global branch
+        dw6m = self._new(l6w.shape[0], 4 * midc)
+        T.conv_wgrad(tp["cat"], dfeat, ConvParams(None, None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False),
+                     dw6m, ws_cache=self.ws)
+        dw6[:, midc:].copy_(dw6m)
+        dcat = ops.conv2d(dfeat, ConvParams(T.dgrad_weight(w6[:, midc:].contiguous(), 1, 1), None, None, l6w.shape[0], 4 * midc,
+                                            1, 1, 1, 0, 1, l6w.shape[0], False, False))
+        s = ops.global_avgpool(dfeat) * float(hw)                   # per-image column sums [N, 512]
+        self.l6.bias.grad.copy_(s.sum(dim=0))
+        dw6g = self._new(l6w.shape[0], midc)
+        T.conv_wgrad(tp["g0"], s.view(nimg, 1, 1, -1), ConvParams(None, None, None, midc, l6w.shape[0], 1, 1, 1, 0, 1, midc, False, False),
+                     dw6g, ws_cache=self.ws)
+        dw6[:, :midc].copy_(dw6g)
+        dg0 = ops.conv2d(s.view(nimg, 1, 1, -1), ConvParams(T.dgrad_weight(w6[:, :midc].contiguous(), 1, 1), None, None, l6w.shape[0],
+                                                            midc, 1, 1, 1, 0, 1, l6w.shape[0], False, False))
+        # branches 1..4
+        dxb = None
+        for i in range(1, 5):
+            conv, bn = self.aspp_conv[i], self.aspp_bn[i]
+            u = tp["cat"][..., (i - 1) * midc:i * midc]
+            g = self._new(nimg, h, w, midc)
+            db = T.relu_bias_bwd(dcat[..., (i - 1) * midc:i * midc], u, g, relu=True, ws_cache=self.ws)
+            conv.conv.bias.grad.copy_(db)
+            conv.wgrad(tp["ts"][i - 1], g, self.ws)
+            dt = ops.conv2d(g, conv.dgrad_params())
+            if tp["ds"][i - 1] is not None:
+                dt = dt * tp["ds"][i - 1].view(nimg, h, w, 1)
+            dz = self._new(nimg, h, w, dt.shape[-1])
+            dgamma, dbeta = T.bn_bwd(dt, None, tp["xb"], tp["mean_x"], tp["invstd_x"], bn.bn.weight.data, dz, relu=False, ws_cache=self.ws)
+            bn.write_grads(dgamma, dbeta)
+            if dxb is None:
+                dxb = dz
+            else:
+                T.relu_bias_bwd(dz, None, dxb, add=dxb, relu=False, want_dbias=False)
+        # branch 0 (global)
+        conv0, bn0 = self.aspp_conv[0], self.aspp_bn[0]
+        g = self._new(nimg, 1, 1, midc)
+        db = T.relu_bias_bwd(dg0, tp["g0"], g, relu=True, ws_cache=self.ws)
+        conv0.conv.bias.grad.copy_(db)
+        conv0.wgrad(tp["t0d"].view(nimg, 1, 1, -1), g, self.ws)
+        dt0 = ops.conv2d(g, conv0.dgrad_params()).view(nimg, -1)
+        if tp["d0"] is not None:
+            dt0 = dt0 * tp["d0"].view(nimg, 1)
+        dgap = self._new(nimg, dt0.shape[1])
+        dgamma, dbeta = T.bn_bwd(dt0, None, tp["gap"], tp["m0"], tp["i0"], bn0.bn.weight.data, dgap, relu=False, ws_cache=self.ws)
+        bn0.write_grads(dgamma, dbeta)
+        T.gap_bwd_add(dgap, dxb)
+        # purifier.3 and purifier.0 (conv + bias + ReLU (+ DropBlock))
+        if tp["db"] is not None:
+            dxb = dxb * tp["db"].view(nimg, h, w, 1)
+        g = torch.empty_like(tp["yb"])
+        self.p3.conv.bias.grad.copy_(T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws))
+        self.p3.wgrad(tp["xa"], g, self.ws)
+        dxa = ops.conv2d(g, self.p3.dgrad_params())
+        if tp["da"] is not None:
+            dxa = dxa * tp["da"].view(nimg, h, w, 1)
+        g = torch.empty_like(tp["ya"])
+        self.p0.conv.bias.grad.copy_(T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws))
+        self.p0.wgrad(tp["p0_in"], g, self.ws)
+        dx = ops.conv2d(g, self.p0.dgrad_params())
+        # residual blocks, last to first
+        for b, rec in zip(reversed(self.blocks), reversed(tp["blocks"])):
+            x = rec["x"]
+            stride = b["c1"].stride
+            dy2, gout = self._cbn_bwd(dx, rec["r3"], b["c3"], b["b3"], want_gout=True)
+            dy1, _ = self._cbn_bwd(dy2, rec["r2"], b["c2"], b["b2"])
+            if b["ds"] is not None:
+                dxd, _ = self._cbn_bwd(gout, rec["rd"], b["ds"][0], b["ds"][1])
+                dxc, _ = self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=dxd)
+                dx = dxc if stride == 1 else T.scatter_strided(dxc, (x.shape[1], x.shape[2]), stride)
+            else:
+                dx, _ = self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=gout)
+        # stem: max pool, BN+ReLU, 7x7 conv (weight gradient only)
+        dy = T.maxpool_bwd(tp["pool_in"], dx, 3, 2, 1)
+        self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
+        self.tape = None
+
+
+# ---------------------------------------------------------------------------------------------
+# head on torch ops (GPU), differentiated by autograd -- reference networks/pemp_stage1.py:142-163,195-261
+# ---------------------------------------------------------------------------------------------
+def head_loss(feat_nhwc, sup_mask, qry_mask, ctr, B, S, Q, protos, dist_scalar, out_shape):
+    n, h, w, c = feat_nhwc.shape
+    f = feat_nhwc.permute(0, 3, 1, 2)
+    sup = f[:B * S].reshape(B, S, c, h * w).reshape(B * S, c, h * w)
+    qry = f[B * S:].reshape(B * Q, c, 1, h, w)
+    H, W = sup_mask.shape[-2:]
+    m = F.interpolate(sup_mask.reshape(B * S, 2, H, W), (h, w), mode="nearest")
+    fg, bg = m[:, 0].reshape(B * S, 1, h * w), m[:, 1].reshape(B * S, 1, h * w)
+    if protos > 0:
+        cc = ctr.view(1, c, protos * 2)
+        mask = torch.stack((fg, bg), dim=1)
+        D = -((sup.unsqueeze(2) - cc.unsqueeze(3)) ** 2).sum(dim=1)
+        D = (torch.softmax(D.view(-1, 2, protos, h * w), dim=2) * mask).view(-1, 1, protos * 2, h * w)
+        new = ((sup.view(-1, c, 1, h * w) * D).sum(dim=3) / (D.sum(dim=3) + 1e-6)).view(B, S, c, 2, protos)
+        new = new.transpose(3, 4).reshape(B, S, c * protos, 2).mean(dim=1)
+        fgp, bgp = new.view(B, c, protos, 2).unbind(dim=3)
+        fgd = F.cosine_similarity(qry, fgp[..., None, None], dim=1) * dist_scalar
+        bgd = F.cosine_similarity(qry, bgp[..., None, None], dim=1) * dist_scalar
+        pred = torch.stack((bgd, fgd), dim=1).max(dim=2).values
+    else:
+        fgv = (sup * fg).sum(-1) / (fg.sum(-1) + 1e-5)
+        bgv = (sup * bg).sum(-1) / (bg.sum(-1) + 1e-5)
+        fgp, bgp = fgv.view(B, S, c).mean(1), bgv.view(B, S, c).mean(1)
+        q = qry.view(-1, c, h, w)
+        pred = torch.stack((F.cosine_similarity(q, bgp[..., None, None], dim=1) * dist_scalar,
+                            F.cosine_similarity(q, fgp[..., None, None], dim=1) * dist_scalar), dim=1)
+    logits = F.interpolate(pred, out_shape, mode="bilinear", align_corners=True)
+    return F.cross_entropy(logits, qry_mask, ignore_index=255), logits
+
+
+class Stage1Trainer:
+    """``train_step`` with the reference's contract: zero_grad, forward, CE loss, backward,
+    clip_grad_norm_(1.1), SGD step; returns the loss tensor (entry/pemp_stage1.py:57-65)."""
+
+    def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.1, device=None,
+                 drop_rate=None, block_size=None):
+        from .networks.pemp_stage1 import net_ingredient
+        cfg = net_ingredient.cfg
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.model = model
+        model.train()
+        self.eng = Stage1TrainEngine(model, self.device)
+        self.eng.drop_rate = cfg["drop_rate"] if drop_rate is None else drop_rate
+        self.eng.block_size = cfg["block_size"] if block_size is None else block_size
+        self.lr, self.momentum, self.wd, self.max_norm = lr, momentum, weight_decay, max_norm
+        self.protos = 0 if model.ctr is None else model.ctr.shape[1] // 2
+        self.dist_scalar = cfg["dist_scalar"]
+        self.last_grad_norm = None
+
+    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk):
+        """Fills the flat gradient buffer; returns (loss, logits)."""
+        eng = self.eng
+        B, S, ch, H, W = sup_img.shape
+        Q = qry_img.shape[1]
+        eng.flat.grad.zero_()
+        feat = eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)])
+        leaf = feat.detach().requires_grad_(True)
+        ctr = self.model.ctr
+        if ctr is not None:
+            ctr.grad = None
+        with torch.enable_grad():
+            loss, logits = head_loss(leaf, sup_mask, qry_msk.reshape(-1, *qry_msk.shape[-2:]), ctr, B, S, Q, self.protos,
+                                     self.dist_scalar, tuple(qry_msk.shape[-2:]))
+            grads = torch.autograd.grad(loss, [leaf] + ([ctr] if ctr is not None else []))
+        if ctr is not None:
+            off = eng.flat.offs[[id(p) for p in eng.flat.params].index(id(ctr))]
+            eng.flat.grad[off:off + ctr.numel()].view(ctr.shape).copy_(grads[1])
+            ctr.grad = eng.flat.grad[off:off + ctr.numel()].view(ctr.shape)
+        eng.backward(grads[0].contiguous())
+        return loss.detach(), logits.detach()
+
+    def train_step(self, sup_img, sup_mask, qry_img, qry_msk=None):
+        loss, _ = self.forward_backward(sup_img.to(self.device), sup_mask.to(self.device), qry_img.to(self.device),
+                                        qry_msk.to(self.device))
+        self.optimizer_step()
+        return loss
+
+    def optimizer_step(self):
+        f = self.eng.flat
+        scale = 1.0
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(f.grad, op=dist.ReduceOp.SUM)          # one 47.8 MB bucket over RCCL
+            scale = 1.0 / dist.get_world_size()
+        self.last_grad_norm = T.sgd_clip_step(f.data, f.grad, f.mom, self.max_norm, self.lr, self.momentum, self.wd,
+                                              f.first_step, grad_scale=scale, ws_cache=self.eng.ws)
+        f.first_step = False
