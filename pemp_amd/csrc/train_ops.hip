@@ -84,17 +84,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     }
 }
 
-// stage 2 of BN statistics: mean, invstd, running-stat update (momentum form of nn.BatchNorm2d)
-__global__ void bn_stats_final_kernel(const double* __restrict__ part, int nchunk, int M, int C, float eps,
-                                      float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                      float* __restrict__ run_mean, float* __restrict__ run_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
+// stage 2 of the column sums: one wave per channel; lane l adds chunks l, l+64, ... in order, then a
+// fixed butterfly -> deterministic.  Returns the two totals in every lane.
+__device__ __forceinline__ void colsum_total(const double* __restrict__ part, int nchunk, int C, int c, double& s,
+                                             double& ss) {
+    const int lane = threadIdx.x & 63;
+    s = 0.0;
+    ss = 0.0;
+    for (int k = lane; k < nchunk; k += 64) {
         s += part[((size_t)k * 2 + 0) * C + c];
         ss += part[((size_t)k * 2 + 1) * C + c];
     }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+    }
+}
+
+// BN statistics: mean, invstd, running-stat update (momentum form of nn.BatchNorm2d)
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int nchunk, int M, int C,
+                                                             float eps, float momentum, float* __restrict__ mean,
+                                                             float* __restrict__ invstd, float* __restrict__ run_mean,
+                                                             float* __restrict__ run_var) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s, ss;
+    colsum_total(part, nchunk, C, c, s, ss);
+    if ((threadIdx.x & 63) != 0) return;
     const double mu = s / M;
     double var = ss / M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -107,16 +123,14 @@ __global__ void bn_stats_final_kernel(const double* __restrict__ part, int nchun
     }
 }
 
-// stage 2 of the backward sums: out[0][c] = sum a, out[1][c] = sum b  (fp32 results)
-__global__ void colsum_final_kernel(const double* __restrict__ part, int nchunk, int C, float* __restrict__ out0,
-                                    float* __restrict__ out1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// backward sums: out0[c] = sum a, out1[c] = sum b  (fp32 results)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, int nchunk, int C,
+                                                           float* __restrict__ out0, float* __restrict__ out1) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        s += part[((size_t)k * 2 + 0) * C + c];
-        ss += part[((size_t)k * 2 + 1) * C + c];
-    }
+    double s, ss;
+    colsum_total(part, nchunk, C, c, s, ss);
+    if ((threadIdx.x & 63) != 0) return;
     if (out0) out0[c] = (float)s;
     if (out1) out1[c] = (float)ss;
 }
@@ -372,7 +386,7 @@ extern "C" int pemp_bn_stats_f32(const float* z, int ldz, int M, int C, float ep
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_kernel<0>, dim3(nck, cdiv(C, 64)), dim3(256), 0, st, z, ldz, (const float*)nullptr, 0,
                        (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (double*)ws, M, C, 0);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const double*)ws, nck, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nck, M, C, eps,
                        momentum, mean, invstd, run_mean, run_var);
     return launch_status("bn_stats");
 }
@@ -405,7 +419,7 @@ extern "C" int pemp_bn_bwd_f32(const float* dy, int lddy, const float* y, int ld
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_kernel<1>, dim3(nck, cdiv(C, 64)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean, invstd,
                        (double*)ws, M, C, relu);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const double*)ws, nck, C, dbeta, dgamma);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nck, C, dbeta, dgamma);
     const long long total = (long long)M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean,
                        invstd, gamma, dbeta, dgamma, dz, lddz, gout, ldg, (long long)M, C / 4, relu);
@@ -430,7 +444,7 @@ extern "C" int pemp_relu_bias_bwd_f32(const float* dy, int lddy, const float* y,
         hipLaunchKernelGGL(colsum_kernel<2>, dim3(nck, cdiv(C, 64)), dim3(256), 0, st, (const float*)g, ldg,
                            (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)nullptr,
                            (const float*)nullptr, (double*)ws, M, C, 0);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, (const double*)ws, nck, C, dbias,
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nck, C, dbias,
                            (float*)nullptr);
     }
     return launch_status("relu_bias_bwd");

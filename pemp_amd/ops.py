@@ -58,7 +58,7 @@ class ConvParams:
         self.w, self.scale, self.shift = w, scale, shift
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.stride, self.pad, self.dil, self.kpad, self.stem, self.relu = stride, pad, dil, kpad, stem, relu
-        self.tiles = {}          # autotuned kernel variant per input shape (n, h, w)
+        self.tiles = None        # (kept for ABI of the slot list; the autotune cache is global, keyed by geometry)
 
 
 #: kernel variants the autotuner may pick: id -> (BM, BN); ids >= 11 stage through LDS-DMA.  All variants
@@ -66,6 +66,7 @@ class ConvParams:
 TILE_VARIANTS = {13: (64, 64), 12: (128, 64), 11: (128, 128), 3: (64, 64)}
 AUTOTUNE = True
 DEFAULT_TILE = 13
+_TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared by every ConvParams object
 
 
 def _pick_tile(launch, p, key, cout):
@@ -84,7 +85,7 @@ def _pick_tile(launch, p, key, cout):
         ms = e0.elapsed_time(e1)
         if best_ms is None or ms < best_ms * 0.98:  # prefer earlier (default) variants on ties
             best, best_ms = t, ms
-    p.tiles[key] = best
+    _TILE_CACHE[key] = best
     return best
 
 
@@ -139,10 +140,11 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
                                             _p(residual), _stream()), "pemp_conv2d_nhwc_f32")
 
     if tile == 0:
-        tile = p.tiles.get((n, h, w))
+        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, p.stem, n, h, w)
+        tile = _TILE_CACHE.get(key)
         if tile is None:
             if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():
-                tile = _pick_tile(launch, p, (n, h, w), p.cout)
+                tile = _pick_tile(launch, p, key, p.cout)
             else:
                 tile = DEFAULT_TILE
     launch(tile)
