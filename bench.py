@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PEMP_BENCH_BATCH", "16")),
                     help="episodes per step (the reference evaluates 1 per step)")
     ap.add_argument("--shot", type=int, default=1)
+    ap.add_argument("--mode", choices=("eval", "train"), default="eval",
+                    help="eval (headline metric, BASELINE.json configs[1]) or train (configs[2])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-episodes", type=int, default=12, help="bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -142,8 +144,63 @@ def cpu_baseline(sd, shot, n_eps):
                       f"{cores} threads, median {np.median(times) * 1e3:.0f} ms/episode"}
 
 
+def main_train(args, world, rank, dev):
+    """--mode train: Trainer.train_step (reference entry/pemp_stage1.py:57-65) on `--batch` episodes per
+    rank (the reference's data.bs = 4), data-parallel: one flat-gradient all-reduce per step over RCCL."""
+    from pemp_amd import synth
+    from pemp_amd.networks import pemp_stage1 as m
+    from pemp_amd.train_engine import Stage1Trainer
+    from tests import util
+    net = m.ModelClass(None)
+    net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    tr = Stage1Trainer(net, device=dev)
+    B = args.batch
+    pool = []
+    for g in range(3):
+        b = synth.make_batch([1234 + 1000 * rank + g * B + i for i in range(B)], shot=args.shot, out_hw=(401, 401))
+        pool.append(tuple(torch.from_numpy(b[k]).to(dev) for k in ("sup_img", "sup_mask", "qry_img")) +
+                    (torch.from_numpy(b["qry_mask"][:, 0]).to(dev),))
+    for i in range(args.warmup):
+        tr.train_step(*pool[i % len(pool)])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    losses = []
+    for i in range(args.steps):
+        losses.append(tr.train_step(*pool[i % len(pool)]))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ls = torch.stack(losses).cpu().numpy()
+    assert np.isfinite(ls).all()
+    if rank == 0:
+        gflop = 3 * 2 * 64.94 * B                       # fwd + dgrad + wgrad, 2 images/episode, GFLOP
+        print(json.dumps({
+            "metric": "train episodes/sec (PEMP stage-1 train_step, ResNet-50, 1-shot, 401x401)",
+            "value": round(args.steps * B * world / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "pemp_stage1 train_step (batch-stat BN, DropBlock 0.1, CE, clip 1.1, SGD), "
+                                   "%d episodes/rank/step" % B, "episodes_per_step": B, "shot": args.shot,
+                       "first_loss": round(float(ls[0]), 5), "last_loss": round(float(ls[-1]), 5),
+                       "effective_tflops": round(gflop * world / (dt / args.steps) / 1e3, 2)}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == "train" and args.batch == int(os.environ.get("PEMP_BENCH_BATCH", "16")) and "--batch" not in sys.argv:
+        args.batch = 4
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -154,7 +211,12 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     from pemp_amd import build, ops
-    build.build()
+    if local == 0:
+        build.build()                 # normally a no-op: the prebuilt .so travels with the snapshot
+    if world > 1:
+        dist.barrier()
+    if args.mode == "train":
+        return main_train(args, world, rank, dev)
     net, sd = build_model(dev)
     pool = episode_pool(dev, args.shot, args.batch, rank)
     ws = {}

@@ -1,0 +1,67 @@
+"""Training harness of PEMP stage 1 on MI355X (counterpart of the reference's
+entry/pemp_stage1.py:57-65,68-113 and core/base_trainer.py:183-210 on synthetic episodes).
+
+One process per GPU (``torchrun --nproc-per-node N -m pemp_amd.entry.train_stage1 ...``): every rank
+draws its own ``bs`` episodes per step (distinct sampler offsets), BatchNorm uses the rank-local batch
+statistics exactly as the reference's single-GPU batch does, gradients are SUM-all-reduced in one
+flat 47.8 MB bucket over RCCL and averaged inside the fused clip-norm + SGD kernel, so every rank
+holds identical weights after every step.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from .. import synth
+from ..networks.pemp_stage1 import ModelClass
+from ..train_engine import Stage1Trainer
+
+
+class Trainer(Stage1Trainer):
+    """``train_step(*inputs, qry_msk=...)`` exactly as the reference's Trainer (entry/pemp_stage1.py:57-65)."""
+
+    def train_step(self, *inputs, qry_msk=None):
+        return super().train_step(*inputs, qry_msk=qry_msk.view(-1, *qry_msk.shape[-2:]))
+
+
+def synthetic_batches(bs, shot, n_steps, seed, rank, height=401, width=401):
+    for step in range(n_steps):
+        seeds = [seed + (step * 1000003 + rank * 7919 + i) % 2 ** 30 for i in range(bs)]
+        b = synth.make_batch(seeds, shot=shot, height=height, width=width, out_hw=(height, width))
+        yield (torch.from_numpy(b["sup_img"]), torch.from_numpy(b["sup_mask"]), torch.from_numpy(b["qry_img"])), \
+            torch.from_numpy(b["qry_mask"])
+
+
+def broadcast_model(model, src=0):
+    """Identical start on every rank (parameters and BN buffers)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src)
+
+
+def main(steps=20, bs=4, shot=1, lr=1e-3, seed=1234, log_every=5):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(seed + rank)
+    model = ModelClass(None)
+    trainer = Trainer(model, lr=lr, device=dev)
+    broadcast_model(model)
+    t0 = time.time()
+    for i, (inputs, qry_msk) in enumerate(synthetic_batches(bs, shot, steps, seed, rank)):
+        loss = trainer.train_step(*inputs, qry_msk=qry_msk)
+        if rank == 0 and (i + 1) % log_every == 0:
+            print(f"step {i + 1}/{steps} loss {loss.item():.5f} |g| {trainer.last_grad_norm.item():.4f} "
+                  f"{(i + 1) * bs * world / (time.time() - t0):.1f} episodes/s")
+    return model
+
+
+if __name__ == "__main__":
+    import sys
+    kw = dict(a.split("=") for a in sys.argv[1:])
+    main(**{k: (float(v) if "." in v or "e" in v else int(v)) for k, v in kw.items()})

@@ -384,6 +384,16 @@ def head_loss(feat_nhwc, sup_mask, qry_mask, ctr, B, S, Q, protos, dist_scalar, 
     return F.cross_entropy(logits, qry_mask, ignore_index=255), logits
 
 
+def allreduce_gradients(flat_grad):
+    """The one collective of a training step: SUM all-reduce of the flat gradient bucket (47.8 MB for
+    stage 1) over RCCL (gloo on CPU in tests).  Returns the factor that turns the sum into the mean;
+    the fused optimizer kernel applies it, so no extra pass over the bucket is needed."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        return 1.0 / dist.get_world_size()
+    return 1.0
+
+
 class Stage1Trainer:
     """``train_step`` with the reference's contract: zero_grad, forward, CE loss, backward,
     clip_grad_norm_(1.1), SGD step; returns the loss tensor (entry/pemp_stage1.py:57-65)."""
@@ -433,10 +443,7 @@ class Stage1Trainer:
 
     def optimizer_step(self):
         f = self.eng.flat
-        scale = 1.0
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(f.grad, op=dist.ReduceOp.SUM)          # one 47.8 MB bucket over RCCL
-            scale = 1.0 / dist.get_world_size()
+        scale = allreduce_gradients(f.grad)
         self.last_grad_norm = T.sgd_clip_step(f.data, f.grad, f.mom, self.max_norm, self.lr, self.momentum, self.wd,
                                               f.first_step, grad_scale=scale, ws_cache=self.eng.ws)
         f.first_step = False

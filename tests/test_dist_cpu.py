@@ -61,3 +61,46 @@ def test_two_rank_eval_round_equals_single_process():
         assert miou == single[0] and biou == single[1]          # integer tables: exact
         assert np.array_equal(stat, single[2]) and cnt == n
         assert abs(loss - single[3]) < 1e-9
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pemp_amd.train_engine import allreduce_gradients
+        from pemp_amd.entry.train_stage1 import broadcast_model
+        g = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # rank-specific "gradients"
+        scale = allreduce_gradients(g)
+        lin = torch.nn.Linear(4, 3)
+        torch.manual_seed(100 + rank)
+        with torch.no_grad():
+            lin.weight.normal_()
+        broadcast_model(lin)
+        q.put((rank, g.clone(), scale, lin.weight.detach().clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_bucket_allreduce_and_broadcast():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in procs:
+        r, g, scale, w = q.get(timeout=120)
+        got[r] = (g, scale, w)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = torch.arange(1000, dtype=torch.float32)
+    for r in (0, 1):
+        g, scale, w = got[r]
+        assert scale == 0.5 and torch.equal(g, base * 3) and torch.equal(g * scale, base * 1.5)   # mean of ranks
+    assert torch.equal(got[0][2], got[1][2])                                                     # same weights
