@@ -84,7 +84,9 @@ def conv_roofline(net, pool, reps=3):
         e1.record()
         n, ho, wo, co = y.shape
         cin_real = 3 if (p.stem and p.cin == 4 and not getattr(p, "real4", False)) else p.cin
-        records.append((e0, e1, 2.0 * n * ho * wo * co * p.kh * p.kw * cin_real))
+        nbytes = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * p.cin + n * ho * wo * co * (2 if kw.get("residual") is not None else 1)
+                        + p.w.numel())
+        records.append((e0, e1, 2.0 * n * ho * wo * co * p.kh * p.kw * cin_real, nbytes))
         return y
 
     ops.conv2d = timed
@@ -101,13 +103,23 @@ def conv_roofline(net, pool, reps=3):
     finally:
         ops.conv2d = orig
         eng.ops.conv2d = orig
-    ms = sum(a.elapsed_time(b) for a, b, _ in records)
-    flops = sum(f for _, _, f in records)
+    ms = sum(r[0].elapsed_time(r[1]) for r in records)
+    flops = sum(r[2] for r in records)
+    abytes = sum(r[3] for r in records)
     n = len(records)
     ach = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per launch from the PMC counters cannot be collected in-process; they are measured with
+    # rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) on this same
+    # command and committed under profiles/.  Reported only when that file matches the batch size.
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+    if os.path.exists(tf) and len(pool[0]["seeds"]) == 16:
+        with open(tf) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": "conv_dma_kernel + conv_igemm_kernel (all conv launches of a step)",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(abytes / n),
             "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
             "gflop_per_step": round(flops / reps / 1e9, 2), "conv_ms_per_step": round(ms / reps, 4)}
 
