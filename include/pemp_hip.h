@@ -184,6 +184,19 @@ int pemp_scatter_strided_nhwc_f32(const float* src, float* dst, int N, int H, in
                                   int C, int s, void* stream);
 /* dst[n][i][c] += v[n][c] / HW : backward of F.adaptive_avg_pool2d(x,(1,1)).                      */
 int pemp_gap_bwd_add_nhwc_f32(const float* v, float* dst, int ld, int N, int HW, int C, void* stream);
+/* Backward of the prototype head under mean cross-entropy: reverse of networks/pemp_stage1.py:142-163,
+ * 195-261 + core/losses.py:10.  Inputs are the forward's operands and by-products:
+ *   fwd_ws  the workspace pemp_mpm_protos_f32 (p > 0) / pemp_masked_avg_pool_f32(full_res=0) (p == 0) left
+ *           behind for the same features and masks; protos [B][J][c]; pred [B][2][n];
+ *   target int64 [B][Ho][Wo]; stats [B][8] from pemp_eval_tail_f32 (valid-pixel counts).
+ * Outputs: dsup [B*S][n][ldd], dqry [B][n][ldd] (feature gradients), dctr [c][2p] (NULL when p == 0). */
+size_t pemp_head_bwd_workspace_bytes(int B, int S, int n, int c, int p);
+int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, int ldf, const float* mask,
+                      const float* ctr, const void* fwd_ws, const float* protos, const float* pred,
+                      const int64_t* target, const double* stats, float* dsup, float* dqry, int ldd,
+                      float* dctr, void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W,
+                      int Ho, int Wo, int c, int p, float dist_scalar, void* stream);
+
 /* nn.utils.clip_grad_norm_(params, max_norm) + SGD(momentum, weight_decay).step() on flat buffers
  * (entry/pemp_stage1.py:63-64, core/solver.py:87-91).  grad_scale multiplies the gradients first
  * (1/world after a SUM all-reduce); max_norm <= 0 disables clipping; grad_norm_out[0] = ||g||_2.  */

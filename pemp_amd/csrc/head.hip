@@ -5,20 +5,9 @@
 // All of these are streaming kernels over [pixels][c] feature maps (c contiguous): their bound
 // is HBM/L2 bandwidth (AI ~ 3 flop/B at 2p = 6 prototypes), so the design is wave-per-pixel
 // coalesced 16-B loads + wavefront shuffles, partial sums in a fixed order (deterministic).
-#include "common.h"
+#include "head_common.h"
 
 namespace pemp {
-
-constexpr int MAXJ = 8;     // 2p <= 8
-constexpr int MAXCL = 8;    // channels per lane: c <= 64*MAXCL = 512
-constexpr int PCHUNK = 32;  // pixels per pooling block
-
-// F.interpolate(mode="nearest") source index (legacy rule: floor(dst * in/out), scale in fp32)
-__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
-    float scale = (float)in / (float)out;
-    int s = (int)floorf((float)dst * scale);
-    return min(s, in - 1);
-}
 
 // -----------------------------------------------------------------------------------------------
 // assign weights  A[bs][j][i]
@@ -312,30 +301,6 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ q
 }
 
 // -----------------------------------------------------------------------------------------------
-// bilinear, align_corners=True (ATen area_pixel_compute_scale: (in-1)/(out-1) in fp32)
-struct Bilin {
-    int i0, i1;
-    float l;
-};
-__device__ __forceinline__ Bilin bilin(int dst, int in, int out) {
-    float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    float f = scale * (float)dst;
-    Bilin b;
-    b.i0 = min((int)f, in - 1);
-    b.i1 = b.i0 + (b.i0 < in - 1 ? 1 : 0);
-    b.l = f - (float)b.i0;
-    return b;
-}
-__device__ __forceinline__ float bilerp(const float* __restrict__ p, int w, Bilin by, Bilin bx) {
-    float v00 = p[by.i0 * w + bx.i0], v01 = p[by.i0 * w + bx.i1];
-    float v10 = p[by.i1 * w + bx.i0], v11 = p[by.i1 * w + bx.i1];
-    // explicit rounding points so that every kernel using this helper produces the same bits
-    float h0 = 1.f - by.l, w0 = 1.f - bx.l;
-    float top = __fmaf_rn(bx.l, v01, __fmul_rn(w0, v00));
-    float bot = __fmaf_rn(bx.l, v11, __fmul_rn(w0, v10));
-    return __fmaf_rn(by.l, bot, __fmul_rn(h0, top));
-}
-
 __global__ void upsample_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int BC, int h, int w,
                                          int Ho, int Wo) {
     long long total = (long long)BC * Ho * Wo;
@@ -426,18 +391,13 @@ static inline int tail_blocks(int Ho, int Wo) {
     int nb = cdiv(Ho * Wo, 256 * 4);
     return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
 }
-static inline int nchunks_of(int n) { return cdiv(n, PCHUNK); }
 
 }  // namespace pemp
 
 using namespace pemp;
 
 // workspace layout for pooling: A[BS][J][n] | part[BS][nchunks][J][c] | asum[BS][nchunks][J] | msum[BS][2]
-static size_t pool_ws_bytes(int BS, int n, int c, int J) {
-    size_t nck = nchunks_of(n);
-    size_t f = (size_t)BS * J * n + (size_t)BS * nck * J * c + (size_t)BS * nck * J + (size_t)BS * 2 + 16;
-    return f * sizeof(float);
-}
+static size_t pool_ws_bytes(int BS, int n, int c, int J) { return pool_ws_floats(BS, n, c, J) * sizeof(float); }
 
 extern "C" size_t pemp_mpm_workspace_bytes(int B, int S, int n, int c, int p) {
     return pool_ws_bytes(B * S, n, c, 2 * p);
@@ -456,10 +416,8 @@ static int pooled_protos(int mode, const float* feat, int ldf, const float* mask
     PEMP_REQUIRE(ws_bytes >= pool_ws_bytes(BS, n, c, J), "protos: workspace too small");
     PEMP_REQUIRE(((uintptr_t)feat & 15) == 0, "protos: feat must be 16-byte aligned");
     const int nck = nchunks_of(n);
-    float* A = (float*)ws;
-    float* part = A + (size_t)BS * J * n;
-    float* asum = part + (size_t)BS * nck * J * c;
-    float* msum = asum + (size_t)BS * nck * J;
+    const PoolWs L = pool_ws_layout(ws, BS, n, c, J);
+    float *A = L.A, *part = L.part, *asum = L.asum, *msum = L.msum;
     // few, long-lived blocks: every block first loads its lanes' slice of ctr (48 values per lane)
     const int ablk = min(cdiv(n, 4), max(1, 512 / BS));
     if (mode == 0) {

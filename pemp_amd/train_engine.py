@@ -413,13 +413,17 @@ class Stage1Trainer:
         self.dist_scalar = cfg["dist_scalar"]
         self.last_grad_norm = None
 
-    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk):
-        """Fills the flat gradient buffer; returns (loss, logits)."""
+    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, head="hip"):
+        """Fills the flat gradient buffer; returns (loss, logits).  ``head="hip"`` runs the prototype head
+        and its backward on libpemp_hip.so (logits are then produced only on request: returns the low-res
+        prediction instead); ``head="torch"`` is the autograd cross-check used by the tests."""
         eng = self.eng
         B, S, ch, H, W = sup_img.shape
         Q = qry_img.shape[1]
         eng.flat.grad.zero_()
         feat = eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)])
+        if head == "hip":
+            return self._head_hip(feat, sup_mask, qry_msk, B, S, Q)
         leaf = feat.detach().requires_grad_(True)
         ctr = self.model.ctr
         if ctr is not None:
@@ -434,6 +438,33 @@ class Stage1Trainer:
             ctr.grad = eng.flat.grad[off:off + ctr.numel()].view(ctr.shape)
         eng.backward(grads[0].contiguous())
         return loss.detach(), logits.detach()
+
+    def _head_hip(self, feat, sup_mask, qry_msk, B, S, Q):
+        """MPM / cosine / upsample + CE forward and backward on the HIP kernels."""
+        if Q != 1:
+            raise ValueError("query must be 1")
+        eng, ws = self.eng, self.eng.ws
+        H, W = sup_mask.shape[-2:]
+        msk = sup_mask.reshape(B * S, 2, H, W).contiguous()
+        tgt = qry_msk.reshape(-1, *qry_msk.shape[-2:]).contiguous()
+        sup, qry = feat[:B * S], feat[B * S:]
+        ctr = self.model.ctr
+        if self.protos > 0:
+            key = ("mpm", B, S, sup.shape[1], sup.shape[2], sup.shape[3], self.protos)
+            pro = ops.mpm_protos(sup, msk, ctr.data, B, S, self.protos, ws_cache=ws)
+        else:
+            key = ("map", B, S, sup.shape[1], sup.shape[2], sup.shape[3])
+            pro = ops.masked_avg_pool(sup, msk, B, S, full_res=False, ws_cache=ws)
+        pred = ops.cosine_proto_max(qry, pro, self.dist_scalar)
+        _, stats, _ = ops.eval_tail(pred, tgt, ws_cache=ws)
+        loss = stats[:, 0].sum() / stats[:, 1].sum()
+        dfeat = torch.empty_like(feat)
+        dctr = T.head_bwd(sup, qry, msk, ctr.data if ctr is not None else None, ws[key], pro, pred, tgt, stats, dfeat,
+                          B, S, self.protos, self.dist_scalar, ws_cache=ws)
+        if ctr is not None:
+            ctr.grad.copy_(dctr)
+        eng.backward(dfeat)
+        return loss.float(), pred
 
     def train_step(self, sup_img, sup_mask, qry_img, qry_msk=None):
         loss, _ = self.forward_backward(sup_img.to(self.device), sup_mask.to(self.device), qry_img.to(self.device),

@@ -33,12 +33,17 @@ def _batch(dev):
     return t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0])
 
 
-def test_train_step_gradients_match_reference(hip_lib, dev):
+@pytest.mark.parametrize("head", ["hip", "torch"])
+def test_train_step_gradients_match_reference(hip_lib, dev, head):
+    """head="hip": the whole step on libpemp_hip.so; head="torch": encoder on HIP, head by autograd (cross-check)."""
+    from pemp_amd import ops
     g = util.gold("stage1_rn50_trainstep")
     g64 = util.gold("stage1_rn50_trainstep_f64")
     tr, net = _trainer(dev)
     sup, msk, qry, gt = _batch(dev)
-    loss, logits = tr.forward_backward(sup, msk, qry, gt)
+    loss, logits = tr.forward_backward(sup, msk, qry, gt, head=head)
+    if head == "hip":
+        logits = ops.upsample_bilinear_ac(logits, (97, 97))
     torch.cuda.synchronize()
     assert abs(loss.item() - float(g["loss"])) < 2e-5
     assert (logits.cpu()[:, :, ::7, ::7].numpy() - g["logits_s7"]).__abs__().max() < 5e-3

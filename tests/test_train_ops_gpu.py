@@ -167,3 +167,40 @@ def test_sgd_clip_step_matches_torch(hip_lib, dev):
     T.sgd_clip_step(pa, (g2 * 4).to(dev), torch.zeros(n, device=dev), 1.1, 1e-3, 0.9, 5e-4, True, grad_scale=0.25)
     T.sgd_clip_step(pb, g2.to(dev), torch.zeros(n, device=dev), 1.1, 1e-3, 0.9, 5e-4, True)
     assert torch.allclose(pa.cpu(), pb.cpu(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,S,p,c,h,w,H,W,Ho,Wo", [(2, 2, 3, 512, 9, 11, 70, 85, 50, 61), (1, 1, 2, 256, 7, 7, 50, 50, 33, 40),
+                                                   (2, 1, 0, 512, 6, 5, 41, 37, 41, 37), (1, 5, 3, 128, 5, 6, 40, 47, 40, 47)])
+def test_head_backward_matches_autograd(hip_lib, dev, B, S, p, c, h, w, H, W, Ho, Wo):
+    """pemp_head_bwd_f32 vs torch autograd through the torch restatement of the head (CPU)."""
+    from pemp_amd import ops, train_ops as T
+    from pemp_amd.train_engine import head_loss
+    feat = (_rand(B * S + B, h, w, c, seed=1) * 2).requires_grad_()
+    m = (_rand(B, S, 1, H, W, seed=3) > 0.1).float()
+    mask = torch.cat((m, 1 - m), dim=2)
+    ctr = _rand(c, 2 * p, seed=4, lo=0, hi=1).requires_grad_() if p > 0 else None
+    tgt = (_rand(B, Ho, Wo, seed=5) > 0.2).long()
+    tgt[0, :3] = 255
+    loss, _ = head_loss(feat, mask, tgt, ctr, B, S, 1, p, 20.0, (Ho, Wo))
+    grads = torch.autograd.grad(loss, [feat] + ([ctr] if p > 0 else []))
+    fd, md, td = feat.detach().to(dev), mask.reshape(B * S, 2, H, W).to(dev), tgt.to(dev)
+    ws = {}
+    sup, qry = fd[:B * S], fd[B * S:]
+    if p > 0:
+        pro = ops.mpm_protos(sup, md, ctr.detach().to(dev), B, S, p, ws_cache=ws)
+        key = ("mpm", B, S, h, w, c, p)
+    else:
+        pro = ops.masked_avg_pool(sup, md, B, S, full_res=False, ws_cache=ws)
+        key = ("map", B, S, h, w, c)
+    pred = ops.cosine_proto_max(qry, pro, 20.0)
+    _, stats, _ = ops.eval_tail(pred, td, ws_cache=ws)
+    got_loss = (stats[:, 0].sum() / stats[:, 1].sum()).item()
+    assert abs(got_loss - loss.item()) < 1e-5
+    dfeat = torch.empty_like(fd)
+    dctr = T.head_bwd(sup, qry, md, ctr.detach().to(dev) if p > 0 else None, ws[key], pro, pred, td, stats, dfeat, B, S, p,
+                      20.0, ws_cache=ws)
+    scale = grads[0].abs().max().item()
+    assert (dfeat.cpu() - grads[0]).abs().max().item() < 2e-4 * scale + 1e-9, (dfeat.cpu() - grads[0]).abs().max().item() / scale
+    if p > 0:
+        cs = grads[1].abs().max().item()
+        assert (dctr.cpu() - grads[1]).abs().max().item() < 5e-4 * cs + 1e-9, (dctr.cpu() - grads[1]).abs().max().item() / cs
