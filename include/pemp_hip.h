@@ -184,6 +184,19 @@ int pemp_scatter_strided_nhwc_f32(const float* src, float* dst, int N, int H, in
                                   int C, int s, void* stream);
 /* dst[n][i][c] += v[n][c] / HW : backward of F.adaptive_avg_pool2d(x,(1,1)).                      */
 int pemp_gap_bwd_add_nhwc_f32(const float* v, float* dst, int ld, int N, int HW, int C, void* stream);
+/* Same as pemp_eval_tail_f32 with per-pixel CE weights (CELossDT, core/losses.py:33-43): stats[b][0] =
+ * sum w*ce over valid pixels, stats[b][1] = sum of w over ALL pixels (the reference's denominator).   */
+int pemp_eval_tail_weighted_f32(const float* pred, const int64_t* target, const float* weight,
+                                uint8_t* pred_out, float* logits_out, double* stats, void* ws,
+                                size_t ws_bytes, int B, int h, int w, int Ho, int Wo, void* stream);
+
+/* CELossDT.boundary2weight (core/losses.py:23-31,35-41): boundary of the fg mask (3x3 dilate/erode), exact
+ * Euclidean distance transform, weight = exp(-edt/sigma^2) + 1, all on the device (the reference calls scipy
+ * on the host every step).  target int64 [B][H][W] -> weight fp32 [B][H][W].                          */
+size_t pemp_cedt_workspace_bytes(int B, int H, int W);
+int pemp_cedt_weight_f32(const int64_t* target, float* weight, void* ws, size_t ws_bytes,
+                         int B, int H, int W, float sigma, void* stream);
+
 /* Backward of the prototype head under mean cross-entropy: reverse of networks/pemp_stage1.py:142-163,
  * 195-261 + core/losses.py:10.  Inputs are the forward's operands and by-products:
  *   fwd_ws  the workspace pemp_mpm_protos_f32 (p > 0) / pemp_masked_avg_pool_f32(full_res=0) (p == 0) left
@@ -193,7 +206,8 @@ int pemp_gap_bwd_add_nhwc_f32(const float* v, float* dst, int ld, int N, int HW,
 size_t pemp_head_bwd_workspace_bytes(int B, int S, int n, int c, int p);
 int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, int ldf, const float* mask,
                       const float* ctr, const void* fwd_ws, const float* protos, const float* pred,
-                      const int64_t* target, const double* stats, float* dsup, float* dqry, int ldd,
+                      const int64_t* target, const float* weight /* NULL or [B][Ho][Wo] */,
+                      const double* stats, float* dsup, float* dqry, int ldd,
                       float* dctr, void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W,
                       int Ho, int Wo, int c, int p, float dist_scalar, void* stream);
 

@@ -331,3 +331,27 @@ class FewShotMetric:
 
 def to_torch_sd(np_sd):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in np_sd.items()}
+
+
+def cedt_weight(target, sigma=5.0):
+    """CELossDT.boundary2weight + the boundary extraction of CELossDT.__call__ (core/losses.py:23-41), with the
+    reference's removed ``np.bool`` spelled ``bool``.  target int64 [B,H,W] -> float32 weight [B,H,W]."""
+    from scipy.ndimage import distance_transform_edt
+    mask = torch.zeros_like(target, dtype=torch.float32)
+    mask[target == 1] = 1
+    mask = mask.unsqueeze(1)
+    kernel = torch.ones(1, 1, 3, 3, dtype=torch.float32)
+    conv = F.conv2d(mask, kernel, padding=1)
+    dilated = torch.clamp(conv, 0, 1) - mask
+    erosion = mask - torch.clamp(conv - 8, 0, 1)
+    boundary = (dilated + erosion).squeeze(1)
+    bb = np.around(boundary.numpy()).astype(bool)
+    edts = np.stack([distance_transform_edt(np.bitwise_not(b)) for b in bb], axis=0)
+    return (torch.exp(-torch.from_numpy(edts) / sigma ** 2) + 1).to(torch.float32)
+
+
+def celoss_dt(logits, target, sigma=5.0):
+    """CELossDT.__call__ (core/losses.py:33-43): sum(CE * w) / sum(w), ignore_index 255."""
+    loss = F.cross_entropy(logits, target, ignore_index=255, reduction="none")
+    w = cedt_weight(target, sigma)
+    return (loss * w).sum() / w.sum()

@@ -330,6 +330,7 @@ __global__ void upsample_nearest_kernel(const uint8_t* __restrict__ in, int64_t*
 // eval tail: upsample + argmax + CE partials + tp/fp/fn partials.  part[b][blk][8] doubles.
 __global__ __launch_bounds__(256) void eval_tail_kernel(const float* __restrict__ pred,
                                                         const int64_t* __restrict__ target,
+                                                        const float* __restrict__ weight,
                                                         uint8_t* __restrict__ pred_out, float* __restrict__ logits,
                                                         double* __restrict__ part, int h, int w, int Ho, int Wo) {
     __shared__ double red[4][8];
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void eval_tail_kernel(const float* __restrict_
     const int npix = Ho * Wo;
     const float* p0 = pred + (size_t)b * 2 * h * w;
     const float* p1 = p0 + h * w;
-    double ce = 0.0;
+    double ce = 0.0, wsum = 0.0;
     int cnt[7] = {0, 0, 0, 0, 0, 0, 0};  // valid, tp0, fp0, fn0, tp1, fp1, fn1
     for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
         int Y = i / Wo, X = i - Y * Wo;
@@ -351,10 +352,14 @@ __global__ __launch_bounds__(256) void eval_tail_kernel(const float* __restrict_
         }
         if (target) {
             int t = (int)target[(size_t)b * npix + i];
+            // CELossDT (core/losses.py:33-43): per-pixel weights; the denominator sums the weight of EVERY
+            // pixel, ignored ones included (their CE term is zero)
+            const float wgt = weight ? weight[(size_t)b * npix + i] : 1.f;
+            wsum += (double)wgt;
             if (t != 255) {
                 float m = fmaxf(l0, l1);
                 float lse = m + logf(expf(l0 - m) + expf(l1 - m));
-                ce += (double)(lse - (t == 1 ? l1 : l0));
+                ce += (double)((lse - (t == 1 ? l1 : l0)) * wgt);
                 cnt[0]++;
                 for (int j = 0; j < 2; ++j) {
                     cnt[1 + 3 * j] += (am == j && t == j);
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(256) void eval_tail_kernel(const float* __restrict_
     double v[8];
     v[0] = ce;
     for (int k = 0; k < 7; ++k) v[k + 1] = (double)cnt[k];
+    if (weight) v[1] = wsum;      // loss denominator: sum of weights instead of the valid-pixel count
     for (int k = 0; k < 8; ++k) {
         double x = v[k];
         for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -484,14 +490,26 @@ extern "C" size_t pemp_eval_tail_workspace_bytes(int B, int Ho, int Wo) {
     return (size_t)B * tail_blocks(Ho, Wo) * 8 * sizeof(double);
 }
 
+extern "C" int pemp_eval_tail_weighted_f32(const float* pred, const int64_t* target, const float* weight,
+                                           uint8_t* pred_out, float* logits_out, double* stats, void* ws,
+                                           size_t ws_bytes, int B, int h, int w, int Ho, int Wo, void* stream);
+
 extern "C" int pemp_eval_tail_f32(const float* pred, const int64_t* target, uint8_t* pred_out, float* logits_out,
                                   double* stats, void* ws, size_t ws_bytes, int B, int h, int w, int Ho, int Wo,
                                   void* stream) {
+    return pemp_eval_tail_weighted_f32(pred, target, nullptr, pred_out, logits_out, stats, ws, ws_bytes, B, h, w, Ho, Wo,
+                                       stream);
+}
+
+extern "C" int pemp_eval_tail_weighted_f32(const float* pred, const int64_t* target, const float* weight,
+                                           uint8_t* pred_out, float* logits_out, double* stats, void* ws,
+                                           size_t ws_bytes, int B, int h, int w, int Ho, int Wo, void* stream) {
     PEMP_REQUIRE(pred && pred_out && stats && ws, "eval_tail: null pointer");
+    PEMP_REQUIRE(!weight || target, "eval_tail: weight without target");
     PEMP_REQUIRE(B > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0, "eval_tail: bad dims");
     PEMP_REQUIRE(ws_bytes >= pemp_eval_tail_workspace_bytes(B, Ho, Wo), "eval_tail: workspace too small");
     const int nb = tail_blocks(Ho, Wo);
-    hipLaunchKernelGGL(eval_tail_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, pred, target, pred_out,
+    hipLaunchKernelGGL(eval_tail_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, pred, target, weight, pred_out,
                        logits_out, (double*)ws, h, w, Ho, Wo);
     hipLaunchKernelGGL(eval_tail_final_kernel, dim3(B, 8), dim3(64), 0, (hipStream_t)stream, (const double*)ws, stats, nb);
     return launch_status("eval_tail");

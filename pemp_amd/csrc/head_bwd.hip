@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void pool_shot_kernel(const float* __restrict__
 // One thread per low-resolution pixel; it visits the full-resolution pixels whose bilinear stencil
 // touches it and re-evaluates their logits from `pred`.
 __global__ void ce_upsample_bwd_kernel(const float* __restrict__ pred, const int64_t* __restrict__ target,
-                                       const double* __restrict__ stats, int B, float* __restrict__ dpred, int h, int w,
+                                       const float* __restrict__ weight, const double* __restrict__ stats, int B, float* __restrict__ dpred, int h, int w,
                                        int Ho, int Wo) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,7 +68,7 @@ __global__ void ce_upsample_bwd_kernel(const float* __restrict__ pred, const int
             const float m = fmaxf(l0, l1);
             const float e0 = expf(l0 - m), e1 = expf(l1 - m);
             const float s = e0 + e1;
-            const float wgt = wy * wx * inv;
+            const float wgt = wy * wx * inv * (weight ? weight[((size_t)b * Ho + Y) * Wo + X] : 1.f);
             g0 += wgt * (e0 / s - (t == 0 ? 1.f : 0.f));
             g1 += wgt * (e1 / s - (t == 1 ? 1.f : 0.f));
         }
@@ -448,11 +448,13 @@ extern "C" size_t pemp_head_bwd_workspace_bytes(int B, int S, int n, int c, int 
 //   fwd_ws   the workspace pemp_mpm_protos_f32 / pemp_masked_avg_pool_f32(full_res=0) left behind for the
 //            same inputs (holds the pooling partial sums)
 //   protos   [B][J][c] prototypes of the forward; pred [B][2][n] its low-res prediction
-//   target   int64 [B][Ho][Wo]; stats [B][8] from pemp_eval_tail_f32 (n_valid per episode at index 1)
+//   target   int64 [B][Ho][Wo]; weight [B][Ho][Wo] per-pixel CE weights or NULL (CELossDT);
+//   stats    [B][8] from pemp_eval_tail(_weighted)_f32 (loss denominator per episode at index 1)
 //   dsup [B*S][n][ldd], dqry [B][n][ldd] out; dctr [c][2p] out (ignored when p == 0: plain MAP)
 extern "C" int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, int ldf, const float* mask,
                                  const float* ctr, const void* fwd_ws, const float* protos, const float* pred,
-                                 const int64_t* target, const double* stats, float* dsup, float* dqry, int ldd,
+                                 const int64_t* target, const float* weight, const double* stats, float* dsup,
+                                 float* dqry, int ldd,
                                  float* dctr, void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W,
                                  int Ho, int Wo, int c, int p, float dist_scalar, void* stream) {
     PEMP_REQUIRE(sup_feat && qry_feat && mask && fwd_ws && protos && pred && target && stats && dsup && dqry && ws,
@@ -474,8 +476,8 @@ extern "C" int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, i
     const int nck = nchunks_of(n);
     hipLaunchKernelGGL(pool_shot_kernel, dim3(J, BS, cdiv(c, 64)), dim3(64), 0, st, (const float*)L.part,
                        (const float*)L.asum, Pps, Dps, c, J, nck, p > 0 ? 1e-6f : 1e-5f);
-    hipLaunchKernelGGL(ce_upsample_bwd_kernel, dim3(cdiv(n, 128), B), dim3(128), 0, st, pred, target, stats, B, dpred, h,
-                       w, Ho, Wo);
+    hipLaunchKernelGGL(ce_upsample_bwd_kernel, dim3(cdiv(n, 128), B), dim3(128), 0, st, pred, target, weight, stats, B,
+                       dpred, h, w, Ho, Wo);
     hipLaunchKernelGGL(cosine_bwd_kernel, dim3(HB_BLOCKS, B), dim3(256), 0, st, qry_feat, ldf, protos, (const float*)dpred,
                        dqry, ldd, cpart, n, c, p > 0 ? p : 1, dist_scalar);
     hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(J * c, 256), B), dim3(256), 0, st, (const float*)cpart, HB_BLOCKS, J * c,

@@ -305,7 +305,20 @@ def upsample_nearest_u8_i64(resp, out_hw):
     return out
 
 
-def eval_tail(pred, target, want_logits=False, ws_cache=None, out_hw=None):
+def cedt_weight(target, sigma=5.0, ws_cache=None):
+    """CELossDT weight map (core/losses.py:23-41) on the device: target int64 [B,H,W] -> fp32 [B,H,W]."""
+    lib = _lib.load()
+    _chk_dev(target)
+    if target.dtype != torch.int64 or not target.is_contiguous() or target.dim() != 3:
+        raise ValueError("cedt_weight: target must be contiguous int64 [B,H,W]")
+    b, h, w = target.shape
+    out = torch.empty((b, h, w), dtype=torch.float32, device=target.device)
+    ws = _ws(lib.pemp_cedt_workspace_bytes(b, h, w), target.device, ws_cache, ("cedt", b, h, w))
+    _lib.check(lib.pemp_cedt_weight_f32(_p(target), _p(out), _p(ws), ws.numel(), b, h, w, float(sigma), _stream()), "cedt_weight")
+    return out
+
+
+def eval_tail(pred, target, want_logits=False, ws_cache=None, out_hw=None, weight=None):
     """pred [B,2,h,w]; target int64 [B,Ho,Wo] (or None with ``out_hw``: argmax only, statistics are zero)
     -> (argmax uint8 [B,Ho,Wo], stats f64 [B,8], logits|None)."""
     lib = _lib.load()
@@ -324,8 +337,10 @@ def eval_tail(pred, target, want_logits=False, ws_cache=None, out_hw=None):
     logits = torch.empty((b, 2, ho, wo), dtype=torch.float32, device=pred.device) if want_logits else None
     nbytes = lib.pemp_eval_tail_workspace_bytes(b, ho, wo)
     ws = _ws(nbytes, pred.device, ws_cache, ("tail", b, ho, wo))
-    _lib.check(lib.pemp_eval_tail_f32(_p(pred), _p(target), _p(am), _p(logits), _p(stats), _p(ws), ws.numel(),
-                                      b, h, w, ho, wo, _stream()), "eval_tail")
+    if weight is not None and (weight.dtype != torch.float32 or not weight.is_contiguous() or tuple(weight.shape) != (b, ho, wo)):
+        raise ValueError("eval_tail: weight must be contiguous fp32 [B,Ho,Wo]")
+    _lib.check(lib.pemp_eval_tail_weighted_f32(_p(pred), _p(target), _p(weight), _p(am), _p(logits), _p(stats), _p(ws),
+                                               ws.numel(), b, h, w, ho, wo, _stream()), "eval_tail")
     return am, stats, logits
 
 

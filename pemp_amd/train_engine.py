@@ -354,7 +354,7 @@ class Stage1TrainEngine:
 # ---------------------------------------------------------------------------------------------
 # head on torch ops (GPU), differentiated by autograd -- reference networks/pemp_stage1.py:142-163,195-261
 # ---------------------------------------------------------------------------------------------
-def head_loss(feat_nhwc, sup_mask, qry_mask, ctr, B, S, Q, protos, dist_scalar, out_shape):
+def head_loss(feat_nhwc, sup_mask, qry_mask, ctr, B, S, Q, protos, dist_scalar, out_shape, weight=None):
     n, h, w, c = feat_nhwc.shape
     f = feat_nhwc.permute(0, 3, 1, 2)
     sup = f[:B * S].reshape(B, S, c, h * w).reshape(B * S, c, h * w)
@@ -381,6 +381,9 @@ def head_loss(feat_nhwc, sup_mask, qry_mask, ctr, B, S, Q, protos, dist_scalar, 
         pred = torch.stack((F.cosine_similarity(q, bgp[..., None, None], dim=1) * dist_scalar,
                             F.cosine_similarity(q, fgp[..., None, None], dim=1) * dist_scalar), dim=1)
     logits = F.interpolate(pred, out_shape, mode="bilinear", align_corners=True)
+    if weight is not None:          # CELossDT: sum(CE * w) / sum(w), core/losses.py:33-43
+        ce = F.cross_entropy(logits, qry_mask, ignore_index=255, reduction="none")
+        return (ce * weight).sum() / weight.sum(), logits
     return F.cross_entropy(logits, qry_mask, ignore_index=255), logits
 
 
@@ -399,7 +402,7 @@ class Stage1Trainer:
     clip_grad_norm_(1.1), SGD step; returns the loss tensor (entry/pemp_stage1.py:57-65)."""
 
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.1, device=None,
-                 drop_rate=None, block_size=None):
+                 drop_rate=None, block_size=None, loss="ce", sigma=5.0):
         from .networks.pemp_stage1 import net_ingredient
         cfg = net_ingredient.cfg
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -412,6 +415,8 @@ class Stage1Trainer:
         self.protos = 0 if model.ctr is None else model.ctr.shape[1] // 2
         self.dist_scalar = cfg["dist_scalar"]
         self.last_grad_norm = None
+        from .core import losses
+        self.loss_obj = losses.get({"loss": loss, "sigma": sigma})
 
     def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, head="hip"):
         """Fills the flat gradient buffer; returns (loss, logits).  ``head="hip"`` runs the prototype head
@@ -428,9 +433,10 @@ class Stage1Trainer:
         ctr = self.model.ctr
         if ctr is not None:
             ctr.grad = None
+        tgt_ = qry_msk.reshape(-1, *qry_msk.shape[-2:]).contiguous()
         with torch.enable_grad():
-            loss, logits = head_loss(leaf, sup_mask, qry_msk.reshape(-1, *qry_msk.shape[-2:]), ctr, B, S, Q, self.protos,
-                                     self.dist_scalar, tuple(qry_msk.shape[-2:]))
+            loss, logits = head_loss(leaf, sup_mask, tgt_, ctr, B, S, Q, self.protos,
+                                     self.dist_scalar, tuple(qry_msk.shape[-2:]), weight=self.loss_obj.weight_map(tgt_))
             grads = torch.autograd.grad(loss, [leaf] + ([ctr] if ctr is not None else []))
         if ctr is not None:
             off = eng.flat.offs[[id(p) for p in eng.flat.params].index(id(ctr))]
@@ -456,11 +462,12 @@ class Stage1Trainer:
             key = ("map", B, S, sup.shape[1], sup.shape[2], sup.shape[3])
             pro = ops.masked_avg_pool(sup, msk, B, S, full_res=False, ws_cache=ws)
         pred = ops.cosine_proto_max(qry, pro, self.dist_scalar)
-        _, stats, _ = ops.eval_tail(pred, tgt, ws_cache=ws)
+        wmap = self.loss_obj.weight_map(tgt)                    # None for plain CE
+        _, stats, _ = ops.eval_tail(pred, tgt, ws_cache=ws, weight=wmap)
         loss = stats[:, 0].sum() / stats[:, 1].sum()
         dfeat = torch.empty_like(feat)
         dctr = T.head_bwd(sup, qry, msk, ctr.data if ctr is not None else None, ws[key], pro, pred, tgt, stats, dfeat,
-                          B, S, self.protos, self.dist_scalar, ws_cache=ws)
+                          B, S, self.protos, self.dist_scalar, ws_cache=ws, weight=wmap)
         if ctr is not None:
             ctr.grad.copy_(dctr)
         eng.backward(dfeat)

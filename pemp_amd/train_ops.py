@@ -166,7 +166,7 @@ def sgd_clip_step(params, grads, buf, max_norm, lr, momentum, weight_decay, firs
 
 
 def head_bwd(sup_feat, qry_feat, sup_mask, ctr, fwd_ws, protos, pred, target, stats, dfeat, B, S, p, dist_scalar,
-             ws_cache=None):
+             ws_cache=None, weight=None):
     """Gradient of the mean CE loss w.r.t. the features (written into ``dfeat`` [B*S + B, h, w, c], supports
     first) and w.r.t. ``ctr`` (returned, [c, 2p]; None for the plain-MAP head p == 0)."""
     lib = _lib.load()
@@ -181,7 +181,7 @@ def head_bwd(sup_feat, qry_feat, sup_mask, ctr, fwd_ws, protos, pred, target, st
     nbytes = lib.pemp_head_bwd_workspace_bytes(B, S, h * w, c, p)
     ws = _ws(nbytes, sup_feat.device, ws_cache, ("head_bwd", B, S, h, w, c, p))
     _lib.check(lib.pemp_head_bwd_f32(_p(sup_feat), _p(qry_feat), ldf, _p(sup_mask), _p(ctr), _p(fwd_ws), _p(protos),
-                                     _p(pred), _p(target), _p(stats), _p(dfeat[:bs]), _p(dfeat[bs:]), ldd, _p(dctr),
+                                     _p(pred), _p(target), _p(weight), _p(stats), _p(dfeat[:bs]), _p(dfeat[bs:]), ldd, _p(dctr),
                                      _p(ws), ws.numel(), B, S, h, w, H, W, ho, wo, c, p, float(dist_scalar), _stream()),
                "head_bwd")
     return dctr
