@@ -77,7 +77,7 @@ def _grad_worker(rank, world, port, q):
         with torch.no_grad():
             lin.weight.normal_()
         broadcast_model(lin)
-        q.put((rank, g.clone(), scale, lin.weight.detach().clone()))
+        q.put((rank, g.numpy().copy(), scale, lin.weight.detach().numpy().copy()))   # plain arrays: no fd passing
     finally:
         dist.destroy_process_group()
 
@@ -99,8 +99,8 @@ def test_two_rank_gradient_bucket_allreduce_and_broadcast():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    base = torch.arange(1000, dtype=torch.float32)
+    base = np.arange(1000, dtype=np.float32)
     for r in (0, 1):
         g, scale, w = got[r]
-        assert scale == 0.5 and torch.equal(g, base * 3) and torch.equal(g * scale, base * 1.5)   # mean of ranks
-    assert torch.equal(got[0][2], got[1][2])                                                     # same weights
+        assert scale == 0.5 and np.array_equal(g, base * 3) and np.array_equal(g * scale, base * 1.5)   # mean of ranks
+    assert np.array_equal(got[0][2], got[1][2])                                                        # same weights
