@@ -21,12 +21,13 @@ __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f}
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WGM, bool STEM>
-__global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
-    constexpr int WGN = 4 / WGM;
+template <int BM, int BN, int WGM, bool STEM, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_dma_kernel(ConvArgs a) {
+    constexpr int WGN = NW / WGM;
+    constexpr int RPI = NW * 8;                 // rows covered by one DMA instruction round of the block
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int AL = BM / 32, BL = BN / 32;   // DMA wave-instructions per thread per K step
+    constexpr int AL = BM / RPI, BL = BN / RPI; // DMA wave-instructions per thread per K step
     constexpr int NBUF = 2;
 
     extern __shared__ __attribute__((aligned(16))) v4f smem[];
@@ -49,13 +50,13 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
     // loader role: thread (r, p) fetches, for rows r + 32 i, the quad that belongs at position p
     const int p = tid & 7;
     const int r = tid >> 3;
-    const int sq = p ^ ((r >> 1) & 7);          // source quad (same for every i: 32 i >> 1 = 0 mod 8)
+    const int sq = p ^ ((r >> 1) & 7);          // source quad (same for every i: RPI i >> 1 = 0 mod 8)
     const float* zero = g_zero16;
 
     int a_pix[AL], a_hi0[AL], a_wi0[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-        int m = m0 + r + 32 * i;
+        int m = m0 + r + RPI * i;
         bool ok = m < a.M;
         int mm = ok ? m : 0;
         int img = mm / a.HoWo;
@@ -70,20 +71,25 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
     }
     const float* pa[AL];
     const float* pb[BL];
+    const float* pb0[BL];
 #pragma unroll
-    for (int i = 0; i < BL; ++i) pb[i] = a.w + (size_t)(n0 + r + 32 * i) * a.Kpad + sq * 4;
+    for (int i = 0; i < BL; ++i) pb0[i] = pb[i] = a.w + (size_t)(n0 + r + RPI * i) * a.Kpad + sq * 4;
     int cur_tap = 0, cur_cb = 0;
 
-#define PEMP_SET_TAP(tap_)                                                                           \
+#ifndef PEMP_KORDER
+#define PEMP_KORDER 0   // (1 measured no better: L2 reuse is not the limiter, per-step tap decode costs) K-step order of multi-tap convs: 0 = tap outer / channel chunk inner, 1 = chunk outer / tap inner
+#endif
+#define PEMP_SET_TAP(tap_, cb_)                                                                      \
     do {                                                                                             \
         const int tap__ = (tap_);                                                                    \
+        const int coff__ = (cb_) * 32 + sq * 4;                                                      \
         const int kh = tap__ / a.KW, kw = tap__ - kh * a.KW;                                         \
         const int dh = kh * a.dil, dw = kw * a.dil;                                                  \
         const bool tok = tap__ < a.ntaps;                                                            \
         _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                             \
             const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                        \
             const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;     \
-            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + sq * 4 : zero;        \
+            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + coff__ : zero;        \
         }                                                                                            \
     } while (0)
 
@@ -101,24 +107,36 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
                 const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                    \
                 const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
                 const float* s_ = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * 4 : zero;       \
-                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(Ad_ + i * 256), 16, 0, 0);    \
+                __builtin_amdgcn_global_load_lds((gptr_t)s_, (lptr_t)(Ad_ + i * RPI * 8), 16, 0, 0); \
             }                                                                                        \
         } else {                                                                                     \
             _Pragma("unroll") for (int i = 0; i < AL; ++i)                                           \
-                __builtin_amdgcn_global_load_lds((gptr_t)pa[i], (lptr_t)(Ad_ + i * 256), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((gptr_t)pa[i], (lptr_t)(Ad_ + i * RPI * 8), 16, 0, 0); \
         }                                                                                            \
         _Pragma("unroll") for (int i = 0; i < BL; ++i)                                               \
-            __builtin_amdgcn_global_load_lds((gptr_t)pb[i], (lptr_t)(Bd_ + i * 256), 16, 0, 0);     \
+            __builtin_amdgcn_global_load_lds((gptr_t)pb[i], (lptr_t)(Bd_ + i * RPI * 8), 16, 0, 0); \
     } while (0)
 
 #define PEMP_ADVANCE()                                                                               \
     do {                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] += 32;                                  \
-        if constexpr (!STEM) {                                                                       \
+        if constexpr (STEM) {                                                                        \
+            _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] += 32;                              \
+        } else if (PEMP_KORDER == 1 && a.ntaps > 1) {                                                \
+            /* chunk outer, tap inner: the 9 taps of one 32-channel chunk re-read almost the same   \
+               cache lines back to back (L2 hits) instead of streaming the whole tensor per tap */   \
+            if (++cur_tap == a.ntaps) {                                                              \
+                cur_tap = 0;                                                                         \
+                ++cur_cb;                                                                            \
+            }                                                                                        \
+            PEMP_SET_TAP(cur_tap, cur_cb);                                                           \
+            const int koff = cur_tap * a.Cin + cur_cb * 32;                                          \
+            _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] = pb0[i] + koff;                    \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] += 32;                              \
             if (++cur_cb == a.cin_steps) {                                                           \
                 cur_cb = 0;                                                                          \
                 ++cur_tap;                                                                           \
-                PEMP_SET_TAP(cur_tap);                                                               \
+                PEMP_SET_TAP(cur_tap, 0);                                                            \
             } else {                                                                                 \
                 _Pragma("unroll") for (int i = 0; i < AL; ++i) pa[i] = pa[i] == zero ? zero : pa[i] + 32; \
             }                                                                                        \
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    if constexpr (!STEM) PEMP_SET_TAP(0);
+    if constexpr (!STEM) PEMP_SET_TAP(0, 0);
     PEMP_DMA(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -143,7 +161,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
     const int arow = (wm0 + lr) * 8, brow = (wn0 + lr) * 8;
     for (int kt = 0; kt < a.nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < a.nk) {      // wave-uniform
+#ifndef PEMP_ABLATE
+#define PEMP_ABLATE 0   // timing builds only: 1 = no DMA in the loop, 2 = DMA but no wait/barrier, 3 = neither
+#endif
+        if (kt + 1 < a.nk && !(PEMP_ABLATE & 1)) {      // wave-uniform
             PEMP_ADVANCE();
             PEMP_DMA(kt + 1, buf ^ 1);
         }
@@ -178,8 +199,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of step kt+1 have landed
-        __syncthreads();                                    // ... and everybody's; all reads of `buf` are done
+        if (!(PEMP_ABLATE & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of step kt+1 have landed
+            __syncthreads();                                    // ... and everybody's; all reads of `buf` are done
+        }
     }
 #undef PEMP_DMA
 #undef PEMP_ADVANCE
@@ -227,10 +250,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(ConvArgs a) {
     }
 }
 
-template <int BM, int BN, int WGM, bool STEM>
+template <int BM, int BN, int WGM, bool STEM, int NW = 4>
 static int launch_dma(const ConvArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
-    auto kern = conv_dma_kernel<BM, BN, WGM, STEM>;
+    auto kern = conv_dma_kernel<BM, BN, WGM, STEM, NW>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -239,12 +262,14 @@ static int launch_dma(const ConvArgs& a, hipStream_t st) {
         }
     }
     const int grid = cdiv(a.M, BM) * (a.Cout / BN);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
     return launch_status("conv_dma");
 }
 
 int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st) {
     const bool stem = a.flags & PEMP_CONV_STEM4;
+    if (tile == 4) return stem ? launch_dma<128, 128, 4, true, 8>(a, st) : launch_dma<128, 128, 4, false, 8>(a, st);
+    if (tile == 5) return stem ? launch_dma<128, 64, 4, true, 8>(a, st) : launch_dma<128, 64, 4, false, 8>(a, st);
     if (tile == 1) return stem ? launch_dma<128, 128, 2, true>(a, st) : launch_dma<128, 128, 2, false>(a, st);
     if (tile == 2) return stem ? launch_dma<128, 64, 2, true>(a, st) : launch_dma<128, 64, 2, false>(a, st);
     return stem ? launch_dma<64, 64, 2, true>(a, st) : launch_dma<64, 64, 2, false>(a, st);

@@ -63,7 +63,7 @@ class ConvParams:
 
 #: kernel variants the autotuner may pick: id -> (BM, BN); ids >= 11 stage through LDS-DMA.  All variants
 #: accumulate in the same K order, so they are bit-identical and the choice only affects speed.
-TILE_VARIANTS = {13: (64, 64), 12: (128, 64), 11: (128, 128), 3: (64, 64)}
+TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15: (128, 64), 3: (64, 64)}
 AUTOTUNE = True
 DEFAULT_TILE = 13
 _TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared by every ConvParams object

@@ -38,12 +38,15 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dma", [0, 10])
+@pytest.mark.parametrize("dma", [0, 10, 14, 15])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_generic(hip_lib, dev, case, dma):
     from pemp_amd import ops
     N, H, W, Cin, Cout, k, s, p, d, tile = case
-    tile = tile + dma if tile else (13 if dma else 0)
+    if dma >= 14:                       # 8-wave LDS-DMA blocks: 128x128 (needs Cout % 128 == 0) / 128x64
+        tile = dma if (dma == 15 or Cout % 128 == 0) else 15
+    else:
+        tile = tile + dma if tile else (13 if dma else 0)
     x = _rand(N, Cin, H, W, seed=1)
     w = _rand(Cout, Cin, k, k, seed=2) * (1.0 / (Cin * k * k) ** 0.5)
     scale = _rand(Cout, seed=3, lo=0.5, hi=1.5)
@@ -85,7 +88,7 @@ def test_conv2d_channel_slices_and_per_image_shift(hip_lib, dev):
 
 
 @pytest.mark.parametrize("cin,k,s,p,H", [(3, 7, 2, 3, 97), (3, 3, 1, 1, 33), (4, 7, 2, 3, 50)])
-@pytest.mark.parametrize("tile", [0, 2, 3, 12, 13])
+@pytest.mark.parametrize("tile", [0, 2, 3, 12, 13, 15])
 def test_conv2d_stem4(hip_lib, dev, cin, k, s, p, H, tile):
     from pemp_amd import ops
     N, Cout = 2, 64
