@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PEMP_BENCH_BATCH", "16")),
                     help="episodes per step (the reference evaluates 1 per step)")
     ap.add_argument("--shot", type=int, default=1)
+    ap.add_argument("--model", choices=("stage1", "stage2"), default="stage1",
+                    help="stage1 = headline; stage2 = stage-1 prior + stage-2 (use with --shot 5 for configs[3])")
     ap.add_argument("--mode", choices=("eval", "train"), default="eval",
                     help="eval (headline metric, BASELINE.json configs[1]) or train (configs[2])")
     ap.add_argument("--no-graph", action="store_true")
@@ -234,13 +236,23 @@ def main():
     ws = {}
     stats_log = torch.zeros((args.steps, args.batch, 8), dtype=torch.float64, device=dev)
 
+    stage2 = None
+    if args.model == "stage2":          # BASELINE.json configs[3]: stage-1 prior + stage-2 (ResNet-50 + CM)
+        from pemp_amd.networks import pemp_stage2 as m2
+        from tests import util
+        stage2 = m2.PEMPStage2(args.shot, 1, None)
+        stage2.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+        stage2 = stage2.to(dev).eval()
+
     def step(i, log=True):
         ep = pool[i % len(pool)]
+        ins = (ep["sup_img"], ep["sup_mask"], ep["qry_img"])
         with torch.no_grad():
-            if args.no_graph:
-                pred, _ = net.lowres(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
-            else:
-                pred, _ = net.lowres_graphed(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
+            pred, _ = net.lowres(*ins) if args.no_graph else net.lowres_graphed(*ins)
+            if stage2 is not None:
+                prior, _, _ = ops.eval_tail(pred, None, out_hw=ins[0].shape[-2:], ws_cache=ws)
+                prior = prior.unsqueeze(1).float()
+                pred, _ = stage2.lowres(*ins, prior) if args.no_graph else stage2.lowres_graphed(*ins, prior)
             am, stats, _ = ops.eval_tail(pred, ep["qry_mask"], ws_cache=ws)
         if log:
             stats_log[i].copy_(stats)
@@ -274,16 +286,17 @@ def main():
     if rank == 0:
         eps_total = args.steps * args.batch * world
         out = {
-            "metric": "episodes/sec (PEMP stage-1 eval step, PASCAL-5i-shaped 1-shot, ResNet-50)",
+            "metric": "episodes/sec (PEMP %s eval step, PASCAL-5i-shaped %d-shot, ResNet-50)" % (
+                "stage-1" if stage2 is None else "stage-1 prior + stage-2", args.shot),
             "value": round(eps_total / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "pemp_stage1 eval test_step, ResNet-50, %d-shot, 401x401, %d episode(s)/step, "
-                                   "synthetic E(seed) episodes + Wgen(1234) weights" % (args.shot, args.batch),
+            "config": {"workload": "pemp_%s eval test_step, ResNet-50, %d-shot, 401x401, %d episode(s)/step, "
+                                   "synthetic E(seed) episodes + Wgen(1234) weights" % (args.model, args.shot, args.batch),
                        "episodes_per_step": args.batch, "shot": args.shot, "hipgraph": not args.no_graph,
                        "mean_ce_loss": round(mean_loss, 6)},
         }
-        if not args.no_roofline:
+        if not args.no_roofline and stage2 is None:
             out["roofline"] = conv_roofline(net, pool)
         if world == 1 and args.cpu_episodes > 0:
             out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in sd.items()}, args.shot, args.cpu_episodes)

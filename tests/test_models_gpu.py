@@ -115,3 +115,25 @@ def test_stage2_prior_from_stage1_pipeline(hip_lib, dev):
     g = util.gold("stage2_rn50cm_small")
     ref_prior = np.unpackbits(g["e0_prior_bits"])[: 97 * 97].reshape(1, 97, 97)
     assert (am.cpu().numpy() == ref_prior).mean() > 0.998
+
+
+def test_stage2_evaluator_pipeline_with_graphs(hip_lib, dev):
+    """entry/pemp_stage2 Evaluator: stage-1 prior -> stage 2 -> fused tail, eager vs hipGraph replay."""
+    from pemp_amd.entry import pemp_stage2 as e2
+    from pemp_amd.networks import pemp_stage1 as m1, pemp_stage2 as m2
+    s1 = m1.ModelClass(None)
+    s1.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    s2 = m2.PEMPStage2(1, 1, None)
+    s2.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+    s1, s2 = s1.to(dev).eval(), s2.to(dev).eval()
+    t = util.episode_tensors(3, 1, 97, (80, 120))
+    inputs = (t["sup_img"], t["sup_mask"], t["qry_img"])
+    ev_e = e2.Evaluator(s1, s2, dev, use_graph=False)
+    ev_g = e2.Evaluator(s1, s2, dev, use_graph=True)
+    p_e, l_e = ev_e.test_step(inputs, t["qry_mask"][None])
+    for _ in range(2):                                   # second call replays the captured graphs
+        p_g, l_g = ev_g.test_step(inputs, t["qry_mask"][None])
+    assert p_e.shape == (1, 80, 120) and (p_e == p_g).all() and l_e == l_g
+    g = util.gold("stage2_rn50cm_small")
+    ref_bits = np.unpackbits(g["e0_argmax_bits"])[: p_e.size].reshape(p_e.shape)
+    assert (p_e == ref_bits).mean() > 0.995 and abs(l_e - float(g["e0_loss"])) < 5e-4
