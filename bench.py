@@ -33,9 +33,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PEMP_BENCH_BATCH", "16")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PEMP_BENCH_BATCH", "24")),
                     help="episodes per step (the reference evaluates 1 per step)")
     ap.add_argument("--shot", type=int, default=1)
     ap.add_argument("--model", choices=("stage1", "stage2"), default="stage1",
@@ -115,7 +115,7 @@ def conv_roofline(net, pool, reps=3):
     # command and committed under profiles/.  Reported only when that file matches the batch size.
     traffic = None
     tf = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-    if os.path.exists(tf) and len(pool[0]["seeds"]) == 16:
+    if os.path.exists(tf) and len(pool[0]["seeds"]) == 24:
         with open(tf) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": "conv_dma_kernel + conv_igemm_kernel (all conv launches of a step)",
@@ -213,7 +213,7 @@ def main_train(args, world, rank, dev):
 
 def main():
     args = parse()
-    if args.mode == "train" and args.batch == int(os.environ.get("PEMP_BENCH_BATCH", "16")) and "--batch" not in sys.argv:
+    if args.mode == "train" and args.batch == int(os.environ.get("PEMP_BENCH_BATCH", "24")) and "--batch" not in sys.argv:
         args.batch = 4
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
