@@ -15,7 +15,8 @@ gradient in a second flat buffer of the same layout -- that buffer is the single
 The encoder (99.9 % of the flops) runs entirely on libpemp_hip.so: raw conv -> batch statistics ->
 normalise(+residual)(+ReLU) forward; BN backward -> MFMA wgrad -> dgrad (the forward kernel with
 flipped/transposed weights) backward.  The prototype head (MPM / cosine / upsample / CE; 0.1 % of
-the flops) is evaluated with torch ops on the GPU and differentiated by autograd in this round.
+the flops) runs forward and backward on the HIP head kernels (head.hip, head_bwd.hip); a torch-autograd
+restatement of the head (head_loss) is kept only as the cross-check the tests use.
 """
 import torch
 import torch.distributed as dist
