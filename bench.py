@@ -91,7 +91,21 @@ def conv_roofline(net, pool, reps=3):
         records.append((e0, e1, 2.0 * n * ho * wo * co * p.kh * p.kw * cin_real, nbytes))
         return y
 
+    cos_rec = []
+    orig_cos = ops.cosine_proto_max
+
+    def timed_cos(qry, protos, dist_scalar, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_cos(qry, protos, dist_scalar, **kw)
+        e1.record()
+        b, h, w, c = qry.shape
+        j = protos.shape[1]
+        cos_rec.append((e0, e1, 4.0 * (b * h * w * c + protos.numel() + 2 * b * h * w), 2.0 * b * h * w * c * j))
+        return out
+
     ops.conv2d = timed
+    ops.cosine_proto_max = timed_cos
     import pemp_amd.engine as eng
     eng.ops.conv2d = timed
     try:
@@ -105,6 +119,16 @@ def conv_roofline(net, pool, reps=3):
     finally:
         ops.conv2d = orig
         eng.ops.conv2d = orig
+        ops.cosine_proto_max = orig_cos
+    cos = None
+    if cos_rec:
+        cos_rec = cos_rec[1:] if len(cos_rec) > 1 else cos_rec
+        cms = sum(r[0].elapsed_time(r[1]) for r in cos_rec)
+        gbs = sum(r[2] for r in cos_rec) / (cms * 1e-3) / 1e9
+        cos = {"bound": "hbm", "kernel": "cosine_mfma_kernel (pixel x prototype cosine, MFMA outer product)",
+               "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+               "avg_launch_us": round(cms * 1e3 / len(cos_rec), 2),
+               "useful_mfma_tflops": round(sum(r[3] for r in cos_rec) / (cms * 1e-3) / 1e12, 3)}
     ms = sum(r[0].elapsed_time(r[1]) for r in records)
     flops = sum(r[2] for r in records)
     abytes = sum(r[3] for r in records)
@@ -123,7 +147,8 @@ def conv_roofline(net, pool, reps=3):
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(abytes / n),
             "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
-            "gflop_per_step": round(flops / reps / 1e9, 2), "conv_ms_per_step": round(ms / reps, 4)}
+            "gflop_per_step": round(flops / reps / 1e9, 2), "conv_ms_per_step": round(ms / reps, 4),
+            "cosine_kernel": cos}
 
 
 def cpu_baseline(sd, shot, n_eps):

@@ -5,6 +5,7 @@
 // All of these are streaming kernels over [pixels][c] feature maps (c contiguous): their bound
 // is HBM/L2 bandwidth (AI ~ 3 flop/B at 2p = 6 prototypes), so the design is wave-per-pixel
 // coalesced 16-B loads + wavefront shuffles, partial sums in a fixed order (deterministic).
+#include <stdlib.h>
 #include "head_common.h"
 
 namespace pemp {
@@ -220,7 +221,97 @@ __global__ __launch_bounds__(64) void pool_final_kernel(const float* __restrict_
 }
 
 // -----------------------------------------------------------------------------------------------
-// cosine map + group max (networks/pemp_stage1.py:214-222,256-260), one wave per query pixel.
+// cosine map as an MFMA outer product with fused L2 normalisation (networks/pemp_stage1.py:214-222,
+// 256-260).  One wave owns 32 query pixels: D[32 px][32 cols] += X[32 px][k] * Pn[k][32 cols] on
+// v_mfma_f32_32x32x2_f32, columns 0..2p-1 = the L2-normalised prototypes (rows of an LDS table; the
+// remaining columns read an all-zero row).  Lane (r = l&31, h = l>>5) streams its pixel's row straight
+// from HBM: float4 #h of every 8-float chunk feeds four MFMAs (k = {8t+e, 8t+4+e}), the prototype
+// side reads the same positions from LDS; |x|^2 accumulates on the VALU from the very same registers.
+// The epilogue divides by max(|x|, 1e-8), scales, and takes the group maxima / response index.
+typedef __attribute__((ext_vector_type(16))) float hf32x16;
+typedef __attribute__((ext_vector_type(4))) float hv4f;
+
+__global__ __launch_bounds__(256) void cosine_mfma_kernel(const float* __restrict__ qry, int ldf,
+                                                          const float* __restrict__ protos, float* __restrict__ pred,
+                                                          uint8_t* __restrict__ resp, int n, int c, int p,
+                                                          float scalar) {
+    extern __shared__ __attribute__((aligned(16))) float pnl[];      // [(2p + 1)][c], last row = zeros
+    __shared__ float nrm[MAXJ];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int J = 2 * p;
+    const float* pb = protos + (size_t)b * J * c;
+    for (int j = wave; j < J; j += 4) {
+        float s = 0.f;
+        for (int ch = lane; ch < c; ch += 64) {
+            float v = pb[(size_t)j * c + ch];
+            s += v * v;
+        }
+        s = wave_sum(s);
+        if (lane == 0) nrm[j] = fmaxf(sqrtf(s), 1e-8f);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < (J + 1) * c; t += 256) {
+        int j = t / c;
+        pnl[t] = j < J ? pb[t] / nrm[j] : 0.f;
+    }
+    __syncthreads();
+    const int tile = blockIdx.x * 4 + wave;
+    const int i0 = tile * 32;
+    if (i0 >= n) return;
+    const int r = lane & 31, h = lane >> 5;
+    const int pix = min(i0 + r, n - 1);
+    const float* xp = qry + ((size_t)b * n + pix) * ldf + 4 * h;
+    const float* bp = pnl + (size_t)min(r, J) * c + 4 * h;           // column r (zero row beyond 2p)
+    hf32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float ss = 0.f;
+    const int nchunk = c / 8;
+    hv4f xv = *(const hv4f*)xp;
+    for (int t = 0; t < nchunk; ++t) {
+        const hv4f xn = t + 1 < nchunk ? *(const hv4f*)(xp + (t + 1) * 8) : xv;   // prefetch next chunk
+        const hv4f pv = *(const hv4f*)(bp + t * 8);
+        ss += (xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.x, pv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.y, pv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.z, pv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.w, pv.w, acc, 0, 0, 0);
+        xv = xn;
+    }
+    ss += __shfl_xor(ss, 32, 64);                                    // both k-halves of the pixel's row
+    const float inv = scalar / fmaxf(sqrtf(ss), 1e-8f);               // lane l holds pixel (l & 31)'s factor
+    // D[i][j]: column j = lane & 31, row i = (e&3) + 8*(e>>2) + 4*h.  Columns 0..2p-1 of a row live in
+    // lanes 32h + 0..2p-1: gather them into lane 32h (column 0).
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float f = __shfl(inv, row, 64);
+        float v[MAXJ];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) v[j] = __shfl(acc[e], 32 * h + j, 64) * f;
+        if (r == 0 && i0 + row < n) {
+            float best[2];
+            int bi[2];
+            for (int g = 0; g < 2; ++g) {      // g = 0: fg rows [0,p), g = 1: bg rows [p,2p)
+                best[g] = v[g * p];
+                bi[g] = 0;
+                for (int j = 1; j < p; ++j)
+                    if (v[g * p + j] > best[g]) {
+                        best[g] = v[g * p + j];
+                        bi[g] = j;
+                    }
+            }
+            const int i = i0 + row;
+            pred[((size_t)b * 2 + 0) * n + i] = best[1];
+            pred[((size_t)b * 2 + 1) * n + i] = best[0];
+            if (resp) resp[(size_t)b * n + i] = (uint8_t)(best[0] > best[1] ? bi[0] + 3 : bi[1]);
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------
+// cosine map + group max, VALU variant (c not a multiple of 8, or PEMP_COSINE_VALU set): one wave per query pixel.
 // torch>=2 F.cosine_similarity: each vector is divided by max(||.||, 1e-8), then dotted.
 __global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ qry, int ldf,
                                                      const float* __restrict__ protos, float* __restrict__ pred,
@@ -463,6 +554,14 @@ extern "C" int pemp_cosine_proto_max_f32(const float* qry, int ldf, const float*
     PEMP_REQUIRE(B > 0 && n > 0 && p >= 1 && 2 * p <= MAXJ, "cosine: bad dims");
     PEMP_REQUIRE(c > 0 && c % 4 == 0 && c <= 64 * MAXCL && ldf >= c && ldf % 4 == 0, "cosine: c=%d must be a multiple of 4 and <= %d", c, 64 * MAXCL);
     PEMP_REQUIRE(((uintptr_t)qry & 15) == 0, "cosine: qry must be 16-byte aligned");
+    static const bool force_valu = getenv("PEMP_COSINE_VALU") != nullptr;     // A/B switch for measurements
+    if (c % 8 == 0 && !force_valu) {
+        // MFMA outer product: 32 query pixels x (2p prototypes padded to 32 columns) per wave
+        const size_t lds = (size_t)(2 * p + 1) * c * sizeof(float);
+        hipLaunchKernelGGL(cosine_mfma_kernel, dim3(cdiv(cdiv(n, 32), 4), B), dim3(256), lds, (hipStream_t)stream, qry, ldf,
+                           protos, pred, resp, n, c, p, dist_scalar);
+        return launch_status("cosine_mfma");
+    }
     hipLaunchKernelGGL(cosine_kernel, dim3(min(cdiv(n, 4), max(1, 4096 / B)), B), dim3(256), 0, (hipStream_t)stream, qry, ldf, protos,
                        pred, resp, n, c, p, dist_scalar);
     return launch_status("cosine");
