@@ -30,6 +30,57 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int nblk) {
     return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
 }
 
+// Wave-level epilogue through LDS.  The 32x32 accumulator tile sits "column per lane" (lane = channel,
+// 16 registers = pixels), which would mean 16 scalar residual loads + 16 scalar stores per lane.  Each
+// wave transposes its tile through a private 4 KB LDS patch so that a lane owns 4 consecutive channels
+// of one pixel: float4 residual loads and float4 stores, 8 lanes = one 128-B row segment.  Same
+// arithmetic, in the same order, as the scalar form:  v = acc * scale + (shift (+ per-image) (+ res)).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
+                                                  int n_base, int lane) {
+    const bool relu = a.flags & PEMP_CONV_RELU;
+    const bool per_img = a.flags & PEMP_CONV_SHIFT_PER_IMAGE;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = n_base + ni * 32 + c4;
+        v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale) sc = *(const v4f*)(a.scale + n);
+        if (a.shift && !per_img) sh = *(const v4f*)(a.shift + n);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + lr] = acc[mi][ni][e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's writes have landed (DS is in-order per wave)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rr + 8 * i;
+                const int m = m_base + mi * 32 + row;
+                const v4f v = *(const v4f*)(S + row * 32 + c4);
+                if (m < a.M) {
+                    v4f add = sh;
+                    if (per_img) add += *(const v4f*)(a.shift + (size_t)(m / a.HoWo) * a.Cout + n);
+                    if (a.res) add += *(const v4f*)(a.res + (size_t)m * a.ldr + n);
+                    v4f o;
+                    o.x = v.x * sc.x + add.x;
+                    o.y = v.y * sc.y + add.y;
+                    o.z = v.z * sc.z + add.z;
+                    o.w = v.w * sc.w + add.w;
+                    if (relu) {
+                        o.x = fmaxf(o.x, 0.f);
+                        o.y = fmaxf(o.y, 0.f);
+                        o.z = fmaxf(o.z, 0.f);
+                        o.w = fmaxf(o.w, 0.f);
+                    }
+                    *(v4f*)(a.y + (size_t)m * a.ldy + n) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the patch is rewritten
+        }
+    }
+}
+
 // conv_dma.hip
 int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st);
 

@@ -208,46 +208,8 @@ __global__ __launch_bounds__(NW * 64) void conv_dma_kernel(ConvArgs a) {
 #undef PEMP_ADVANCE
 #undef PEMP_SET_TAP
 
-    // ---- epilogue (identical to conv_igemm.hip) ----
-    const bool relu = a.flags & PEMP_CONV_RELU;
-    const bool per_img = a.flags & PEMP_CONV_SHIFT_PER_IMAGE;
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int n = n0 + wn0 + ni * 32 + lr;
-        const float sc = a.scale ? a.scale[n] : 1.f;
-        const float sh = (a.shift && !per_img) ? a.shift[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const int mb = m0 + wm0 + mi * 32 + 4 * lh;
-            float add[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) add[e] = sh;
-            if (per_img) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int mc = min(mb + (e & 3) + 8 * (e >> 2), a.M - 1);
-                    add[e] += a.shift[(size_t)(mc / a.HoWo) * a.Cout + n];
-                }
-            }
-            if (a.res) {
-                float rv[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int mc = min(mb + (e & 3) + 8 * (e >> 2), a.M - 1);
-                    rv[e] = a.res[(size_t)mc * a.ldr + n];
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) add[e] += rv[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                float v = acc[mi][ni][e] * sc + add[e];
-                if (relu) v = fmaxf(v, 0.f);
-                if (m < a.M) a.y[(size_t)m * a.ldy + n] = v;
-            }
-        }
-    }
+    // ---- epilogue: transpose through LDS (staging buffers are free after the loop's last barrier) ----
+    conv_epilogue_lds<TM, TN>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
 }
 
 template <int BM, int BN, int WGM, bool STEM, int NW = 4>

@@ -220,46 +220,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #undef PEMP_SET_TAP
 #undef PEMP_LSTORE
 
-    // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel) ----
-    const bool relu = a.flags & PEMP_CONV_RELU;
-    const bool per_img = a.flags & PEMP_CONV_SHIFT_PER_IMAGE;
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int n = n0 + wn0 + ni * 32 + lr;
-        const float sc = a.scale ? a.scale[n] : 1.f;
-        const float sh = (a.shift && !per_img) ? a.shift[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const int mb = m0 + wm0 + mi * 32 + 4 * lh;
-            float add[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) add[e] = sh;
-            if (per_img) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int mc = min(mb + (e & 3) + 8 * (e >> 2), a.M - 1);
-                    add[e] += a.shift[(size_t)(mc / a.HoWo) * a.Cout + n];
-                }
-            }
-            if (a.res) {   // all 16 residual loads are independent and in flight together
-                float rv[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int mc = min(mb + (e & 3) + 8 * (e >> 2), a.M - 1);
-                    rv[e] = a.res[(size_t)mc * a.ldr + n];
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) add[e] += rv[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                float v = acc[mi][ni][e] * sc + add[e];
-                if (relu) v = fmaxf(v, 0.f);
-                if (m < a.M) a.y[(size_t)m * a.ldy + n] = v;
-            }
-        }
-    }
+    // ---- epilogue: transpose through LDS (staging buffers are free after the loop's last barrier) ----
+    conv_epilogue_lds<TM, TN>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
 }
 
 template <int BM, int BN, int WGM, bool STEM>
@@ -292,7 +254,9 @@ extern "C" int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, con
     const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
     PEMP_REQUIRE(ho == d->Ho && wo == d->Wo, "conv2d: Ho/Wo (%d,%d) do not match geometry (%d,%d)", d->Ho, d->Wo, ho, wo);
     PEMP_REQUIRE(d->Cout % 64 == 0, "conv2d: Cout=%d must be a multiple of 64", d->Cout);
-    PEMP_REQUIRE(d->ldy >= d->Cout, "conv2d: ldy < Cout");
+    PEMP_REQUIRE(d->ldy >= d->Cout && d->ldy % 4 == 0 && ((uintptr_t)y & 15) == 0, "conv2d: ldy must be >= Cout and a multiple of 4, y 16-byte aligned");
+    PEMP_REQUIRE(!scale || ((uintptr_t)scale & 15) == 0, "conv2d: scale must be 16-byte aligned");
+    PEMP_REQUIRE(!shift || ((uintptr_t)shift & 15) == 0, "conv2d: shift must be 16-byte aligned");
     PEMP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "conv2d: x/w must be 16-byte aligned");
     const bool stem = d->flags & PEMP_CONV_STEM4;
     const int ntaps = d->KH * d->KW;
@@ -318,7 +282,7 @@ extern "C" int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, con
     a.ntaps = ntaps;
     a.cin_steps = stem ? 1 : d->Cin / 32;
     a.nk = d->Kpad / 32;
-    if (residual) PEMP_REQUIRE(d->ldr >= d->Cout, "conv2d: ldr < Cout");
+    if (residual) PEMP_REQUIRE(d->ldr >= d->Cout && d->ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0, "conv2d: ldr must be >= Cout and x4, residual 16-byte aligned");
 
     int tile = d->tile;
     if (tile == 0) {
