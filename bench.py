@@ -192,7 +192,7 @@ def main_train(args, world, rank, dev):
     from tests import util
     net = m.ModelClass(None)
     net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
-    tr = Stage1Trainer(net, device=dev)
+    tr = Stage1Trainer(net, device=dev, use_graph=not args.no_graph)
     B = args.batch
     pool = []
     for g in range(3):

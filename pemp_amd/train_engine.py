@@ -59,6 +59,30 @@ class FlatParams:
                 p.data = self.data[o:o + p.numel()].view(p.shape)
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
+    def build_dgrad_mirror(self):
+        """One int32 permutation that turns the flat parameter buffer into a second buffer holding, for every
+        conv weight, the KRSC weight of its input-gradient conv ([Cin, KH*KW*Cout], taps flipped).  Refreshing the
+        mirror is then ONE gather per step instead of a transpose per layer."""
+        idx = torch.arange(self.n, dtype=torch.int32, device=self.data.device)
+        perm = idx.clone()
+        self.dg_view = {}
+        for p, o in zip(self.params, self.offs):
+            if p.dim() != 4:
+                continue
+            co, ci, kh, kw = p.shape
+            src = idx[o:o + p.numel()].view(co, kh * kw * ci)
+            perm[o:o + p.numel()] = T.dgrad_weight(src, kh, kw).reshape(-1)
+            self.dg_view[id(p)] = (o, ci, kh * kw * co)
+        self.dg_perm = perm
+        self.dg_data = torch.empty_like(self.data)
+
+    def refresh_dgrad_mirror(self):
+        torch.index_select(self.data, 0, self.dg_perm, out=self.dg_data)
+
+    def dgrad_krsc(self, p):
+        o, rows, cols = self.dg_view[id(p)]
+        return self.dg_data[o:o + rows * cols].view(rows, cols)
+
     def krsc(self, p):
         """[Cout, KH*KW*Cin] KRSC matrix view of a conv weight (no copy)."""
         co, ci, kh, kw = p.shape
@@ -95,7 +119,7 @@ class _Conv:
                           self.stem, relu)
 
     def dgrad_params(self):
-        wd = T.dgrad_weight(self.flat.krsc(self.conv.weight), self.kh, self.kw)
+        wd = self.flat.dgrad_krsc(self.conv.weight)          # refreshed once per step by the engine
         return ConvParams(wd, None, None, self.cout, self.cin, self.kh, self.kw, 1, self.dil * (self.kh - 1) - self.pad,
                           self.dil, wd.shape[1], False, False)
 
@@ -119,7 +143,6 @@ class _BN:
         self.bn = bn
 
     def stats(self, z, ws):
-        self.bn.num_batches_tracked += 1
         return T.bn_stats(z, self.bn.eps, BN_MOM, self.bn.running_mean, self.bn.running_var, ws_cache=ws)
 
     def write_grads(self, dgamma, dbeta):
@@ -176,6 +199,8 @@ class Stage1TrainEngine:
         self.midc = self.aspp_conv[0].cout
         self.ws = {}
         self.drop_rate, self.block_size = 0.0, 4
+        self.flat.build_dgrad_mirror()
+        self.bn_counters = [m.num_batches_tracked for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
 
     # -- helpers ------------------------------------------------------------------------------
     def _new(self, *shape):
@@ -202,6 +227,8 @@ class Stage1TrainEngine:
     def forward(self, images_list):
         """images_list: [n_i,3,H,W] tensors -> NHWC features; keeps what backward needs in self.tape."""
         tape = {}
+        torch._foreach_add_(self.bn_counters, 1)            # every BatchNorm runs exactly once per step
+        self.flat.refresh_dgrad_mirror()
         n = sum(t.shape[0] for t in images_list)
         H, W = images_list[0].shape[-2:]
         x4 = self._new(n, H, W, 4)
@@ -403,7 +430,7 @@ class Stage1Trainer:
     clip_grad_norm_(1.1), SGD step; returns the loss tensor (entry/pemp_stage1.py:57-65)."""
 
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.1, device=None,
-                 drop_rate=None, block_size=None, loss="ce", sigma=5.0):
+                 drop_rate=None, block_size=None, loss="ce", sigma=5.0, use_graph=False):
         from .networks.pemp_stage1 import net_ingredient
         cfg = net_ingredient.cfg
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -416,6 +443,8 @@ class Stage1Trainer:
         self.protos = 0 if model.ctr is None else model.ctr.shape[1] // 2
         self.dist_scalar = cfg["dist_scalar"]
         self.last_grad_norm = None
+        self.use_graph = use_graph
+        self._graphs = {}
         from .core import losses
         self.loss_obj = losses.get({"loss": loss, "sigma": sigma})
 
@@ -475,10 +504,33 @@ class Stage1Trainer:
         return loss.float(), pred
 
     def train_step(self, sup_img, sup_mask, qry_img, qry_msk=None):
-        loss, _ = self.forward_backward(sup_img.to(self.device), sup_mask.to(self.device), qry_img.to(self.device),
-                                        qry_msk.to(self.device))
+        ins = (sup_img.to(self.device), sup_mask.to(self.device), qry_img.to(self.device), qry_msk.to(self.device))
+        loss = self._graphed_forward_backward(*ins) if self.use_graph else self.forward_backward(*ins)[0]
         self.optimizer_step()
         return loss
+
+    def _graphed_forward_backward(self, *ins):
+        """forward + backward (~450 short launches) replayed from a hipGraph per input signature; the first two
+        calls run eagerly (they populate workspaces and the conv autotune cache).  The optimizer (all-reduce +
+        fused clip/SGD) stays outside the graph."""
+        key = tuple((tuple(t.shape), t.dtype) for t in ins)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = {"calls": 0}
+        if "graph" not in ent:
+            ent["calls"] += 1
+            if ent["calls"] <= 2:
+                return self.forward_backward(*ins)[0]
+            static = [t.clone() for t in ins]
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, _ = self.forward_backward(*static)
+            ent.update(graph=g, static=static, loss=loss)
+        for s_, t in zip(ent["static"], ins):
+            s_.copy_(t, non_blocking=True)
+        ent["graph"].replay()
+        return ent["loss"]
 
     def optimizer_step(self):
         f = self.eng.flat
