@@ -209,7 +209,8 @@ int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, int ldf, con
                       const int64_t* target, const float* weight /* NULL or [B][Ho][Wo] */,
                       const double* stats, float* dsup, float* dqry, int ldd,
                       float* dctr, void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W,
-                      int Ho, int Wo, int c, int p, float dist_scalar, void* stream);
+                      int Ho, int Wo, int c, int p, int map_full_res /* Baseline: fwd_ws from full_res=1 */,
+                      float dist_scalar, void* stream);
 
 /* nn.utils.clip_grad_norm_(params, max_norm) + SGD(momentum, weight_decay).step() on flat buffers
  * (entry/pemp_stage1.py:63-64, core/solver.py:87-91).  grad_scale multiplies the gradients first
@@ -217,7 +218,8 @@ int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, int ldf, con
 size_t pemp_sgd_workspace_bytes(void);
 int pemp_sgd_clip_step_f32(float* params, const float* grads, float* momentum_buf, long long n,
                            float max_norm, float lr, float momentum, float weight_decay, int first_step,
-                           float grad_scale, float* grad_norm_out, void* ws, size_t ws_bytes, void* stream);
+                           float grad_scale, int nesterov, float* grad_norm_out, void* ws, size_t ws_bytes,
+                           void* stream);
 
 #ifdef __cplusplus
 }

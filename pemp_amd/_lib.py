@@ -66,13 +66,13 @@ SYMBOLS = {
     "pemp_gap_bwd_add_nhwc_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "pemp_head_bwd_workspace_bytes": (c_size, [c_int] * 5),
     "pemp_head_bwd_f32": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int,
-                                  c_fp, c_fp, c_size] + [c_int] * 10 + [C.c_float, c_fp]),
+                                  c_fp, c_fp, c_size] + [c_int] * 11 + [C.c_float, c_fp]),
     "pemp_eval_tail_weighted_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size] + [c_int] * 5 + [c_fp]),
     "pemp_cedt_workspace_bytes": (c_size, [c_int] * 3),
     "pemp_cedt_weight_f32": (c_int, [c_fp, c_fp, c_fp, c_size, c_int, c_int, c_int, C.c_float, c_fp]),
     "pemp_sgd_workspace_bytes": (c_size, []),
     "pemp_sgd_clip_step_f32": (c_int, [c_fp, c_fp, c_fp, C.c_longlong, C.c_float, C.c_float, C.c_float,
-                                       C.c_float, c_int, C.c_float, c_fp, c_fp, c_size, c_fp]),
+                                       C.c_float, c_int, C.c_float, c_int, c_fp, c_fp, c_size, c_fp]),
 }
 
 _lib = None

@@ -14,11 +14,13 @@ namespace pemp {
 // -----------------------------------------------------------------------------------------------
 // per-shot prototypes from the forward workspace:  Pps[bs][j][c] = N/D,  Dps[bs][j] = D
 __global__ __launch_bounds__(64) void pool_shot_kernel(const float* __restrict__ part, const float* __restrict__ asum,
+                                                       const float* __restrict__ den_override,
                                                        float* __restrict__ Pps, float* __restrict__ Dps, int c, int J,
                                                        int nchunks, float eps) {
     const int bs = blockIdx.y, j = blockIdx.x;
     float den = 0.f;
     for (int k = 0; k < nchunks; ++k) den += asum[((size_t)bs * nchunks + k) * J + j];
+    if (den_override) den = den_override[bs * J + j];      // Baseline: exact full-resolution mask sums
     den += eps;
     for (int ch = blockIdx.z * 64 + threadIdx.x; ch < c; ch += gridDim.z * 64) {
         float num = 0.f;
@@ -244,10 +246,13 @@ __global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, int
 //   dN_j = dP_j / (S D_sj),  dD_j = -(dP_j . P_sj) / (S D_sj),  da_ij = x_i . dN_j + dD_j
 //   dsig_ij = da_ij m_g(i),  dd_ij = sig_ij (dsig_ij - sum_{k in g} sig_ik dsig_ik)
 //   dx_i = sum_j a_ij dN_j - 2 sum_j dd_ij (x_i - ctr_j),   dctr_j += 2 sum_i dd_ij (x_i - ctr_j)
-// MAP mode (p == 0 on entry -> J = 2, a = mask): dx_i = sum_g m_g(i) dN_g.
+// MAP mode (p == 0 on entry -> J = 2): a = mask at feature resolution, or, for the Baseline's pooling over
+// up-sampled features, the adjoint weights Aext[bs][g][i] the forward left in its workspace:
+// dx_i = sum_g a_g(i) dN_g.
 template <bool MPM>
 __global__ __launch_bounds__(256) void mpm_bwd_kernel(const float* __restrict__ feat, int ldf,
-                                                      const float* __restrict__ mask, const float* __restrict__ ctr,
+                                                      const float* __restrict__ mask, const float* __restrict__ Aext,
+                                                      const float* __restrict__ ctr,
                                                       const float* __restrict__ dP, const float* __restrict__ Pps,
                                                       const float* __restrict__ Dps, float* __restrict__ dsup, int ldd,
                                                       float* __restrict__ part, int S, int n, int h, int w, int H, int W,
@@ -371,6 +376,9 @@ __global__ __launch_bounds__(256) void mpm_bwd_kernel(const float* __restrict__ 
                     dd[g * p + j] = sg[j] * (ds[j] - dot);
                 }
             }
+        } else if (Aext) {
+            a[0] = Aext[((size_t)bs * 2 + 0) * n + i];
+            a[1] = Aext[((size_t)bs * 2 + 1) * n + i];
         } else {
             a[0] = mg[0];
             a[1] = mg[1];
@@ -456,13 +464,14 @@ extern "C" int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, i
                                  const int64_t* target, const float* weight, const double* stats, float* dsup,
                                  float* dqry, int ldd,
                                  float* dctr, void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W,
-                                 int Ho, int Wo, int c, int p, float dist_scalar, void* stream) {
+                                 int Ho, int Wo, int c, int p, int map_full_res, float dist_scalar, void* stream) {
     PEMP_REQUIRE(sup_feat && qry_feat && mask && fwd_ws && protos && pred && target && stats && dsup && dqry && ws,
                  "head_bwd: null pointer");
     PEMP_REQUIRE(B > 0 && S > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && p >= 0 && 2 * p <= MAXJ, "head_bwd: bad dims");
     PEMP_REQUIRE(c > 0 && c % 4 == 0 && c <= 64 * MAXCL && ldf >= c && ldd >= c && ldf % 4 == 0 && ldd % 4 == 0,
                  "head_bwd: c=%d must be a multiple of 4 and <= %d", c, 64 * MAXCL);
     PEMP_REQUIRE(p == 0 || (ctr && dctr), "head_bwd: ctr/dctr required when p > 0");
+    PEMP_REQUIRE(!map_full_res || p == 0, "head_bwd: map_full_res is the Baseline's plain-MAP head (p == 0)");
     const int n = h * w, BS = B * S, J = p > 0 ? 2 * p : 2;
     PEMP_REQUIRE(ws_bytes >= head_bwd_floats(B, S, n, c, J) * sizeof(float), "head_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -475,7 +484,8 @@ extern "C" int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, i
     float* mpart = cpart + (size_t)B * HB_BLOCKS * J * c;
     const int nck = nchunks_of(n);
     hipLaunchKernelGGL(pool_shot_kernel, dim3(J, BS, cdiv(c, 64)), dim3(64), 0, st, (const float*)L.part,
-                       (const float*)L.asum, Pps, Dps, c, J, nck, p > 0 ? 1e-6f : 1e-5f);
+                       (const float*)L.asum, map_full_res ? (const float*)L.msum : (const float*)nullptr, Pps, Dps, c, J,
+                       nck, p > 0 ? 1e-6f : 1e-5f);
     hipLaunchKernelGGL(ce_upsample_bwd_kernel, dim3(cdiv(n, 128), B), dim3(128), 0, st, pred, target, weight, stats, B,
                        dpred, h, w, Ho, Wo);
     hipLaunchKernelGGL(cosine_bwd_kernel, dim3(HB_BLOCKS, B), dim3(256), 0, st, qry_feat, ldf, protos, (const float*)dpred,
@@ -485,12 +495,14 @@ extern "C" int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, i
     int e = launch_status("head_bwd/cosine");
     if (e) return e;
     if (p > 0) {
-        hipLaunchKernelGGL(mpm_bwd_kernel<true>, dim3(HB_BLOCKS, BS), dim3(256), 0, st, sup_feat, ldf, mask, ctr,
+        hipLaunchKernelGGL(mpm_bwd_kernel<true>, dim3(HB_BLOCKS, BS), dim3(256), 0, st, sup_feat, ldf, mask,
+                           (const float*)nullptr, ctr,
                            (const float*)dP, (const float*)Pps, (const float*)Dps, dsup, ldd, mpart, S, n, h, w, H, W, c, p);
         hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(J * c, 256), 1), dim3(256), 0, st, (const float*)mpart,
                            BS * HB_BLOCKS, J * c, dctr, J);
     } else {
-        hipLaunchKernelGGL(mpm_bwd_kernel<false>, dim3(HB_BLOCKS, BS), dim3(256), 0, st, sup_feat, ldf, mask, ctr,
+        hipLaunchKernelGGL(mpm_bwd_kernel<false>, dim3(HB_BLOCKS, BS), dim3(256), 0, st, sup_feat, ldf, mask,
+                           map_full_res ? (const float*)L.A : (const float*)nullptr, ctr,
                            (const float*)dP, (const float*)Pps, (const float*)Dps, dsup, ldd, mpart, S, n, h, w, H, W, c, 1);
     }
     return launch_status("head_bwd/mpm");

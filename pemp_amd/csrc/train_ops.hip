@@ -342,7 +342,7 @@ __global__ void sqsum_final_kernel(const double* __restrict__ part, int nb, floa
 // torch.nn.utils.clip_grad_norm_ + torch.optim.SGD (momentum, weight decay, no nesterov) in one pass
 __global__ void sgd_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                 long long n, const float* __restrict__ norm, float max_norm, float lr, float mom,
-                                float wd, int first_step, float grad_scale) {
+                                float wd, int first_step, float grad_scale, int nesterov) {
     float coef = 1.f;
     if (max_norm > 0.f) coef = fminf(max_norm / (norm[0] * grad_scale + 1e-6f), 1.f);
     coef *= grad_scale;
@@ -351,7 +351,7 @@ __global__ void sgd_clip_kernel(float* __restrict__ p, const float* __restrict__
         float d = g[i] * coef + wd * w;
         const float b = first_step ? d : mom * buf[i] + d;
         buf[i] = b;
-        p[i] = w - lr * b;
+        p[i] = w - lr * (nesterov ? d + mom * b : b);
     }
 }
 
@@ -482,7 +482,8 @@ extern "C" size_t pemp_sgd_workspace_bytes(void) { return 1024 * sizeof(double) 
 // multiplies every gradient first (1/world after a SUM all-reduce).
 extern "C" int pemp_sgd_clip_step_f32(float* params, const float* grads, float* momentum_buf, long long n,
                                       float max_norm, float lr, float momentum, float weight_decay, int first_step,
-                                      float grad_scale, float* grad_norm_out, void* ws, size_t ws_bytes, void* stream) {
+                                      float grad_scale, int nesterov, float* grad_norm_out, void* ws, size_t ws_bytes,
+                                      void* stream) {
     PEMP_REQUIRE(params && grads && momentum_buf && grad_norm_out && ws && n > 0, "sgd_clip_step: bad arguments");
     PEMP_REQUIRE(ws_bytes >= pemp_sgd_workspace_bytes(), "sgd_clip_step: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -490,6 +491,6 @@ extern "C" int pemp_sgd_clip_step_f32(float* params, const float* grads, float* 
     hipLaunchKernelGGL(sqsum_partial_kernel, dim3(nb), dim3(256), 0, st, grads, n, (double*)ws);
     hipLaunchKernelGGL(sqsum_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, grad_norm_out);
     hipLaunchKernelGGL(sgd_clip_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, params, grads, momentum_buf, n,
-                       (const float*)grad_norm_out, max_norm, lr, momentum, weight_decay, first_step, grad_scale);
+                       (const float*)grad_norm_out, max_norm, lr, momentum, weight_decay, first_step, grad_scale, nesterov);
     return launch_status("sgd_clip_step");
 }

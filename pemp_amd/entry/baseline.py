@@ -1,0 +1,44 @@
+"""Evaluation harness of the Baseline model on MI355X (counterpart of the reference's entry/baseline.py:46-51,
+BASELINE.json configs[0]: baseline, VGG-16, PASCAL-5i 1-shot).  Same loop, sharding and fused tail as
+stage 1; the model is ``pemp_amd.networks.baseline.Baseline`` (full-resolution masked average pooling
+through the adjoint of the bilinear upsample)."""
+from ..config import Experiment
+from ..networks.baseline import ModelClass, net_ingredient  # noqa: F401
+from .pemp_stage1 import Evaluator, SyntheticEpisodes, get_val_labels  # noqa: F401
+
+NAME = "Baseline"
+ex = Experiment(name=NAME, ingredients=[net_ingredient])
+
+
+@ex.config
+def ex_config():
+    tag = "baseline"            # str, configuration tag
+    shot = 1                    # int, support samples per episode
+    query = 1                   # int, query samples per episode
+    split = -1                  # int, split number [0, 1, 2, 3], required
+    seed = 1234                 # int, random seed
+    ckpt = "bestckpt.pth"       # str, checkpoint file
+    exp_id = -1                 # experiment id to load checkpoint
+    loss = "ce"                 # str, loss type [ce/cedt]
+    sigma = 5.                  # float, sigma of the DT loss
+    test_n = 1000               # int, episodes per evaluation round
+    test_seed = 5678            # int, evaluation sampler seed
+    te_epochs = 5               # int, evaluation rounds
+
+
+@ex.command
+def test(_config, split, shot, test_n, test_seed, te_epochs):
+    import logging
+    import numpy as np
+    logging.basicConfig(level=logging.INFO, format="%(message)s")
+    logger = logging.getLogger(NAME)
+    if split < 0:
+        raise ValueError("Argument `split` is required! For example: `python -m pemp_amd.entry.baseline test with split=0`")
+    model = ModelClass(logger).cuda().eval()
+    ev = Evaluator(model)
+    loss, miou, biou = ev.start_eval_loop(SyntheticEpisodes(test_n, test_seed, shot, split), 20, split, te_epochs, logger)
+    return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
+
+
+if __name__ == "__main__":
+    print(ex.run_commandline())

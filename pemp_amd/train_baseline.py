@@ -1,0 +1,124 @@
+"""Training step of the Baseline model (VGG-16 or ResNet-50 + projection) on MI355X: counterpart of
+``Trainer.train_step`` in the reference's entry/baseline.py:54-62 (no gradient clipping there) for
+``networks/baseline.py``.  Reuses the flat-buffer machinery, the conv/BN forward-backward helpers and
+the optimizer of ``pemp_amd.train_engine``; only the trunk (VGG chain) and the head (masked average
+pooling over bilinearly up-sampled features, done through its adjoint) differ.
+"""
+import torch
+
+from . import ops, train_ops as T
+from .train_engine import Stage1TrainEngine, Stage1Trainer, _Conv
+
+
+class _ResNetProjectionEngine(Stage1TrainEngine):
+    """ResNet trunk of stage 1 + ``encoder.projection`` (1x1, 1024 -> out_channels, bias, no ReLU)."""
+
+    def _init_tail(self, model):
+        self.proj = _Conv(self.flat, model.encoder.projection)
+
+    def _tail_forward(self, x, tape):
+        tape["proj_in"] = x
+        return ops.conv2d(x, self.proj.fwd_params(relu=False))
+
+    def _tail_backward(self, dfeat):
+        x = self.tape["proj_in"]
+        g = torch.empty_like(dfeat)
+        self.proj.conv.bias.grad.copy_(T.relu_bias_bwd(dfeat, None, g, relu=False, ws_cache=self.ws))
+        self.proj.wgrad(x, g, self.ws)
+        return ops.conv2d(g, self.proj.dgrad_params())
+
+
+class _VGGEngine(Stage1TrainEngine):
+    """VGG16 chain: 3x3 conv + bias (+ ReLU), four max pools (reference networks/backbones.py:372-405)."""
+
+    def _init_trunk(self, bb):
+        from .networks.backbones import VGG_LAYOUT
+        self.steps = []
+        for item in VGG_LAYOUT:
+            if isinstance(item, tuple):
+                idx, _, _, _, relu = item
+                self.steps.append(("conv", _Conv(self.flat, bb.features[idx], stem=(idx == 0)), relu or bb.last_relu))
+            else:
+                self.steps.append(("pool", item, None))
+
+    def _init_tail(self, model):
+        pass
+
+    def _trunk_forward(self, images_list, tape):
+        x = self._pack(images_list)
+        recs = []
+        for kind, obj, relu in self.steps:
+            if kind == "conv":
+                y = ops.conv2d(x, obj.fwd_params(relu=relu))
+                recs.append((kind, obj, relu, x, y))
+            else:
+                y = ops.maxpool2d(x, 3, obj, 1)
+                recs.append((kind, obj, None, x, y))
+            x = y
+        tape["vgg"] = recs
+        return x
+
+    def _tail_forward(self, x, tape):
+        return x
+
+    def _tail_backward(self, dfeat):
+        return dfeat
+
+    def _trunk_backward(self, dx):
+        for kind, obj, relu, x, y in reversed(self.tape["vgg"]):
+            if kind == "pool":
+                dx = T.maxpool_bwd(x, dx.contiguous(), 3, obj, 1)
+                continue
+            g = torch.empty_like(y)
+            obj.conv.bias.grad.copy_(T.relu_bias_bwd(dx, y, g, relu=relu, ws_cache=self.ws))
+            obj.wgrad(x, g, self.ws)
+            dx = ops.conv2d(g, obj.dgrad_params()) if not obj.stem else None
+
+
+class BaselineTrainer(Stage1Trainer):
+    """``train_step`` of the Baseline: forward, CE, backward, SGD step -- no clipping (entry/baseline.py:54-62)."""
+
+    def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=5e-4, device=None, loss="ce", sigma=5.0,
+                 use_graph=False):
+        from .core import losses
+        from .networks.baseline import net_ingredient
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.model = model
+        model.train()
+        eng_cls = _VGGEngine if model.backbone_name == "vgg16" else _ResNetProjectionEngine
+        self.eng = eng_cls(model, self.device)
+        self.lr, self.momentum, self.wd, self.max_norm = lr, momentum, weight_decay, 0.0
+        self.protos, self.dist_scalar = 0, net_ingredient.cfg["dist_scalar"]
+        self.last_grad_norm, self.nesterov, self.optimizer = None, False, None
+        self.use_graph, self._graphs = use_graph, {}
+        self.loss_obj = losses.get({"loss": loss, "sigma": sigma})
+
+    def _head_hip(self, feat, sup_mask, qry_msk, B, S, Q):
+        """Full-resolution masked average pooling (adjoint form) -> cosine -> upsample + CE, and its backward."""
+        if Q != 1:
+            raise ValueError("query must be 1")
+        eng, ws = self.eng, self.eng.ws
+        H, W = sup_mask.shape[-2:]
+        msk = sup_mask.reshape(B * S, 2, H, W).contiguous()
+        tgt = qry_msk.reshape(-1, *qry_msk.shape[-2:]).contiguous()
+        sup, qry = feat[:B * S], feat[B * S:]
+        pro = ops.masked_avg_pool(sup, msk, B, S, full_res=True, ws_cache=ws)
+        pred = ops.cosine_proto_max(qry, pro, self.dist_scalar)
+        wmap = self.loss_obj.weight_map(tgt)
+        _, stats, _ = ops.eval_tail(pred, tgt, ws_cache=ws, weight=wmap)
+        loss = stats[:, 0].sum() / stats[:, 1].sum()
+        dfeat = torch.empty_like(feat)
+        T.head_bwd(sup, qry, msk, None, ws[("map", B, S, sup.shape[1], sup.shape[2], sup.shape[3])], pro, pred, tgt, stats,
+                   dfeat, B, S, 0, self.dist_scalar, ws_cache=ws, weight=wmap, map_full_res=True)
+        eng.backward(dfeat)
+        return loss.float(), pred
+
+    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, head="hip"):
+        if head != "hip":
+            raise ValueError("BaselineTrainer: only the HIP head is available")
+        eng = self.eng
+        B, S, ch, H, W = sup_img.shape
+        Q = qry_img.shape[1]
+        eng.flat.grad.zero_()
+        feat = eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)])
+        return self._head_hip(feat, sup_mask, qry_msk, B, S, Q)

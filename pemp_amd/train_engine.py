@@ -172,8 +172,6 @@ class Stage1TrainEngine:
     """Forward + backward of the stage-1 ResNet-50 encoder in train mode on HIP kernels."""
 
     def __init__(self, model, device):
-        if model.backbone_name == "vgg16":
-            raise NotImplementedError("training engine: ResNet backbones only in this round")
         self.model, self.device = model, device
         self.flat = FlatParams(model, device)
         for b in model.buffers():
@@ -181,7 +179,14 @@ class Stage1TrainEngine:
         for p in model.parameters():
             if not p.requires_grad:
                 p.data = p.data.to(device)
-        bb, pur = model.encoder.backbone, model.encoder.purifier
+        self.ws = {}
+        self.drop_rate, self.block_size = 0.0, 4
+        self._init_trunk(model.encoder.backbone)
+        self._init_tail(model)
+        self.flat.build_dgrad_mirror()
+        self.bn_counters = [m.num_batches_tracked for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+
+    def _init_trunk(self, bb):
         f = self.flat
         self.stem = (_Conv(f, bb.conv1, stem=True), _BN(bb.bn1))
         self.blocks = []
@@ -191,16 +196,15 @@ class Stage1TrainEngine:
                     c1=_Conv(f, blk.conv1), b1=_BN(blk.bn1), c2=_Conv(f, blk.conv2), b2=_BN(blk.bn2),
                     c3=_Conv(f, blk.conv3), b3=_BN(blk.bn3),
                     ds=(_Conv(f, blk.downsample[0]), _BN(blk.downsample[1])) if blk.downsample is not None else None))
+
+    def _init_tail(self, model):
+        f, pur = self.flat, model.encoder.purifier
         self.p0, self.p3 = _Conv(f, pur[0]), _Conv(f, pur[3])
         aspp = pur[6]
         self.aspp_bn = [_BN(getattr(aspp, f"aspp_{i}")[0]) for i in range(5)]
         self.aspp_conv = [_Conv(f, getattr(aspp, f"aspp_{i}")[2]) for i in range(5)]
         self.l6 = aspp.layer6
         self.midc = self.aspp_conv[0].cout
-        self.ws = {}
-        self.drop_rate, self.block_size = 0.0, 4
-        self.flat.build_dgrad_mirror()
-        self.bn_counters = [m.num_batches_tracked for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
 
     # -- helpers ------------------------------------------------------------------------------
     def _new(self, *shape):
@@ -227,8 +231,29 @@ class Stage1TrainEngine:
     def forward(self, images_list):
         """images_list: [n_i,3,H,W] tensors -> NHWC features; keeps what backward needs in self.tape."""
         tape = {}
-        torch._foreach_add_(self.bn_counters, 1)            # every BatchNorm runs exactly once per step
+        if self.bn_counters:
+            torch._foreach_add_(self.bn_counters, 1)        # every BatchNorm runs exactly once per step
         self.flat.refresh_dgrad_mirror()
+        x = self._trunk_forward(images_list, tape)
+        feat = self._tail_forward(x, tape)
+        self.tape = tape
+        return feat
+
+    def backward(self, dfeat):
+        self._trunk_backward(self._tail_backward(dfeat))
+        self.tape = None
+
+    def _pack(self, images_list):
+        n = sum(t.shape[0] for t in images_list)
+        H, W = images_list[0].shape[-2:]
+        x4 = self._new(n, H, W, 4)
+        o = 0
+        for t in images_list:
+            ops.pack_input(t.contiguous(), out=x4[o:o + t.shape[0]])
+            o += t.shape[0]
+        return x4
+
+    def _trunk_forward(self, images_list, tape):
         n = sum(t.shape[0] for t in images_list)
         H, W = images_list[0].shape[-2:]
         x4 = self._new(n, H, W, 4)
@@ -251,6 +276,9 @@ class Stage1TrainEngine:
             rec["x"] = x
             tape["blocks"].append(rec)
             x = out
+        return x
+
+    def _tail_forward(self, x, tape):
         # purifier: conv+bias+ReLU (+DropBlock) twice
         nimg, h, w, _ = x.shape
         ya = ops.conv2d(x, self.p0.fwd_params(relu=True))
@@ -289,12 +317,11 @@ class Stage1TrainEngine:
         w6m = ConvParams(w6[:, midc:].contiguous(), None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False)
         feat = ops.conv2d(cat, w6m, shift_override=bias6.view(nimg, -1), per_image_shift=True)
         tape.update(gap=gap, m0=m0, i0=i0, t0d=t0d, d0=d0, g0=g0, cat=cat, ts=ts, ds=ds_, mean_x=mean_x, invstd_x=invstd_x,
-                    w6=w6, hw=(nimg, h, w), x4=x4)
-        self.tape = tape
+                    w6=w6, hw=(nimg, h, w))
         return feat
 
     # -- backward -----------------------------------------------------------------------------
-    def backward(self, dfeat):
+    def _tail_backward(self, dfeat):
         tp, midc = self.tape, self.midc
         nimg, h, w = tp["hw"]
         hw = h * w
@@ -360,7 +387,10 @@ class Stage1TrainEngine:
         g = torch.empty_like(tp["ya"])
         self.p0.conv.bias.grad.copy_(T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws))
         self.p0.wgrad(tp["p0_in"], g, self.ws)
-        dx = ops.conv2d(g, self.p0.dgrad_params())
+        return ops.conv2d(g, self.p0.dgrad_params())
+
+    def _trunk_backward(self, dx):
+        tp = self.tape
         # residual blocks, last to first
         for b, rec in zip(reversed(self.blocks), reversed(tp["blocks"])):
             x = rec["x"]
@@ -376,7 +406,6 @@ class Stage1TrainEngine:
         # stem: max pool, BN+ReLU, 7x7 conv (weight gradient only)
         dy = T.maxpool_bwd(tp["pool_in"], dx, 3, 2, 1)
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
-        self.tape = None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -443,6 +472,8 @@ class Stage1Trainer:
         self.protos = 0 if model.ctr is None else model.ctr.shape[1] // 2
         self.dist_scalar = cfg["dist_scalar"]
         self.last_grad_norm = None
+        self.nesterov = False
+        self.optimizer = None                     # optional torch optimizer acting as hyper-parameter / scheduler holder
         self.use_graph = use_graph
         self._graphs = {}
         from .core import losses
@@ -532,9 +563,18 @@ class Stage1Trainer:
         ent["graph"].replay()
         return ent["loss"]
 
+    def attach_optimizer(self, optimizer):
+        """Use ``optimizer.param_groups[0]`` (lr, momentum, weight_decay, nesterov) -- e.g. the object returned by
+        ``pemp_amd.core.solver.get`` with its LR scheduler -- as the source of hyper-parameters of every step."""
+        self.optimizer = optimizer
+
     def optimizer_step(self):
         f = self.eng.flat
+        if self.optimizer is not None:
+            g = self.optimizer.param_groups[0]
+            self.lr, self.momentum, self.wd = g["lr"], g.get("momentum", 0.0), g.get("weight_decay", 0.0)
+            self.nesterov = bool(g.get("nesterov", False))
         scale = allreduce_gradients(f.grad)
         self.last_grad_norm = T.sgd_clip_step(f.data, f.grad, f.mom, self.max_norm, self.lr, self.momentum, self.wd,
-                                              f.first_step, grad_scale=scale, ws_cache=self.eng.ws)
+                                              f.first_step, grad_scale=scale, ws_cache=self.eng.ws, nesterov=self.nesterov)
         f.first_step = False

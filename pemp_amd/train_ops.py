@@ -150,7 +150,7 @@ def gap_bwd_add(v, dst):
 
 
 def sgd_clip_step(params, grads, buf, max_norm, lr, momentum, weight_decay, first_step, grad_scale=1.0,
-                  ws_cache=None):
+                  ws_cache=None, nesterov=False):
     """Flat-buffer clip_grad_norm_ + SGD step.  Returns the 1-element tensor holding ||grads||_2."""
     lib = _lib.load()
     _chk_dev(params, grads, buf)
@@ -160,13 +160,13 @@ def sgd_clip_step(params, grads, buf, max_norm, lr, momentum, weight_decay, firs
     norm = torch.empty(1, dtype=torch.float32, device=params.device)
     ws = _ws(lib.pemp_sgd_workspace_bytes(), params.device, ws_cache, ("sgd",))
     _lib.check(lib.pemp_sgd_clip_step_f32(_p(params), _p(grads), _p(buf), n, float(max_norm), float(lr), float(momentum),
-                                          float(weight_decay), 1 if first_step else 0, float(grad_scale), _p(norm),
+                                          float(weight_decay), 1 if first_step else 0, float(grad_scale), 1 if nesterov else 0, _p(norm),
                                           _p(ws), ws.numel(), _stream()), "sgd_clip_step")
     return norm
 
 
 def head_bwd(sup_feat, qry_feat, sup_mask, ctr, fwd_ws, protos, pred, target, stats, dfeat, B, S, p, dist_scalar,
-             ws_cache=None, weight=None):
+             ws_cache=None, weight=None, map_full_res=False):
     """Gradient of the mean CE loss w.r.t. the features (written into ``dfeat`` [B*S + B, h, w, c], supports
     first) and w.r.t. ``ctr`` (returned, [c, 2p]; None for the plain-MAP head p == 0)."""
     lib = _lib.load()
@@ -182,6 +182,7 @@ def head_bwd(sup_feat, qry_feat, sup_mask, ctr, fwd_ws, protos, pred, target, st
     ws = _ws(nbytes, sup_feat.device, ws_cache, ("head_bwd", B, S, h, w, c, p))
     _lib.check(lib.pemp_head_bwd_f32(_p(sup_feat), _p(qry_feat), ldf, _p(sup_mask), _p(ctr), _p(fwd_ws), _p(protos),
                                      _p(pred), _p(target), _p(weight), _p(stats), _p(dfeat[:bs]), _p(dfeat[bs:]), ldd, _p(dctr),
-                                     _p(ws), ws.numel(), B, S, h, w, H, W, ho, wo, c, p, float(dist_scalar), _stream()),
+                                     _p(ws), ws.numel(), B, S, h, w, H, W, ho, wo, c, p, 1 if map_full_res else 0, float(dist_scalar),
+                                     _stream()),
                "head_bwd")
     return dctr

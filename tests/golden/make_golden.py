@@ -268,6 +268,32 @@ def gen_train_step(tmp):
     print("wrote train step; loss", float(loss))
 
 
+def gen_train_step_baseline(tmp):
+    """G10: loss and gradients of one Baseline training step (entry/baseline.py:54-62), VGG16 and ResNet-50."""
+    from networks import baseline as m
+    for backbone, tag in (("vgg16", "baseline_vgg16"), ("resnet50", "baseline_rn50")):
+        cfg = dict(dist_scalar=20, init_channels=3, backbone=backbone, out_channels=512)
+        model = _build(m, "Baseline", cfg, (), tmp)
+        _load_wgen(model)
+        model.train()
+        b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+        logits = model(_t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"]), (97, 97))
+        loss = torch.nn.functional.cross_entropy(logits, _t(b["qry_mask"][:, 0]), ignore_index=255)
+        loss.backward()
+        res = {"loss": np.array(float(loss.detach()), np.float64)}
+        names, norms = [], []
+        for k, p in model.named_parameters():
+            names.append(k)
+            norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+        res["grad_names"], res["grad_norms"] = np.array(names), np.array(norms, np.float64)
+        plist = dict(model.named_parameters())
+        for k in [k for k in plist if plist[k].grad is not None][:2] + list(plist)[-2:]:
+            g = plist[k].grad
+            res["grad__" + k] = g.numpy() if g.numel() <= 40000 else g.reshape(-1)[::37].numpy()
+        np.savez_compressed(OUT / f"{tag}_trainstep.npz", **res)
+        print("wrote", tag, "train step; loss", float(loss))
+
+
 def gen_index_facts():
     """G8: index-map facts of the stock ops."""
     import torch.nn.functional as F
@@ -315,6 +341,8 @@ def main():
             gen_stage2(tmp, s1, {"small": ([3], 1, 97, [(80, 120)]), "small5": ([5], 5, 97, [(64, 90)])})
         if only in ("", "train"):
             gen_train_step(tmp)
+        if only in ("", "trainbase"):
+            gen_train_step_baseline(tmp)
         if only in ("", "facts"):
             gen_index_facts()
 

@@ -248,3 +248,31 @@ def test_state_dict_layout_baseline_and_stage2():
     with pytest.raises(NotImplementedError, match="VGG16CM is broken"):
         s2.PEMPStage2(1, 1, None, backbone2="vgg16")
     assert s2.PriorNet.__name__ in ("PEMPStage1", "PEMP_Stage1/Resnet50", "PEMP_Stage1/VGG16")
+
+
+def test_solver_surface_and_schedules():
+    """core/solver.py mirror: config keys/defaults (incl. the conditional ones) and the LR policies."""
+    from pemp_amd.core import solver
+    cfg = solver.train_ingredient.cfg
+    assert cfg["lr"] == 1e-3 and cfg["lrp"] == "period_step" and cfg["lr_step"] == 999999999 and cfg["lr_rate"] == 0.1
+    assert cfg["opt"] == "sgd" and cfg["sgd_momentum"] == 0.9 and cfg["sgd_nesterov"] is False
+    assert cfg["weight_decay"] == 0.0005 and cfg["total_epochs"] == 3 and "adam_beta1" not in cfg and "power" not in cfg
+    assert solver.test_ingredient.cfg == {"epochs": 5}
+    lin = torch.nn.Linear(3, 2)
+    opt, sch = solver.get(lin, dict(cfg, lrp="poly", lr_end=0.0, power=0.9), max_steps=10)
+    lrs = []
+    for _ in range(3):
+        lrs.append(opt.param_groups[0]["lr"])
+        sch.step()
+    assert abs(lrs[0] - 1e-3 * (1 - 1 / 10) ** 0.9) < 1e-12 and lrs[1] < lrs[0]
+    opt, sch = solver.get(lin, dict(cfg, lr_step=2), max_steps=10)
+    seq = []
+    for _ in range(5):
+        seq.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    assert seq == pytest.approx([1e-3, 1e-3, 1e-4, 1e-4, 1e-5])
+    with pytest.raises(NotImplementedError):
+        solver.get(lin, dict(cfg, opt="adam"))
+    with pytest.raises(ValueError, match="Not supported optimizer"):
+        solver.get(lin, dict(cfg, opt="lamb"))

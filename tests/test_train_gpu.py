@@ -106,3 +106,44 @@ def test_two_steps_reduce_loss_and_dropblock_runs(hip_lib, dev):
     torch.manual_seed(0)
     losses = [tr.train_step(sup, msk, qry, gt).item() for _ in range(8)]
     assert all(np.isfinite(losses)) and min(losses[4:]) < losses[0], losses
+
+
+@pytest.mark.parametrize("backbone,tag", [("vgg16", "baseline_vgg16"), ("resnet50", "baseline_rn50")])
+def test_baseline_train_step_matches_reference(hip_lib, dev, backbone, tag):
+    """Baseline (VGG16: conv+bias+ReLU chain and max-pool backward; ResNet-50: BN trunk + projection) with
+    the full-resolution MAP head differentiated through its adjoint, vs the reference's gradients."""
+    from pemp_amd.networks import baseline as m
+    from pemp_amd.train_baseline import BaselineTrainer
+    g = util.gold(tag + "_trainstep")
+    net = m.Baseline(None, backbone=backbone)
+    net.load_state_dict(util.wgen_state_dict(tag))
+    tr = BaselineTrainer(net, device=dev)
+    sup, msk, qry, gt = _batch(dev)
+    loss, _ = tr.forward_backward(sup, msk, qry, gt)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    params = dict(net.named_parameters())
+    bad = []
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        if ref < 0:
+            continue
+        got = params[str(name)].grad.norm().item()
+        if abs(got - ref) > 1e-2 * ref + 1e-5:
+            bad.append((str(name), got, float(ref)))
+    assert not bad, bad[:10]
+    for key in [k for k in g.files if k.startswith("grad__")]:
+        name = key[len("grad__"):]
+        got = params[name].grad.cpu()
+        ref = torch.from_numpy(g[key])
+        got = (got if got.numel() <= 40000 else got.reshape(-1)[::37]).reshape(ref.shape)
+        assert (got - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item() + 1e-7, name
+    # the reference's baseline Trainer does not clip; the update must equal plain torch SGD
+    plist = [p for p in net.parameters() if p.requires_grad]
+    ref_p = [torch.nn.Parameter(p.detach().clone().contiguous()) for p in plist]
+    for r, p in zip(ref_p, plist):
+        r.grad = p.grad.detach().clone().contiguous()
+    opt = torch.optim.SGD(ref_p, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    opt.step()
+    tr.optimizer_step()
+    for r, p in zip(ref_p, plist):
+        assert torch.allclose(p.detach(), r.detach(), rtol=1e-6, atol=1e-7)
