@@ -143,6 +143,14 @@ int pemp_eval_tail_f32(const float* pred, const int64_t* target, uint8_t* pred_o
 int pemp_cm_reduce_f32(const float* x, int ldx, const float* mask_in, float* mask_out, float* stat,
                        int N, int Hm, int Wm, int Hx, int Wx, int C, int stride, void* stream);
 
+/* Backward of the comm statistics through loss.backward() in stage-2 training (entry/pemp_stage2.py:78;
+ * networks/backbones.py:209-215): given dstat [N][2][C] (gradients of the per-image mean and max),
+ *   dx[n][i][c] += mask[n][i] * (dstat[n][0][c] / HW + [i == argmax_i x*mask] * dstat[n][1][c])
+ * with mask the POOLED mask that cm_reduce returned (mask_out) and the first maximal index taking the
+ * max gradient (torch.max semantics on the host).  Accumulates into dx [N][HW][ldd].              */
+int pemp_cm_bwd_add_f32(const float* x, int ldx, const float* mask, const float* dstat, float* dx, int ldd,
+                        int N, int HW, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training path (Trainer.train_step, entry/pemp_stage1.py:57-65; model.train() at
  * core/base_trainer.py:189).

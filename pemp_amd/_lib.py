@@ -50,6 +50,7 @@ SYMBOLS = {
     "pemp_eval_tail_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size] + [c_int] * 5 + [c_fp]),
     "pemp_cm_reduce_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp]),
     # training path
+    "pemp_cm_bwd_add_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "pemp_conv2d_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
     "pemp_conv2d_wgrad_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_int, c_fp, c_size, c_fp]),
     "pemp_colsum_workspace_bytes": (c_size, [c_int, c_int]),

@@ -175,6 +175,51 @@ __global__ __launch_bounds__(256) void cm_stat_kernel(const float* __restrict__ 
     }
 }
 
+// Adjoint of cm_stat_kernel: dx[n,i,c] += mask[n,i] * (dmean[n,c]/HW + [i == first argmax_i x*mask] * dmax[n,c]).
+// Same block shape as the forward; the arg-max is recomputed (first index wins, as torch.max on the CPU does).
+__global__ __launch_bounds__(256) void cm_bwd_kernel(const float* __restrict__ x, int ldx,
+                                                     const float* __restrict__ mask, const float* __restrict__ dstat,
+                                                     float* __restrict__ dx, int ldd, int HW, int C) {
+    __shared__ float rm[4][64];
+    __shared__ int ri[4][64];
+    const int n = blockIdx.y;
+    const int cl = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + cl;
+    const int pl = threadIdx.x >> 6;
+    const float* mk = mask + (long long)n * HW;
+    float mx = -INFINITY;
+    int arg = 0x7fffffff;
+    if (c < C) {
+        const float* b = x + (long long)n * HW * ldx + c;
+        for (int i = pl; i < HW; i += 4) {
+            float v = b[(long long)i * ldx] * mk[i];
+            if (v > mx) {
+                mx = v;
+                arg = i;
+            }
+        }
+    }
+    rm[pl][cl] = mx;
+    ri[pl][cl] = arg;
+    __syncthreads();
+    if (c >= C) return;
+    for (int q = 0; q < 4; ++q) {
+        float v = rm[q][cl];
+        int a = ri[q][cl];
+        if (q == 0 || v > mx || (v == mx && a < arg)) {
+            mx = v;
+            arg = a;
+        }
+    }
+    const float gm = dstat[((long long)n * 2 + 0) * C + c] / (float)HW;
+    const float gx = dstat[((long long)n * 2 + 1) * C + c];
+    float* d = dx + (long long)n * HW * ldd + c;
+    for (int i = pl; i < HW; i += 4) {
+        float g = gm + (i == arg ? gx : 0.f);
+        d[(long long)i * ldd] += mk[i] * g;
+    }
+}
+
 static int grid_for(long long total, int block) {
     long long g = (total + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;
@@ -263,4 +308,13 @@ extern "C" int pemp_cm_reduce_f32(const float* x, int ldx, const float* mask_in,
     hipLaunchKernelGGL(cm_stat_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, (hipStream_t)stream, x, ldx, mask_out, stat,
                        Hx * Wx, C);
     return launch_status("cm_reduce/stat");
+}
+
+extern "C" int pemp_cm_bwd_add_f32(const float* x, int ldx, const float* mask, const float* dstat, float* dx, int ldd,
+                                   int N, int HW, int C, void* stream) {
+    PEMP_REQUIRE(x && mask && dstat && dx, "cm_bwd_add: null pointer");
+    PEMP_REQUIRE(N > 0 && HW > 0 && C > 0 && ldx >= C && ldd >= C, "cm_bwd_add: bad dims");
+    hipLaunchKernelGGL(cm_bwd_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, (hipStream_t)stream, x, ldx, mask, dstat, dx,
+                       ldd, HW, C);
+    return launch_status("cm_bwd_add");
 }

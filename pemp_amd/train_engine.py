@@ -210,31 +210,57 @@ class Stage1TrainEngine:
     def _new(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
-    def _cbn_fwd(self, x, conv, bn, relu, residual=None):
-        z = ops.conv2d(x, conv.fwd_params(relu=False, with_bias=False))
+    def _cbn_fwd(self, x, conv, bn, relu, residual=None, img_bias=None):
+        """conv -> (+ per-image bias [N,Cout]) -> batch-stat BN (+residual)(+ReLU); returns (y, tape record)."""
+        prm = conv.fwd_params(relu=False, with_bias=False)
+        z = ops.conv2d(x, prm) if img_bias is None else ops.conv2d(x, prm, shift_override=img_bias, per_image_shift=True)
         mean, invstd = bn.stats(z, self.ws)
         y = T.bn_apply(z, mean, invstd, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(z), residual=residual, relu=relu)
         return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu)
 
     def _cbn_bwd(self, dy, rec, conv, bn, want_gout=False, need_dx=True, add_to=None):
-        """-> (dx [compact for stride-2], gout).  ``add_to`` is added to dx inside the dgrad epilogue."""
+        """-> (dx [compact for stride-2], gout).  ``add_to`` is added to dx inside the dgrad epilogue; the
+        gradient at the conv output stays in rec["dz"]."""
         dz = torch.empty_like(rec["z"])
         gout = torch.empty_like(rec["z"]) if want_gout else None
         dgamma, dbeta = T.bn_bwd(dy, rec["y"], rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, dz, gout=gout,
                                  relu=rec["relu"], ws_cache=self.ws)
         bn.write_grads(dgamma, dbeta)
         conv.wgrad(rec["x"], dz, self.ws)
+        rec["dz"] = dz
         dx = ops.conv2d(dz, conv.dgrad_params(), residual=add_to) if need_dx else None
         return dx, gout
 
+    def _block_fwd(self, x, b, bias_c1=None, bias_ds=None):
+        rec = {"x": x}
+        y1, rec["r1"] = self._cbn_fwd(x, b["c1"], b["b1"], True, img_bias=bias_c1)
+        y2, rec["r2"] = self._cbn_fwd(y1, b["c2"], b["b2"], True)
+        if b["ds"] is not None:
+            res, rec["rd"] = self._cbn_fwd(x, b["ds"][0], b["ds"][1], False, img_bias=bias_ds)
+        else:
+            res = x
+        out, rec["r3"] = self._cbn_fwd(y2, b["c3"], b["b3"], True, residual=res)
+        return out, rec
+
+    def _block_bwd(self, dx, b, rec):
+        x = rec["x"]
+        stride = b["c1"].stride
+        dy2, gout = self._cbn_bwd(dx, rec["r3"], b["c3"], b["b3"], want_gout=True)
+        dy1, _ = self._cbn_bwd(dy2, rec["r2"], b["c2"], b["b2"])
+        if b["ds"] is None:
+            return self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=gout)[0]
+        dxd, _ = self._cbn_bwd(gout, rec["rd"], b["ds"][0], b["ds"][1])
+        dxc, _ = self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=dxd)
+        return dxc if stride == 1 else T.scatter_strided(dxc, (x.shape[1], x.shape[2]), stride)
+
     # -- forward ------------------------------------------------------------------------------
-    def forward(self, images_list):
+    def forward(self, images_list, **kw):
         """images_list: [n_i,3,H,W] tensors -> NHWC features; keeps what backward needs in self.tape."""
         tape = {}
         if self.bn_counters:
             torch._foreach_add_(self.bn_counters, 1)        # every BatchNorm runs exactly once per step
         self.flat.refresh_dgrad_mirror()
-        x = self._trunk_forward(images_list, tape)
+        x = self._trunk_forward(images_list, tape, **kw)
         feat = self._tail_forward(x, tape)
         self.tape = tape
         return feat
@@ -243,39 +269,23 @@ class Stage1TrainEngine:
         self._trunk_backward(self._tail_backward(dfeat))
         self.tape = None
 
-    def _pack(self, images_list):
+    def _pack(self, images_list, priors=None):
         n = sum(t.shape[0] for t in images_list)
         H, W = images_list[0].shape[-2:]
         x4 = self._new(n, H, W, 4)
         o = 0
-        for t in images_list:
-            ops.pack_input(t.contiguous(), out=x4[o:o + t.shape[0]])
+        for i, t in enumerate(images_list):
+            ops.pack_input(t.contiguous(), None if priors is None else priors[i].contiguous(), out=x4[o:o + t.shape[0]])
             o += t.shape[0]
         return x4
 
     def _trunk_forward(self, images_list, tape):
-        n = sum(t.shape[0] for t in images_list)
-        H, W = images_list[0].shape[-2:]
-        x4 = self._new(n, H, W, 4)
-        o = 0
-        for t in images_list:
-            ops.pack_input(t.contiguous(), out=x4[o:o + t.shape[0]])
-            o += t.shape[0]
-        y, tape["stem"] = self._cbn_fwd(x4, *self.stem, relu=True)
+        y, tape["stem"] = self._cbn_fwd(self._pack(images_list), *self.stem, relu=True)
         x = ops.maxpool2d(y, 3, 2, 1, ceil_mode=True)
         tape["pool_in"], tape["blocks"] = y, []
         for b in self.blocks:
-            rec = {}
-            y1, rec["r1"] = self._cbn_fwd(x, b["c1"], b["b1"], True)
-            y2, rec["r2"] = self._cbn_fwd(y1, b["c2"], b["b2"], True)
-            if b["ds"] is not None:
-                res, rec["rd"] = self._cbn_fwd(x, b["ds"][0], b["ds"][1], False)
-            else:
-                res = x
-            out, rec["r3"] = self._cbn_fwd(y2, b["c3"], b["b3"], True, residual=res)
-            rec["x"] = x
+            x, rec = self._block_fwd(x, b)
             tape["blocks"].append(rec)
-            x = out
         return x
 
     def _tail_forward(self, x, tape):
@@ -391,18 +401,8 @@ class Stage1TrainEngine:
 
     def _trunk_backward(self, dx):
         tp = self.tape
-        # residual blocks, last to first
-        for b, rec in zip(reversed(self.blocks), reversed(tp["blocks"])):
-            x = rec["x"]
-            stride = b["c1"].stride
-            dy2, gout = self._cbn_bwd(dx, rec["r3"], b["c3"], b["b3"], want_gout=True)
-            dy1, _ = self._cbn_bwd(dy2, rec["r2"], b["c2"], b["b2"])
-            if b["ds"] is not None:
-                dxd, _ = self._cbn_bwd(gout, rec["rd"], b["ds"][0], b["ds"][1])
-                dxc, _ = self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=dxd)
-                dx = dxc if stride == 1 else T.scatter_strided(dxc, (x.shape[1], x.shape[2]), stride)
-            else:
-                dx, _ = self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=gout)
+        for b, rec in zip(reversed(self.blocks), reversed(tp["blocks"])):       # residual blocks, last to first
+            dx = self._block_bwd(dx, b, rec)
         # stem: max pool, BN+ReLU, 7x7 conv (weight gradient only)
         dy = T.maxpool_bwd(tp["pool_in"], dx, 3, 2, 1)
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)

@@ -149,6 +149,20 @@ def gap_bwd_add(v, dst):
     return dst
 
 
+def cm_bwd_add(x, mask, dstat, dx):
+    """Backward of ``ops.cm_reduce``'s statistics: dx += mask * (dmean/HW + onehot(argmax) * dmax).
+    x, dx: NHWC [N,h,w,C]; mask: the pooled mask cm_reduce returned [N,h,w]; dstat [N,2,C]."""
+    lib = _lib.load()
+    _chk_dev(x, mask, dstat, dx)
+    from .ops import _nhwc
+    n, h, w, c = x.shape
+    if tuple(dx.shape) != (n, h, w, c) or tuple(dstat.shape) != (n, 2, c) or mask.numel() != n * h * w:
+        raise ValueError("cm_bwd_add: shape mismatch")
+    _lib.check(lib.pemp_cm_bwd_add_f32(_p(x), _nhwc(x, "x"), _p(mask.contiguous()), _p(dstat.contiguous()), _p(dx),
+                                       _nhwc(dx, "dx"), n, h * w, c, _stream()), "cm_bwd_add")
+    return dx
+
+
 def sgd_clip_step(params, grads, buf, max_norm, lr, momentum, weight_decay, first_step, grad_scale=1.0,
                   ws_cache=None, nesterov=False):
     """Flat-buffer clip_grad_norm_ + SGD step.  Returns the 1-element tensor holding ||grads||_2."""

@@ -1,0 +1,288 @@
+"""Training step of PEMP stage 2 (ResNet-50 + communication modules) on MI355X: counterpart of
+``Trainer.train_step`` in the reference's entry/pemp_stage2.py:72-83 for ``networks/pemp_stage2.py``
+in ``train()`` mode.
+
+What differs from stage 1 (pemp_amd/train_engine.py), and how it is laid out here:
+
+* the stem sees 4 channels (RGB + prior, pemp_stage2.py:130-138) -- the NHWC4 stem kernel takes the prior
+  plane as its 4th channel, nothing is concatenated;
+* ``ResNetCM.comm`` (backbones.py:208-222) appends two channels that are constant over space to the input
+  of each stage.  A 1x1 conv over a constant channel is a per-image bias, so the first block's conv1 /
+  downsample run on the REAL channels (MFMA implicit GEMM) with ``bias[img][co] = sum_e W[co][C+e] feat[img][e]``
+  added in the conv epilogue; backward: per-image column sums of dz give the gradients of the two
+  extra weight columns and of ``feat``; the Linear(2C -> 2), the episode mean and the mean/max statistics
+  are differentiated explicitly (``pemp_cm_bwd_add_f32`` routes the max gradient to the arg-max pixel);
+* the block BatchNorms are trainable here (only the stem / downsample BNs are frozen, backbones.py:175-202);
+* the purifier uses ``ASPP`` (conv -> ReLU -> Dropout2d, no BN; backbones.py:279-321) and Dropout2d(drop_rate2);
+  the channel masks come from torch's device RNG (parity unpinned, like DropBlock in stage 1);
+* gradients are clipped only for the VGG variant (entry/pemp_stage2.py:79-81), i.e. never for ResNet-50.
+"""
+import torch
+
+from . import ops, train_ops as T
+from .ops import ConvParams
+from .train_engine import Stage1TrainEngine, Stage1Trainer, _BN, _Conv
+
+_CM_STRIDES = (2, 1, 2)          # backbones.py:230,235,240
+
+
+class _ConvCM(_Conv):
+    """1x1 conv whose last two input channels are the communication channels ([Cout, C+2, 1, 1])."""
+
+    def __init__(self, flat, conv):
+        super().__init__(flat, conv)
+        if self.kh != 1 or self.kw != 1:
+            raise ValueError("communication channels enter 1x1 convs only")
+        self.creal = self.cin - 2
+        self.wreal = self.wext = None
+
+    def split(self):
+        """Once per step: contiguous copy of the real-channel columns, view of the two comm columns."""
+        w = self.flat.krsc(self.conv.weight)                       # [Cout, C+2]
+        self.wreal = w[:, :self.creal].contiguous()
+        self.wext = w[:, self.creal:]
+        return self
+
+    def fwd_params(self, relu=False, with_bias=True):
+        return ConvParams(self.wreal, None, None, self.creal, self.cout, 1, 1, self.stride, 0, 1, self.creal, False, relu)
+
+    def dgrad_params(self):
+        wd = self.flat.dgrad_krsc(self.conv.weight)[:self.creal]     # rows of the transposed weight = real channels
+        return ConvParams(wd, None, None, self.cout, self.creal, 1, 1, 1, 0, 1, self.cout, False, False)
+
+    def wgrad(self, x, g, ws):
+        dw = torch.empty((self.cout, self.creal), dtype=torch.float32, device=x.device)
+        prm = ConvParams(None, None, None, self.creal, self.cout, 1, 1, self.stride, 0, 1, self.creal, False, False)
+        T.conv_wgrad(x, g, prm, dw, ws_cache=ws)
+        self.flat.krsc_grad(self.conv.weight)[:, :self.creal].copy_(dw)
+
+    def ext_backward(self, colsum, feat_img):
+        """colsum [N,Cout] = per-image sums of dz; writes the grads of the comm columns, returns dfeat_img [N,2]."""
+        self.flat.krsc_grad(self.conv.weight)[:, self.creal:].copy_(colsum.t() @ feat_img)
+        return colsum @ self.wext
+
+
+def dropout2d_scale(n, c, p, device):
+    """nn.Dropout2d(p) in train(): one Bernoulli(1-p)/(1-p) multiplier per (image, channel), or None."""
+    if p <= 0.0:
+        return None
+    return torch.bernoulli(torch.full((n, c), 1.0 - p, device=device)) / (1.0 - p)
+
+
+class Stage2TrainEngine(Stage1TrainEngine):
+    def _init_trunk(self, bb):
+        f = self.flat
+        self.stem = (_Conv(f, bb.conv1, stem=True), _BN(bb.bn1))
+        self.blocks, self.stage_first, self.lin = [], [], []
+        for name, lin in (("layer1", bb.linear1), ("layer2", bb.linear2), ("layer3", bb.linear3)):
+            self.stage_first.append(len(self.blocks))
+            self.lin.append(lin)
+            for i, blk in enumerate(getattr(bb, name)):
+                mk = _ConvCM if i == 0 else _Conv
+                self.blocks.append(dict(
+                    c1=mk(f, blk.conv1), b1=_BN(blk.bn1), c2=_Conv(f, blk.conv2), b2=_BN(blk.bn2),
+                    c3=_Conv(f, blk.conv3), b3=_BN(blk.bn3),
+                    ds=(mk(f, blk.downsample[0]), _BN(blk.downsample[1])) if blk.downsample is not None else None))
+        self.drop_rate2 = 0.0
+
+    def _init_tail(self, model):
+        f, pur = self.flat, model.encoder.purifier
+        self.p0, self.p3 = _Conv(f, pur[0]), _Conv(f, pur[3])
+        aspp = pur[6]
+        self.aspp_conv = [_Conv(f, getattr(aspp, f"aspp_{i}")[0]) for i in range(5)]
+        self.l6 = aspp.layer6
+        self.midc = self.aspp_conv[0].cout
+
+    # -- trunk --------------------------------------------------------------------------------
+    def _trunk_forward(self, images_list, tape, priors=None, group=None, cnt=None):
+        """priors: per entry of images_list a [n_i,H,W] fp32 plane; group: LongTensor [N] episode of each image;
+        cnt: fp32 [episodes,1] images per episode (= shot + query)."""
+        n_groups = cnt.shape[0]
+        prior = torch.cat([p.reshape(-1, *p.shape[-2:]) for p in priors]).contiguous()
+        mask = ops.cm_reduce(None, prior, 2)[0]                               # backbones.py:227
+        y, tape["stem"] = self._cbn_fwd(self._pack(images_list, priors), *self.stem, relu=True)
+        x = ops.maxpool2d(y, 3, 2, 1, ceil_mode=True)
+        tape["pool_in"], tape["blocks"], tape["cm"] = y, [], []
+        tape["group"], tape["n_groups"] = group, n_groups
+        tape["cnt"] = cnt
+        for bi, b in enumerate(self.blocks):
+            if bi in self.stage_first:
+                si = self.stage_first.index(bi)
+                lin = self.lin[si]
+                mask, stat = ops.cm_reduce(x, mask, _CM_STRIDES[si])
+                n, _, c = stat.shape
+                agg = torch.zeros((n_groups, 2 * c), dtype=torch.float32, device=x.device)
+                agg.index_add_(0, group, stat.view(n, 2 * c))
+                agg = agg / cnt                                                # episode mean of (mean, max)
+                feat = torch.addmm(lin.bias.data, agg, lin.weight.data.t())    # [episodes, 2]
+                feat_img = feat[group].contiguous()                            # [N, 2]
+                c1, ds = b["c1"].split(), b["ds"][0].split()
+                tape["cm"].append(dict(x=x, mask=mask, agg=agg, feat_img=feat_img))
+                x, rec = self._block_fwd(x, b, bias_c1=(feat_img @ c1.wext.t()).contiguous(),
+                                         bias_ds=(feat_img @ ds.wext.t()).contiguous())
+            else:
+                x, rec = self._block_fwd(x, b)
+            tape["blocks"].append(rec)
+        return x
+
+    def _trunk_backward(self, dx):
+        tp = self.tape
+        group, n_groups, cnt = tp["group"], tp["n_groups"], tp["cnt"]
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            b, rec = self.blocks[bi], tp["blocks"][bi]
+            dx = self._block_bwd(dx, b, rec)
+            if bi not in self.stage_first:
+                continue
+            si = self.stage_first.index(bi)
+            cm, lin = tp["cm"][si], self.lin[si]
+            dz1, dzd = rec["r1"]["dz"], rec["rd"]["dz"]
+            hw_out = float(dz1.shape[1] * dz1.shape[2])
+            dfeat_img = b["c1"].ext_backward(ops.global_avgpool(dz1) * hw_out, cm["feat_img"]) \
+                + b["ds"][0].ext_backward(ops.global_avgpool(dzd) * hw_out, cm["feat_img"])
+            dfeat = torch.zeros((n_groups, 2), dtype=torch.float32, device=dx.device).index_add_(0, group, dfeat_img)
+            lin.weight.grad.copy_(dfeat.t() @ cm["agg"])
+            lin.bias.grad.copy_(dfeat.sum(dim=0))
+            dstat = ((dfeat @ lin.weight.data) / cnt)[group]                   # [N, 2C]: d(mean), d(max) per image
+            n, h, w, c = cm["x"].shape
+            T.cm_bwd_add(cm["x"], cm["mask"], dstat.view(n, 2, c).contiguous(), dx)
+        dy = T.maxpool_bwd(tp["pool_in"], dx, 3, 2, 1)
+        self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
+
+    # -- purifier: conv+ReLU+Dropout2d twice, ASPP (no BN), layer6 ------------------------------
+    def _drop(self, y, n, c):
+        m = dropout2d_scale(n, c, self.drop_rate2, self.device)
+        return (y if m is None else y * m.view(n, 1, 1, c)), m
+
+    def _tail_forward(self, x, tape):
+        nimg, h, w, _ = x.shape
+        midc = self.midc
+        ya = ops.conv2d(x, self.p0.fwd_params(relu=True))
+        xa, ma = self._drop(ya, nimg, ya.shape[-1])
+        yb = ops.conv2d(xa, self.p3.fwd_params(relu=True))
+        xb, mb = self._drop(yb, nimg, yb.shape[-1])
+        gap = ops.global_avgpool(xb)
+        g0 = ops.conv2d(gap.view(nimg, 1, 1, -1), self.aspp_conv[0].fwd_params(relu=True))
+        g0d, m0 = self._drop(g0, nimg, midc)
+        l6w = self.l6.weight
+        w6 = self.flat.krsc(l6w)                                              # [512, 1280]
+        w6g = ConvParams(w6[:, :midc].contiguous(), None, self.l6.bias.data, midc, l6w.shape[0], 1, 1, 1, 0, 1, midc, False, False)
+        bias6 = ops.conv2d(g0d, w6g)
+        cat = self._new(nimg, h, w, 4 * midc)                                 # post-ReLU branch outputs u_i
+        ms = []
+        for i in range(1, 5):
+            ops.conv2d(xb, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
+            ms.append(dropout2d_scale(nimg, midc, self.drop_rate2, self.device))
+        catd = cat if ms[0] is None else cat * torch.cat(ms, dim=1).view(nimg, 1, 1, 4 * midc)
+        w6m = ConvParams(w6[:, midc:].contiguous(), None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False)
+        feat = ops.conv2d(catd, w6m, shift_override=bias6.view(nimg, -1), per_image_shift=True)
+        tape.update(p0_in=x, ya=ya, ma=ma, xa=xa, yb=yb, mb=mb, xb=xb, gap=gap, g0=g0, m0=m0, g0d=g0d, cat=cat, catd=catd,
+                    ms=ms, w6=w6, hw=(nimg, h, w))
+        return feat
+
+    def _tail_backward(self, dfeat):
+        tp, midc = self.tape, self.midc
+        nimg, h, w = tp["hw"]
+        l6w = self.l6.weight
+        cout = l6w.shape[0]
+        w6 = tp["w6"]
+        dw6 = self.flat.krsc_grad(l6w)
+        dw6m = self._new(cout, 4 * midc)
+        T.conv_wgrad(tp["catd"], dfeat, ConvParams(None, None, None, 4 * midc, cout, 1, 1, 1, 0, 1, 4 * midc, False, False),
+                     dw6m, ws_cache=self.ws)
+        dw6[:, midc:].copy_(dw6m)
+        dcat = ops.conv2d(dfeat, ConvParams(T.dgrad_weight(w6[:, midc:].contiguous(), 1, 1), None, None, cout, 4 * midc,
+                                            1, 1, 1, 0, 1, cout, False, False))
+        s = ops.global_avgpool(dfeat) * float(h * w)                          # per-image column sums [N, 512]
+        self.l6.bias.grad.copy_(s.sum(dim=0))
+        dw6g = self._new(cout, midc)
+        T.conv_wgrad(tp["g0d"], s.view(nimg, 1, 1, -1), ConvParams(None, None, None, midc, cout, 1, 1, 1, 0, 1, midc, False, False),
+                     dw6g, ws_cache=self.ws)
+        dw6[:, :midc].copy_(dw6g)
+        dg0 = ops.conv2d(s.view(nimg, 1, 1, -1), ConvParams(T.dgrad_weight(w6[:, :midc].contiguous(), 1, 1), None, None, cout,
+                                                            midc, 1, 1, 1, 0, 1, cout, False, False))
+        if tp["ms"][0] is not None:
+            dcat = dcat * torch.cat(tp["ms"], dim=1).view(nimg, 1, 1, 4 * midc)
+        dxb = None
+        for i in range(1, 5):
+            conv = self.aspp_conv[i]
+            g = self._new(nimg, h, w, midc)
+            sl = slice((i - 1) * midc, i * midc)
+            conv.conv.bias.grad.copy_(T.relu_bias_bwd(dcat[..., sl], tp["cat"][..., sl], g, relu=True, ws_cache=self.ws))
+            conv.wgrad(tp["xb"], g, self.ws)
+            dxb = ops.conv2d(g, conv.dgrad_params(), residual=dxb)            # branch gradients accumulate in the epilogue
+        conv0 = self.aspp_conv[0]
+        if tp["m0"] is not None:
+            dg0 = dg0 * tp["m0"].view(nimg, 1, 1, midc)
+        g = self._new(nimg, 1, 1, midc)
+        conv0.conv.bias.grad.copy_(T.relu_bias_bwd(dg0, tp["g0"], g, relu=True, ws_cache=self.ws))
+        conv0.wgrad(tp["gap"].view(nimg, 1, 1, -1), g, self.ws)
+        T.gap_bwd_add(ops.conv2d(g, conv0.dgrad_params()).view(nimg, -1), dxb)
+        if tp["mb"] is not None:
+            dxb = dxb * tp["mb"].view(nimg, 1, 1, -1)
+        g = torch.empty_like(tp["yb"])
+        self.p3.conv.bias.grad.copy_(T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws))
+        self.p3.wgrad(tp["xa"], g, self.ws)
+        dxa = ops.conv2d(g, self.p3.dgrad_params())
+        if tp["ma"] is not None:
+            dxa = dxa * tp["ma"].view(nimg, 1, 1, -1)
+        g = torch.empty_like(tp["ya"])
+        self.p0.conv.bias.grad.copy_(T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws))
+        self.p0.wgrad(tp["p0_in"], g, self.ws)
+        return ops.conv2d(g, self.p0.dgrad_params())
+
+
+class Stage2Trainer(Stage1Trainer):
+    """``train_step(*inputs, qry_msk=...)`` of the reference's stage-2 Trainer: frozen stage-1 prior (eval, HIP
+    inference path) -> stage-2 forward, CE, backward, SGD (entry/pemp_stage2.py:72-83)."""
+
+    def __init__(self, stage1, model, lr=1e-3, momentum=0.9, weight_decay=5e-4, device=None, drop_rate2=None,
+                 loss="ce", sigma=5.0, use_graph=False):
+        from .core import losses
+        from .networks.pemp_stage2 import net_ingredient
+        cfg = net_ingredient.cfg
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.stage1, self.model = stage1, model
+        if stage1 is not None:
+            stage1.eval()
+        model.train()
+        self.eng = Stage2TrainEngine(model, self.device)
+        self.eng.drop_rate2 = cfg["drop_rate2"] if drop_rate2 is None else drop_rate2
+        self.lr, self.momentum, self.wd, self.max_norm = lr, momentum, weight_decay, 0.0
+        self.protos = 0 if model.ctr is None else model.ctr.shape[1] // 2
+        self.dist_scalar = cfg["dist_scalar"]
+        self.last_grad_norm, self.nesterov, self.optimizer = None, False, None
+        self.use_graph, self._graphs = use_graph, {}
+        self.loss_obj = losses.get({"loss": loss, "sigma": sigma})
+        self._groups = {}
+
+    def prior(self, sup_img, sup_mask, qry_img):
+        """argmax of the stage-1 logits at the input resolution, [BQ,1,H,W] (entry/pemp_stage2.py:74-75)."""
+        with torch.no_grad():
+            return self.stage1(sup_img, sup_mask, qry_img).argmax(dim=1, keepdim=True)
+
+    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, qry_prior=None, head="hip"):
+        if head != "hip":
+            raise ValueError("Stage2Trainer: only the HIP head is available")
+        eng = self.eng
+        B, S, ch, H, W = sup_img.shape
+        Q = qry_img.shape[1]
+        if S + Q != self.model.spq:
+            raise ValueError(f"model was built for shot+query={self.model.spq}, got {S + Q}")
+        if qry_prior is None:
+            qry_prior = self.prior(sup_img, sup_mask, qry_img)
+        key = (B, S, Q)
+        if key not in self._groups:
+            g = torch.cat((torch.arange(B).repeat_interleave(S), torch.arange(B).repeat_interleave(Q)))
+            self._groups[key] = (g.to(self.device), torch.full((B, 1), float(S + Q), device=self.device))
+        eng.flat.grad.zero_()
+        priors = [sup_mask[:, :, 0].reshape(B * S, H, W).float(), qry_prior.reshape(B * Q, H, W).float()]
+        feat = eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)], priors=priors,
+                           group=self._groups[key][0], cnt=self._groups[key][1])
+        return self._head_hip(feat, sup_mask, qry_msk, B, S, Q)
+
+    def train_step(self, sup_img, sup_mask, qry_img, qry_msk=None, qry_prior=None):
+        ins = [t.to(self.device) for t in (sup_img, sup_mask, qry_img, qry_msk)]
+        ins.append(self.prior(*ins[:3]) if qry_prior is None else qry_prior.to(self.device))
+        loss = self._graphed_forward_backward(*ins) if self.use_graph else self.forward_backward(*ins)[0]
+        self.optimizer_step()
+        return loss

@@ -294,6 +294,49 @@ def gen_train_step_baseline(tmp):
         print("wrote", tag, "train step; loss", float(loss))
 
 
+def stage2_train_prior(qry_mask):
+    """Deterministic stand-in for the stage-1 argmax prior of the stage-2 train-step fixture: the query
+    foreground shifted by (3, 5) pixels (the real prior path is pinned by the stage-2 eval fixtures)."""
+    fg = (qry_mask[:, 0] == 1)
+    return np.roll(fg, (3, 5), axis=(1, 2)).astype(np.int64)[:, None]          # [BQ,1,H,W]
+
+
+def gen_train_step_stage2(tmp):
+    """G11: loss and gradients of one stage-2 training step (entry/pemp_stage2.py:72-83): ResNet-50+CM in
+    train() mode (batch-stat BN, Dropout2d off = drop_rate2 0), B=2 episodes, 97x97, CE loss."""
+    from networks import pemp_stage2 as m
+    cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
+               drop_rate=0.1, block_size=4, backbone2="resnet50", protos2=3, drop_rate2=0.0, cm=True)
+    model = _build(m, "PEMPStage2", cfg, (1, 1), tmp)
+    _load_wgen(model, seed=4321)
+    model.train()
+    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    prior = torch.from_numpy(stage2_train_prior(b["qry_mask"]))
+    logits = model(_t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"]), prior, (97, 97))
+    loss = torch.nn.functional.cross_entropy(logits, _t(b["qry_mask"][:, 0]), ignore_index=255)
+    loss.backward()
+    res = {"loss": np.array(float(loss.detach()), np.float64), "logits_s7": logits.detach()[:, :, ::7, ::7].numpy()}
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+    res["grad_names"], res["grad_norms"] = np.array(names), np.array(norms, np.float64)
+    plist = dict(model.named_parameters())
+    bb = "encoder.backbone."
+    for k in ("ctr", bb + "conv1.weight", bb + "linear1.weight", bb + "linear2.bias", bb + "linear3.weight",
+              bb + "layer1.0.conv1.weight", bb + "layer2.0.downsample.0.weight", bb + "layer3.0.conv1.weight",
+              bb + "layer3.5.bn3.weight", bb + "layer1.1.bn2.bias", "encoder.purifier.6.aspp_3.0.weight",
+              "encoder.purifier.6.aspp_0.0.bias", "encoder.purifier.6.layer6.bias", "encoder.purifier.0.weight"):
+        g = plist[k].grad
+        res["grad__" + k] = g.numpy() if g.numel() <= 40000 else g.reshape(-1)[::37].numpy()
+    sd = model.state_dict()
+    for k in (bb + "bn1.running_mean", bb + "layer3.5.bn3.running_var", bb + "layer2.0.downsample.1.running_mean",
+              bb + "bn1.num_batches_tracked"):
+        res["buf__" + k] = sd[k].numpy()
+    np.savez_compressed(OUT / "stage2_rn50cm_trainstep.npz", **res)
+    print("wrote stage-2 train step; loss", float(loss))
+
+
 def gen_index_facts():
     """G8: index-map facts of the stock ops."""
     import torch.nn.functional as F
@@ -343,6 +386,8 @@ def main():
             gen_train_step(tmp)
         if only in ("", "trainbase"):
             gen_train_step_baseline(tmp)
+        if only in ("", "train2"):
+            gen_train_step_stage2(tmp)
         if only in ("", "facts"):
             gen_index_facts()
 

@@ -147,3 +147,77 @@ def test_baseline_train_step_matches_reference(hip_lib, dev, backbone, tag):
     tr.optimizer_step()
     for r, p in zip(ref_p, plist):
         assert torch.allclose(p.detach(), r.detach(), rtol=1e-6, atol=1e-7)
+
+
+def _stage2_trainer(dev, **kw):
+    from pemp_amd.networks import pemp_stage2 as m
+    from pemp_amd.train_stage2 import Stage2Trainer
+    net = m.ModelClass(1, 1, None)
+    net.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+    return Stage2Trainer(None, net, device=dev, **kw), net
+
+
+def test_stage2_train_step_matches_reference(hip_lib, dev):
+    """Stage 2 (4-channel stem, communication modules as per-image conv bias with explicit backward through the
+    Linear / episode mean / masked mean+max statistics, trainable block BNs, ASPP without BN) vs the gradients
+    the reference produced (tests/golden/stage2_rn50cm_trainstep.npz; Dropout2d off) and their fp64 evaluation."""
+    from pemp_amd import ops
+    from tests.golden.make_golden import stage2_train_prior
+    from pemp_amd import synth
+    g = util.gold("stage2_rn50cm_trainstep")
+    g64 = util.gold("stage2_rn50cm_trainstep_f64")
+    tr, net = _stage2_trainer(dev, drop_rate2=0.0)
+    sup, msk, qry, gt = _batch(dev)
+    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    prior = torch.from_numpy(stage2_train_prior(b["qry_mask"])).to(dev)
+    loss, pred = tr.forward_backward(sup, msk, qry, gt, prior)
+    logits = ops.upsample_bilinear_ac(pred, (97, 97))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    assert (logits.cpu()[:, :, ::7, ::7].numpy() - g["logits_s7"]).__abs__().max() < 5e-3
+    params = dict(net.named_parameters())
+    bad = []
+    for name, ref, ref64 in zip(g["grad_names"], g["grad_norms"], g64["grad_norms64"]):
+        p = params[str(name)]
+        if ref < 0:
+            assert not p.requires_grad, name
+            continue
+        assert p.requires_grad, name
+        got = p.grad.norm().item()
+        # linear*.bias: a constant shift of a pre-BatchNorm activation has zero gradient (1e-9 of rounding in fp32)
+        if abs(got - ref) > 5e-3 * ref + 1e-5 and abs(got - ref64) > 5e-3 * ref64 + 1e-5:
+            bad.append((str(name), got, float(ref), float(ref64)))
+    assert not bad, bad[:10]
+    for key in [k for k in g.files if k.startswith("grad__")]:
+        name = key[len("grad__"):]
+        got = params[name].grad.cpu()
+        ref = torch.from_numpy(g[key])
+        got = (got if got.numel() <= 40000 else got.reshape(-1)[::37]).reshape(ref.shape)
+        ref64 = torch.from_numpy(g64["g64__" + name])
+        scale = max(ref64.abs().max().item(), 1e-6)
+        assert (got - ref).abs().max().item() <= 5e-3 * scale + 1e-7, name
+        assert (got.double() - ref64).abs().max().item() <= 5e-3 * scale + 1e-7, name
+    sd = net.state_dict()
+    for key in [k for k in g.files if k.startswith("buf__")]:
+        name = key[len("buf__"):]
+        ref = torch.from_numpy(g[key])
+        assert torch.allclose(sd[name].cpu().to(ref.dtype), ref, rtol=1e-4, atol=1e-5), name
+
+
+def test_stage2_train_steps_with_stage1_prior_and_dropout(hip_lib, dev):
+    """Whole train_step: frozen stage-1 prior on the HIP eval path, Dropout2d active, SGD without clipping."""
+    from pemp_amd.networks import pemp_stage1 as m1, pemp_stage2 as m2
+    from pemp_amd.train_stage2 import Stage2Trainer
+    s1 = m1.ModelClass(None)
+    s1.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    s1.to(dev).eval()
+    net = m2.ModelClass(1, 1, None)
+    net.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+    tr = Stage2Trainer(s1, net, device=dev, lr=2e-3)
+    assert tr.max_norm == 0.0 and tr.eng.drop_rate2 == 0.5
+    sup, msk, qry, gt = _batch(dev)
+    torch.manual_seed(0)
+    losses = [tr.train_step(sup, msk, qry, qry_msk=gt).item() for _ in range(8)]
+    assert all(np.isfinite(losses)) and min(losses[4:]) < losses[0], losses
+    fresh = m2.ModelClass(1, 1, None)
+    fresh.load_state_dict({k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()})
