@@ -42,3 +42,16 @@ def test(_config, split, shot, test_n, test_seed, te_epochs):
 
 if __name__ == "__main__":
     print(ex.run_commandline())
+
+
+class Trainer:
+    """``train_step(*inputs, qry_msk=...)`` of the reference's baseline Trainer (entry/baseline.py:54-62)."""
+
+    def __new__(cls, model, **kw):
+        from ..train_baseline import BaselineTrainer
+
+        class _Trainer(BaselineTrainer):
+            def train_step(self, *inputs, qry_msk=None):
+                return super().train_step(*inputs, qry_msk=qry_msk.view(-1, *qry_msk.shape[-2:]))
+
+        return _Trainer(model, **kw)

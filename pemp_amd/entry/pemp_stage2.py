@@ -41,3 +41,17 @@ class Evaluator:
         am, stats = self.test_step_device(inputs, qry_msk)
         st = stats.cpu().numpy()
         return am.cpu().numpy(), float(st[:, 0].sum() / max(st[:, 1].sum(), 1.0))
+
+
+class Trainer:
+    """``train_step(*inputs, qry_msk=...)`` of the reference's stage-2 Trainer (entry/pemp_stage2.py:67-83): the
+    frozen stage-1 model gives the prior, stage 2 steps on the HIP training path (no clipping for ResNet-50)."""
+
+    def __new__(cls, stage1, model, **kw):
+        from ..train_stage2 import Stage2Trainer
+
+        class _Trainer(Stage2Trainer):
+            def train_step(self, *inputs, qry_msk=None):
+                return super().train_step(*inputs, qry_msk=qry_msk.view(-1, *qry_msk.shape[-2:]))
+
+        return _Trainer(stage1, model, **kw)

@@ -1,4 +1,5 @@
-"""Training harness of PEMP stage 1 on MI355X (counterpart of the reference's
+"""Training harness (stage 1 by default; ``model=baseline|baseline_rn50|stage2`` for the others) on MI355X
+(counterpart of the reference's
 entry/pemp_stage1.py:57-65,68-113 and core/base_trainer.py:183-210 on synthetic episodes).
 
 One process per GPU (``torchrun --nproc-per-node N -m pemp_amd.entry.train_stage1 ...``): every rank
@@ -40,7 +41,22 @@ def broadcast_model(model, src=0):
             dist.broadcast(t.data, src)
 
 
-def main(steps=20, bs=4, shot=1, lr=1e-3, seed=1234, log_every=5):
+def build_trainer(model_name, shot, lr, dev):
+    """model_name: stage1 | baseline | baseline_rn50 | stage2 (stage 2 trains against a frozen stage-1 model)."""
+    if model_name == "stage1":
+        return Trainer(ModelClass(None), lr=lr, device=dev)
+    if model_name in ("baseline", "baseline_rn50"):
+        from ..networks import baseline as mb
+        from . import baseline as eb
+        return eb.Trainer(mb.Baseline(None, backbone="vgg16" if model_name == "baseline" else "resnet50"), lr=lr, device=dev)
+    if model_name == "stage2":
+        from ..networks import pemp_stage2 as m2
+        from . import pemp_stage2 as e2
+        return e2.Trainer(ModelClass(None).to(dev).eval(), m2.ModelClass(shot, 1, None), lr=lr, device=dev)
+    raise ValueError(f"unknown model {model_name!r}")
+
+
+def main(steps=20, bs=4, shot=1, lr=1e-3, seed=1234, log_every=5, model="stage1"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -49,9 +65,11 @@ def main(steps=20, bs=4, shot=1, lr=1e-3, seed=1234, log_every=5):
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(seed + rank)
-    model = ModelClass(None)
-    trainer = Trainer(model, lr=lr, device=dev)
+    trainer = build_trainer(model, shot, lr, dev)
+    model = trainer.model
     broadcast_model(model)
+    if getattr(trainer, "stage1", None) is not None:
+        broadcast_model(trainer.stage1)
     t0 = time.time()
     for i, (inputs, qry_msk) in enumerate(synthetic_batches(bs, shot, steps, seed, rank)):
         loss = trainer.train_step(*inputs, qry_msk=qry_msk)
@@ -64,4 +82,4 @@ def main(steps=20, bs=4, shot=1, lr=1e-3, seed=1234, log_every=5):
 if __name__ == "__main__":
     import sys
     kw = dict(a.split("=") for a in sys.argv[1:])
-    main(**{k: (float(v) if "." in v or "e" in v else int(v)) for k, v in kw.items()})
+    main(**{k: (v if k == "model" else float(v) if "." in v or "e" in v else int(v)) for k, v in kw.items()})

@@ -561,7 +561,7 @@ class Stage1Trainer:
         for s_, t in zip(ent["static"], ins):
             s_.copy_(t, non_blocking=True)
         ent["graph"].replay()
-        return ent["loss"]
+        return ent["loss"].clone()          # the graph's output buffer is overwritten by the next replay
 
     def attach_optimizer(self, optimizer):
         """Use ``optimizer.param_groups[0]`` (lr, momentum, weight_decay, nesterov) -- e.g. the object returned by

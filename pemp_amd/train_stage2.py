@@ -258,7 +258,9 @@ class Stage2Trainer(Stage1Trainer):
     def prior(self, sup_img, sup_mask, qry_img):
         """argmax of the stage-1 logits at the input resolution, [BQ,1,H,W] (entry/pemp_stage2.py:74-75)."""
         with torch.no_grad():
-            return self.stage1(sup_img, sup_mask, qry_img).argmax(dim=1, keepdim=True)
+            pred, _ = self.stage1.lowres(sup_img, sup_mask, qry_img)
+            am, _, _ = ops.eval_tail(pred, None, out_hw=tuple(sup_img.shape[-2:]), ws_cache=self.eng.ws)   # fused upsample+argmax
+            return am.unsqueeze(1)
 
     def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, qry_prior=None, head="hip"):
         if head != "hip":
