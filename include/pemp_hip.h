@@ -229,6 +229,49 @@ int pemp_sgd_clip_step_f32(float* params, const float* grads, float* momentum_bu
                            float grad_scale, int nesterov, float* grad_norm_out, void* ws, size_t ws_bytes,
                            void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Episode input pipeline on the device: everything
+ * PascalVOCTrain._get_episode (data_kits/pascal_voc.py:185-237) does AFTER the JPEG/PNG decode, on
+ * uint8 arrays uploaded as one blob:
+ *   F.resize(img, BILINEAR) :144   Pillow ImagingResample, 8-bit fixed point (22 fraction bits),
+ *                                  horizontal pass then vertical pass, each rounded to uint8 -- bit-exact;
+ *   ColorJitter(.4,.4,.4)   :146   ImageEnhance Brightness/Contrast/Color = Image.blend with a black /
+ *                                  mean-gray / gray image, in the drawn order -- bit-exact for given factors;
+ *   F.hflip                 :143   ; crop_obj window :26-84 (origin chosen by the host);
+ *   ToTensor + Normalize    :141-142  ((x / 255) - mean) / std in fp32 -- bit-exact;
+ *   F.resize(label, NEAREST):145   Pillow ImagingScaleAffine (source coordinate accumulated in double);
+ *   mask // 255 -> stack(fg, 1 - fg) :209-210 (support) / int64 label :231 (query).
+ * One descriptor per decoded sample.  The host fills the first block of fields, calls
+ * pemp_episode_plan() (fills the "planned" fields, returns the workspace size), uploads descriptors and
+ * pixels, then calls pemp_episode_preprocess().                                                    */
+typedef struct pemp_sample_desc {
+    int64_t img_off;       /* byte offset of the HWC uint8 RGB source inside blob; < 0: no image        */
+    int64_t msk_off;       /* byte offset of the HW uint8 label source ({0,255}); < 0: no label         */
+    int64_t img_out;       /* element offset in img_out of this sample's [3][H][W] fp32 result          */
+    int64_t msk_out;       /* element offset in planes_out (mask_mode 1) / label_out (modes 2, 3)       */
+    int32_t hs, ws;        /* source height, width                                                      */
+    int32_t sh, sw;        /* size after F.resize (eval: H, W; train: int(H*f), int(W*f), f in [1,1.5])   */
+    int32_t oy, ox;        /* crop window origin inside the resized (and flipped) image; window = H x W */
+    int32_t flip;          /* 1: horizontal flip after resize / jitter                                  */
+    int32_t jitter_order;  /* 0: no jitter; else stage0 | stage1<<2 | stage2<<4 with 1 = brightness,
+                              2 = contrast, 3 = saturation                                              */
+    float jitter[3];       /* enhancement factors (brightness, contrast, saturation)                    */
+    int32_t mask_mode;     /* 0 none; 1 support planes fp32 [2][H][W]; 2 label int64 [H][W] (resized,
+                              flipped, cropped); 3 label int64 [hs][ws] (query at test time: not resized) */
+    /* planned (pemp_episode_plan): */
+    int32_t ksx, ksy;      /* filter taps per output pixel, horizontal / vertical                       */
+    int64_t ws_off;        /* byte offset of this sample's tables and intermediates in the workspace    */
+} pemp_sample_desc;
+
+/* Validates descs[0..n) (host memory), fills ksx/ksy/ws_off; returns the workspace bytes (0 on error). */
+size_t pemp_episode_plan(pemp_sample_desc* descs_host, int n, int H, int W);
+/* blob, descs_dev, outputs, ws: device memory; descs_host: the same descriptors in host memory (read
+ * during the call only).  mean/std: host pointers to 3 floats.                                        */
+int pemp_episode_preprocess(const uint8_t* blob, const pemp_sample_desc* descs_host,
+                            const pemp_sample_desc* descs_dev, int n, int H, int W,
+                            const float* mean, const float* std, float* img_out, float* planes_out,
+                            int64_t* label_out, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,14 @@ class ConvDesc(C.Structure):
                  "stride", "pad", "dil", "ldr", "Kpad")] + [("flags", C.c_uint32), ("tile", C.c_int32)]
 
 
+class SampleDesc(C.Structure):
+    """struct pemp_sample_desc (include/pemp_hip.h): one decoded sample of an episode."""
+    _fields_ = [("img_off", C.c_int64), ("msk_off", C.c_int64), ("img_out", C.c_int64), ("msk_out", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("hs", "ws", "sh", "sw", "oy", "ox", "flip", "jitter_order")] + \
+               [("jitter", C.c_float * 3), ("mask_mode", C.c_int32), ("ksx", C.c_int32), ("ksy", C.c_int32),
+                ("ws_off", C.c_int64)]
+
+
 CONV_RELU = 1
 CONV_SHIFT_PER_IMAGE = 2
 CONV_STEM4 = 4
@@ -49,6 +57,10 @@ SYMBOLS = {
     "pemp_eval_tail_workspace_bytes": (c_size, [c_int] * 3),
     "pemp_eval_tail_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size] + [c_int] * 5 + [c_fp]),
     "pemp_cm_reduce_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp]),
+    # episode input pipeline
+    "pemp_episode_plan": (c_size, [C.POINTER(SampleDesc), c_int, c_int, c_int]),
+    "pemp_episode_preprocess": (c_int, [c_fp, C.POINTER(SampleDesc), c_fp, c_int, c_int, c_int, C.POINTER(C.c_float),
+                                        C.POINTER(C.c_float), c_fp, c_fp, c_fp, c_fp, c_size, c_fp]),
     # training path
     "pemp_cm_bwd_add_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "pemp_conv2d_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),

@@ -276,3 +276,70 @@ def test_solver_surface_and_schedules():
         solver.get(lin, dict(cfg, opt="adam"))
     with pytest.raises(ValueError, match="Not supported optimizer"):
         solver.get(lin, dict(cfg, opt="lamb"))
+
+
+# ---------------------------------------------------------------------------------------------
+# episode input pipeline: oracle vs Pillow's own output, host planning, host mirror of the random draws
+# ---------------------------------------------------------------------------------------------
+def test_pil_oracle_matches_pillow_fixtures():
+    import zlib
+    from oracle import pil_ops as P
+    from pemp_amd.data_kits import synth_u8
+    g = util.gold("pil_ops")
+    for i in range(5):
+        h, w = (int(v) for v in g[f"s{i}_hw"])
+        assert np.array_equal(P.resize_bilinear(g[f"s{i}_img"], h, w), g[f"s{i}_bilinear"])
+        assert np.array_equal(P.resize_nearest(g[f"s{i}_msk"], h, w), g[f"s{i}_nearest"])
+    for i in range(4):
+        hs, ws, h, w = (int(v) for v in g[f"f{i}_dims"])
+        b = P.resize_bilinear(synth_u8.image(200 + i, hs, ws), h, w)
+        n = P.resize_nearest(synth_u8.mask(200 + i, hs, ws), h, w)
+        assert zlib.crc32(b.tobytes()) == int(g[f"f{i}_bilinear_crc"]) and np.array_equal(b[::13, ::11], g[f"f{i}_bilinear_s"])
+        assert zlib.crc32(n.tobytes()) == int(g[f"f{i}_nearest_crc"]) and np.array_equal(n[::13, ::11], g[f"f{i}_nearest_s"])
+    for i in range(4):
+        out = P.color_jitter(g["j_img"], tuple(int(v) for v in g[f"j{i}_order"]), tuple(float(v) for v in g[f"j{i}_factors"]))
+        assert np.array_equal(out, g[f"j{i}_out"])
+    assert np.array_equal(P.to_gray(g["j_img"]), g["gray"]) and np.array_equal(P.hflip(g["j_img"]), g["hflip"])
+
+
+def test_pil_oracle_matches_live_pillow_when_present():
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    from oracle import pil_ops as P
+    from pemp_amd.data_kits import synth_u8
+    for seed, (hs, ws, h, w) in enumerate([(77, 130, 97, 97), (300, 210, 97, 140), (40, 41, 120, 123), (500, 375, 401, 401)]):
+        img, msk = synth_u8.image(seed, hs, ws), synth_u8.mask(seed, hs, ws)
+        assert np.array_equal(P.resize_bilinear(img, h, w), np.asarray(Image.fromarray(img).resize((w, h), Image.BILINEAR)))
+        assert np.array_equal(P.resize_nearest(msk, h, w), np.asarray(Image.fromarray(msk).resize((w, h), Image.NEAREST)))
+
+
+def test_episode_plan_and_host_draws(hip_lib):
+    import ctypes as C
+    import random
+    from pemp_amd._lib import SampleDesc
+    from pemp_amd.data_kits import synth_u8
+    from pemp_amd.data_kits.episode import crop_obj_origin, nearest_index, train_samples
+    from oracle import pil_ops as P
+    lib = hip_lib
+    assert C.sizeof(SampleDesc) == 96
+    d = (SampleDesc * 2)()
+    for i, (hs, ws) in enumerate(((375, 500), (500, 333))):
+        d[i].img_off, d[i].msk_off, d[i].hs, d[i].ws, d[i].sh, d[i].sw, d[i].mask_mode = 0, 0, hs, ws, 401, 401, 1
+    assert lib.pemp_episode_plan(d, 2, 401, 401) > 2 * (375 * 401 * 3 + 401 * 401 * 3)
+    assert (d[0].ksx, d[0].ksy, d[1].ksx, d[1].ksy) == (5, 3, 3, 5) and d[1].ws_off > 0
+    d[0].oy = 1
+    assert lib.pemp_episode_plan(d, 2, 401, 401) == 0 and b"crop window" in lib.pemp_last_error()
+    for a, b in ((500, 401), (90, 457), (401, 401)):
+        assert np.array_equal(nearest_index(a, b), P.nearest_index(a, b))
+    # crop_obj: small object -> the window is drawn around it; draws are reproducible from the seed
+    m = np.zeros((140, 150), np.uint8)
+    m[100:110, 120:130] = 255
+    for s in range(20):
+        oy, ox = crop_obj_origin(m, 97, 97, random.Random(s))
+        assert 0 <= oy <= 43 and 0 <= ox <= 53 and m[oy:oy + 97, ox:ox + 97].any()
+    sup = [(synth_u8.image(1, 120, 160), synth_u8.mask(1, 120, 160))]
+    qry = [(synth_u8.image(3, 200, 150), synth_u8.mask(3, 200, 150))]
+    a, b = train_samples(sup, qry, 97, 97, random.Random(5)), train_samples(sup, qry, 97, 97, random.Random(5))
+    assert [(s.scaled, s.crop, s.flip, s.jitter) for s in a] == [(s.scaled, s.crop, s.flip, s.jitter) for s in b]
+    assert 97 <= a[0].scaled[0] <= 145 and a[1].scaled == (97, 97) and a[1].mask_mode == 2
+    assert sorted(a[0].jitter[0]) == ["brightness", "contrast", "saturation"]
