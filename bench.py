@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-episodes", type=int, default=12, help="bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the staging-inclusive end_to_end figure")
     return ap.parse_args()
 
 
@@ -181,6 +182,54 @@ def cpu_baseline(sd, shot, n_eps):
     return {"value": round(len(times) / tot, 3), "unit": "episodes/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} episodes (seeds 5679..), oracle/ref_cpu.py test_step, torch {torch.__version__} CPU, "
                       f"{cores} threads, median {np.median(times) * 1e3:.0f} ms/episode"}
+
+
+def end_to_end(net, args, dev):
+    """Episodes/s INCLUDING input staging (SURVEY.md §8d ii): decoded uint8 samples in host memory -> one
+    pinned blob per step -> async H2D -> Pillow-exact resize/normalise on the device (pemp_episode_preprocess)
+    -> the same eval step, double-buffered on a side stream.  JPEG decode is not included (no dataset)."""
+    from pemp_amd import ops
+    from pemp_amd.data_kits import synth_u8
+    from pemp_amd.data_kits.episode import EpisodeLoader, EpisodeTransform, test_samples
+    B, S = args.batch, args.shot
+    sizes = [(375, 500), (333, 500), (500, 375), (366, 500), (457, 500)]
+    raw = []
+    for g in range(3):
+        hs, ws = sizes[g]
+        imgs = [(synth_u8.image(10 * g + k, hs, ws), synth_u8.mask(10 * g + k, hs, ws)) for k in range(S + 1)]
+        batch = []
+        for _ in range(B):
+            batch += test_samples(imgs[:S], imgs[S:], 401, 401)
+        raw.append(batch)
+    steps = max(6, min(args.steps, 20))
+    ws_cache = {}
+
+    def batches():
+        for i in range(steps + 2):
+            yield raw[i % len(raw)]
+
+    def consume(out):
+        img, planes, labels = out
+        img = img.view(B, S + 1, 3, 401, 401)
+        with torch.no_grad():
+            pred, _ = net.lowres_graphed(img[:, :S].contiguous(), planes.view(B, S, 2, 401, 401), img[:, S:].contiguous())
+            return ops.eval_tail(pred, torch.stack(labels), ws_cache=ws_cache)[1]
+
+    loader = EpisodeLoader(batches(), EpisodeTransform(401, 401, device=dev))
+    stats = [consume(next(loader)) for _ in range(2)]                      # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for out in loader:
+        stats.append(consume(out))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = torch.stack(stats).cpu().numpy()
+    assert np.isfinite(st).all() and (st[..., 1] > 0).all()
+    per_ep = sum(s.img.size + (s.mask.size if s.mask is not None else 0) for s in raw[0]) / B
+    return {"value": round(steps * B / dt, 2), "unit": "episodes/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "h2d_bytes_per_episode": int(per_ep),
+            "path": "host uint8 (decoded) -> pinned blob -> async H2D -> device resize/normalise -> eval step; "
+                    "double-buffered on a side stream; JPEG decode excluded"}
 
 
 def main_train(args, world, rank, dev):
@@ -332,6 +381,8 @@ def main():
         }
         if not args.no_roofline and stage2 is None:
             out["roofline"] = conv_roofline(net, pool)
+        if world == 1 and stage2 is None and not args.no_graph and not args.no_e2e:
+            out["end_to_end"] = end_to_end(net, args, dev)
         if world == 1 and args.cpu_episodes > 0:
             out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in sd.items()}, args.shot, args.cpu_episodes)
     if world > 1:

@@ -190,31 +190,51 @@ __device__ __forceinline__ unsigned char blend8(float deg, float v, float a, boo
     return t <= 0.f ? 0 : (t >= 255.f ? 255 : (unsigned char)(int)t);
 }
 
+// 4 pixels (12 bytes = three aligned dwords of the flat byte image) per thread.
 __global__ __launch_bounds__(256) void jitter_kernel(const pemp_sample_desc* __restrict__ descs, char* __restrict__ ws, int stage) {
-    const pemp_sample_desc d = descs[blockIdx.y];
-    const int op = (d.jitter_order >> (2 * stage)) & 3;
-    if (d.img_off < 0 || op == 0) return;
-    const long long idx = blockIdx.x * 256LL + threadIdx.x;
-    if (idx >= (long long)d.sh * d.sw) return;
+    const pemp_sample_desc* dp = descs + blockIdx.y;
+    const int op = (dp->jitter_order >> (2 * stage)) & 3;
+    if (dp->img_off < 0 || op == 0) return;
+    const long long total = (long long)dp->sh * dp->sw;
+    const long long px0 = (blockIdx.x * 256LL + threadIdx.x) * 4;
+    if (px0 >= total) return;
+    const pemp_sample_desc d = *dp;
     const SampleLayout L = sample_layout(d);
     char* base = ws + d.ws_off;
-    unsigned char* p = (unsigned char*)(base + L.res) + idx * 3;
-    const float a = d.jitter[op - 1];
+    const float a = op == 1 ? d.jitter[0] : (op == 2 ? d.jitter[1] : d.jitter[2]);
     const bool interp = a >= 0.f && a <= 1.f;
-    const int r = p[0], g = p[1], b = p[2];
-    float d0, d1, d2;
-    if (op == 1) {
-        d0 = d1 = d2 = 0.f;                                                   // Brightness: black image
-    } else if (op == 2) {                                                     // Contrast: int(mean(L) + 0.5) everywhere
+    float cmean = 0.f;
+    if (op == 2) {                                                            // Contrast: int(mean(L) + 0.5) everywhere
         const unsigned long long s = *(const unsigned long long*)(base + L.gsum);
-        const double m = __dadd_rn(__ddiv_rn((double)s, (double)((long long)d.sh * d.sw)), 0.5);
-        d0 = d1 = d2 = (float)(int)m;
-    } else {
-        d0 = d1 = d2 = (float)rgb2l(r, g, b);                                 // Color: the gray image
+        cmean = (float)(int)__dadd_rn(__ddiv_rn((double)s, (double)total), 0.5);
     }
-    p[0] = blend8(d0, (float)r, a, interp);
-    p[1] = blend8(d1, (float)g, a, interp);
-    p[2] = blend8(d2, (float)b, a, interp);
+    unsigned char* p = (unsigned char*)(base + L.res) + px0 * 3;
+    unsigned char v[12];
+    const int npx = total - px0 >= 4 ? 4 : (int)(total - px0);
+    if (npx == 4) {
+        const unsigned int* q = (const unsigned int*)p;
+        *(unsigned int*)(v + 0) = q[0];
+        *(unsigned int*)(v + 4) = q[1];
+        *(unsigned int*)(v + 8) = q[2];
+    } else {
+        for (int i = 0; i < npx * 3; ++i) v[i] = p[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = v[i * 3], g = v[i * 3 + 1], b = v[i * 3 + 2];
+        const float deg = op == 1 ? 0.f : (op == 2 ? cmean : (float)rgb2l(r, g, b));   // black / mean gray / gray image
+        v[i * 3 + 0] = blend8(deg, (float)r, a, interp);
+        v[i * 3 + 1] = blend8(deg, (float)g, a, interp);
+        v[i * 3 + 2] = blend8(deg, (float)b, a, interp);
+    }
+    if (npx == 4) {
+        unsigned int* q = (unsigned int*)p;
+        q[0] = *(unsigned int*)(v + 0);
+        q[1] = *(unsigned int*)(v + 4);
+        q[2] = *(unsigned int*)(v + 8);
+    } else {
+        for (int i = 0; i < npx * 3; ++i) p[i] = v[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -355,7 +375,7 @@ extern "C" int pemp_episode_preprocess(const uint8_t* blob, const pemp_sample_de
         hipLaunchKernelGGL(vpass_kernel, dim3((unsigned)((max_v + 255) / 256), n), dim3(256), 0, st, dd, wsc);
         for (int s = 0; s < stages; ++s) {
             hipLaunchKernelGGL(gray_sum_kernel, dim3(64, n), dim3(256), 0, st, dd, wsc, s);
-            hipLaunchKernelGGL(jitter_kernel, dim3((unsigned)((max_v + 255) / 256), n), dim3(256), 0, st, dd, wsc, s);
+            hipLaunchKernelGGL(jitter_kernel, dim3((unsigned)((max_v + 1023) / 1024), n), dim3(256), 0, st, dd, wsc, s);
         }
         Norm3 nm;
         for (int c = 0; c < 3; ++c) nm.mean[c] = mean[c], nm.std[c] = std[c];

@@ -72,6 +72,21 @@ class SyntheticEpisodes:
         return (t(ep["sup_img"]), t(ep["sup_mask"]), t(ep["qry_img"])), t(ep["qry_mask"]), torch.tensor([ep["cls"]])
 
 
+class SyntheticDecodedEpisodes(SyntheticEpisodes):
+    """Same protocol, but an episode is what the reference's loader holds right after ``Image.open``: uint8
+    HWC images and uint8 {0,255} label images at their own sizes (pemp_amd.data_kits.synth_u8).  The
+    evaluator then runs resize / normalise / mask planes on the device (pemp_amd.data_kits.episode)."""
+    SIZES = ((375, 500), (333, 500), (500, 375), (366, 500), (457, 500))
+
+    def decoded_task(self, i):
+        from ..data_kits import synth_u8
+        seed = self.test_seed + self.round * self.test_n + i
+        hs, ws = self.SIZES[seed % len(self.SIZES)]
+        pairs = [(synth_u8.image(seed * 8 + k, hs, ws), synth_u8.mask(seed * 8 + k, hs, ws)) for k in range(self.shot + 1)]
+        cls = get_val_labels(self.split)[seed % 5] if self.split >= 0 else 1
+        return pairs[:self.shot], pairs[self.shot:], cls
+
+
 def shard_indices(n, rank, world):
     """Episode indices of one rank: every rank builds the same task list and takes tasks[rank::world]."""
     return range(rank, n, world)
@@ -115,6 +130,27 @@ class Evaluator:
         loss = float(st[:, 0].sum() / max(st[:, 1].sum(), 1.0))
         return am.cpu().numpy(), loss
 
+    def _episodes(self, dataset, indices):
+        """(inputs, qry_msk, cls) per episode.  Datasets with ``decoded_task`` (uint8 sources) go through the
+        double-buffered device-side input pipeline: episode i+1 is uploaded and preprocessed on a side stream
+        while episode i is evaluated."""
+        if not hasattr(dataset, "decoded_task"):
+            for i in indices:
+                yield dataset.task(i)
+            return
+        from ..data_kits.episode import EpisodeLoader, EpisodeTransform, test_samples
+        H, W, S = dataset.height, dataset.width, dataset.shot
+        classes = []
+
+        def batches():
+            for i in indices:
+                sup, qry, cls = dataset.decoded_task(i)
+                classes.append(cls)
+                yield test_samples(sup, qry, H, W)
+
+        for k, (img, planes, labels) in enumerate(EpisodeLoader(batches(), EpisodeTransform(H, W, device=self.device))):
+            yield (img[:S][None], planes[None], img[S:][None]), labels[0][None, None], torch.tensor([classes[k]])
+
     def start_eval_loop(self, dataset, num_classes, split, te_epochs=5, logger=None):
         """Reference loop (core/base_trainer.py:59-102), sharded over ranks."""
         self.model.eval()
@@ -128,8 +164,7 @@ class Evaluator:
             metric = FewShotMetric(num_classes)
             dataset.sample_tasks()
             rows, classes = [], []
-            for i in shard_indices(len(dataset), rank, world):
-                inputs, qry_msk, cls = dataset.task(i)
+            for inputs, qry_msk, cls in self._episodes(dataset, shard_indices(len(dataset), rank, world)):
                 t0 = time.time()
                 _, stats = self.test_step_device(inputs, qry_msk)
                 timed += time.time() - t0
