@@ -44,7 +44,9 @@ typedef struct pemp_conv_desc {
     int32_t ldr;            /* residual per-pixel stride (ignored when residual == NULL)         */
     int32_t Kpad;           /* weight row length in floats (>= KH*KW*Cin, multiple of 32)        */
     uint32_t flags;
-    int32_t tile;           /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile           */
+    int32_t tile;           /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile (register staging);
+                               11..13 the same with LDS-DMA staging; 14/15 = 128x128 / 128x64, 8 waves;
+                               16/17 = 256x128 / 256x256, 8 waves (all bit-identical results)      */
 } pemp_conv_desc;
 
 const char* pemp_last_error(void);

@@ -230,6 +230,8 @@ static int launch_dma(const ConvArgs& a, hipStream_t st) {
 
 int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st) {
     const bool stem = a.flags & PEMP_CONV_STEM4;
+    if (tile == 7) return stem ? launch_dma<256, 256, 4, true, 8>(a, st) : launch_dma<256, 256, 4, false, 8>(a, st);
+    if (tile == 6) return stem ? launch_dma<256, 128, 4, true, 8>(a, st) : launch_dma<256, 128, 4, false, 8>(a, st);
     if (tile == 4) return stem ? launch_dma<128, 128, 4, true, 8>(a, st) : launch_dma<128, 128, 4, false, 8>(a, st);
     if (tile == 5) return stem ? launch_dma<128, 64, 4, true, 8>(a, st) : launch_dma<128, 64, 4, false, 8>(a, st);
     if (tile == 1) return stem ? launch_dma<128, 128, 2, true>(a, st) : launch_dma<128, 128, 2, false>(a, st);

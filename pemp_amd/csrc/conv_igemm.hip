@@ -292,8 +292,9 @@ extern "C" int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, con
         tile = 3;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (tile >= 11 && tile <= 15) {      // LDS-DMA staging variants (conv_dma.hip); 14/15: 8-wave blocks
-        PEMP_REQUIRE((tile != 11 && tile != 14) || a.Cout % 128 == 0, "conv2d: tile 128x128 needs Cout %% 128 == 0");
+    if (tile >= 11 && tile <= 17) {      // LDS-DMA staging variants (conv_dma.hip); 14..17: 8-wave blocks, 16: 256x128, 17: 256x256
+        PEMP_REQUIRE((tile != 11 && tile != 14 && tile != 16) || a.Cout % 128 == 0, "conv2d: tile N=128 needs Cout %% 128 == 0");
+        PEMP_REQUIRE(tile != 17 || a.Cout % 256 == 0, "conv2d: tile 256x256 needs Cout %% 256 == 0");
         return launch_conv_dma(tile - 10, a, st);
     }
     if (tile == 1) {

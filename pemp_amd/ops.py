@@ -63,7 +63,8 @@ class ConvParams:
 
 #: kernel variants the autotuner may pick: id -> (BM, BN); ids >= 11 stage through LDS-DMA.  All variants
 #: accumulate in the same K order, so they are bit-identical and the choice only affects speed.
-TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15: (128, 64), 3: (64, 64)}
+TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15: (128, 64), 3: (64, 64),
+                 17: (256, 256), 16: (256, 128)}    # 16/17: 8-wave blocks, 98/131 KB LDS, half the L2->LDS bytes per flop
 AUTOTUNE = True
 DEFAULT_TILE = 13
 _TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared by every ConvParams object

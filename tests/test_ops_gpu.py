@@ -38,13 +38,14 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dma", [0, 10, 14, 15])
+@pytest.mark.parametrize("dma", [0, 10, 14, 15, 16, 17])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_generic(hip_lib, dev, case, dma):
     from pemp_amd import ops
     N, H, W, Cin, Cout, k, s, p, d, tile = case
     if dma >= 14:                       # 8-wave LDS-DMA blocks: 128x128 (needs Cout % 128 == 0) / 128x64
-        tile = dma if (dma == 15 or Cout % 128 == 0) else 15
+        need = {14: 128, 15: 64, 16: 128, 17: 256}[dma]     # 16 / 17: 256x128 / 256x256 tiles (98 / 131 KB of LDS)
+        tile = dma if Cout % need == 0 else 15
     else:
         tile = tile + dma if tile else (13 if dma else 0)
     x = _rand(N, Cin, H, W, seed=1)
