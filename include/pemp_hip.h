@@ -231,6 +231,29 @@ int pemp_sgd_clip_step_f32(float* params, const float* grads, float* momentum_bu
                            float grad_scale, int nesterov, float* grad_norm_out, void* ws, size_t ws_bytes,
                            void* stream);
 
+/* Train-time regularisers.  Random numbers: counter-based Philox4x32-10, element i of stream (seed, offset)
+ * (reproducible across launches / graph replays; the reference's torch generator stream is not reproducible,
+ * so the DRAWS are parity-unpinned).  `uniforms` != NULL substitutes caller-provided U[0,1) numbers -- that is
+ * how the tests check the arithmetic exactly.
+ *
+ * DropBlock2D.forward (dropblock==0.3.0; call sites networks/pemp_stage1.py:76,79; backbones.py:329-353):
+ *   seed map (u < drop_prob / block_size^2) per (image, y, x), dilated by max_pool2d(block_size, 1, block_size/2)
+ *   (cropped for even sizes); mask = 1 - dilated [N][H][W]; kept_count[0] = sum(mask) (int, exact).           */
+/*   step (device pointer or NULL): the stream offset becomes offset + (*step << 20), so a captured hipGraph draws
+ *   fresh numbers on every replay once the caller increments *step.                                          */
+int pemp_dropblock_mask_f32(float* mask, int* kept_count, const float* uniforms, int N, int H, int W,
+                            float drop_prob, int block_size, uint64_t seed, uint64_t offset,
+                            const uint64_t* step, void* stream);
+/*   y[m][c] = ((x[m][c] * mask[m]) * M) / kept_count   (the layer's forward AND its backward)               */
+int pemp_pixel_scale_f32(const float* x, int ldx, const float* mask, const int* kept_count, float* y, int ldy,
+                         long long M, int C, void* stream);
+/* nn.Dropout2d(p) in train() (networks/pemp_stage2.py:67,70; backbones.py:284-305):
+ *   mask[n][c] = (u < 1 - p) / (1 - p);   y[n][i][c] = x[n][i][c] * mask[n][c]  (forward and backward)      */
+int pemp_dropout2d_mask_f32(float* mask, const float* uniforms, int N, int C, float p, uint64_t seed,
+                            uint64_t offset, const uint64_t* step, void* stream);
+int pemp_channel_scale_f32(const float* x, int ldx, const float* mask, float* y, int ldy, int N, int HW, int C,
+                           void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Episode input pipeline on the device: everything
  * PascalVOCTrain._get_episode (data_kits/pascal_voc.py:185-237) does AFTER the JPEG/PNG decode, on

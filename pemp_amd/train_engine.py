@@ -151,23 +151,6 @@ class _BN:
             self.bn.bias.grad.copy_(dbeta)
 
 
-# ---------------------------------------------------------------------------------------------
-# DropBlock (dropblock==0.3.0 semantics; train only).  The random seed map comes from torch's device
-# RNG; its stream cannot match the reference's (third-party source absent) -- parity unpinned.
-# ---------------------------------------------------------------------------------------------
-def dropblock_rowscale(n, h, w, drop_prob, block_size, device, generator=None):
-    """-> per-pixel multiplier [n*h*w] = block_mask * numel / sum(block_mask), or None if drop_prob == 0."""
-    if drop_prob <= 0.0:
-        return None
-    gamma = drop_prob / (block_size ** 2)
-    seed = (torch.rand((n, 1, h, w), device=device, generator=generator) < gamma).float()
-    bm = F.max_pool2d(seed, kernel_size=block_size, stride=1, padding=block_size // 2)
-    if block_size % 2 == 0:
-        bm = bm[:, :, :-1, :-1]
-    bm = 1.0 - bm
-    return (bm * (bm.numel() / bm.sum())).reshape(-1).contiguous()
-
-
 class Stage1TrainEngine:
     """Forward + backward of the stage-1 ResNet-50 encoder in train mode on HIP kernels."""
 
@@ -181,6 +164,7 @@ class Stage1TrainEngine:
                 p.data = p.data.to(device)
         self.ws = {}
         self.drop_rate, self.block_size = 0.0, 4
+        self.rng = T.RandomStream(torch.initial_seed(), device)      # Philox stream of the DropBlock / Dropout2d kernels
         self._init_trunk(model.encoder.backbone)
         self._init_tail(model)
         self.flat.build_dgrad_mirror()
@@ -209,6 +193,17 @@ class Stage1TrainEngine:
     # -- helpers ------------------------------------------------------------------------------
     def _new(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _dropblock(self, x, n, h, w):
+        """DropBlock2D(drop_rate, block_size) in train(): -> (y, record for the backward) (identity at rate 0)."""
+        if self.drop_rate <= 0.0:
+            return x, None
+        rec = T.dropblock_mask(n, h, w, self.drop_rate, self.block_size, self.rng, self.device)
+        return T.pixel_scale(x, *rec), rec
+
+    @staticmethod
+    def _dropblock_bwd(dy, rec):
+        return dy if rec is None else T.pixel_scale(dy, *rec)
 
     def _cbn_fwd(self, x, conv, bn, relu, residual=None, img_bias=None):
         """conv -> (+ per-image bias [N,Cout]) -> batch-stat BN (+residual)(+ReLU); returns (y, tape record)."""
@@ -260,6 +255,7 @@ class Stage1TrainEngine:
         if self.bn_counters:
             torch._foreach_add_(self.bn_counters, 1)        # every BatchNorm runs exactly once per step
         self.flat.refresh_dgrad_mirror()
+        self.rng.begin_step()          # a device-side increment: also advances inside a replayed hipGraph
         x = self._trunk_forward(images_list, tape, **kw)
         feat = self._tail_forward(x, tape)
         self.tape = tape
@@ -292,19 +288,16 @@ class Stage1TrainEngine:
         # purifier: conv+bias+ReLU (+DropBlock) twice
         nimg, h, w, _ = x.shape
         ya = ops.conv2d(x, self.p0.fwd_params(relu=True))
-        da = dropblock_rowscale(nimg, h, w, self.drop_rate, self.block_size, self.device)
-        xa = ya if da is None else ya * da.view(nimg, h, w, 1)
+        xa, da = self._dropblock(ya, nimg, h, w)
         yb = ops.conv2d(xa, self.p3.fwd_params(relu=True))
-        db = dropblock_rowscale(nimg, h, w, self.drop_rate, self.block_size, self.device)
-        xb = yb if db is None else yb * db.view(nimg, h, w, 1)
+        xb, db = self._dropblock(yb, nimg, h, w)
         tape.update(p0_in=x, ya=ya, da=da, xa=xa, yb=yb, db=db, xb=xb)
         # ASPPV2: five BNs share the statistics of xb (branch 0: of its global average)
         midc = self.midc
         gap = ops.global_avgpool(xb)
         m0, i0 = self.aspp_bn[0].stats(gap, self.ws)
         t0 = T.bn_apply(gap, m0, i0, self.aspp_bn[0].bn.weight.data, self.aspp_bn[0].bn.bias.data, torch.empty_like(gap), relu=False)
-        d0 = dropblock_rowscale(nimg, 1, 1, self.drop_rate, self.block_size, self.device)
-        t0d = t0 if d0 is None else t0 * d0.view(nimg, 1)
+        t0d, d0 = self._dropblock(t0, nimg, 1, 1)
         g0 = ops.conv2d(t0d.view(nimg, 1, 1, -1), self.aspp_conv[0].fwd_params(relu=True))
         l6w = self.l6.weight
         w6 = self.flat.krsc(l6w)                                   # [512, 1280]
@@ -319,8 +312,7 @@ class Stage1TrainEngine:
             # that BN's own running statistics
             mean_x, invstd_x = bn.stats(xb, self.ws)
             t = T.bn_apply(xb, mean_x, invstd_x, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(xb), relu=False)
-            d = dropblock_rowscale(nimg, h, w, self.drop_rate, self.block_size, self.device)
-            td = t if d is None else t * d.view(nimg, h, w, 1)
+            td, d = self._dropblock(t, nimg, h, w)
             ops.conv2d(td, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
             ts.append(td)
             ds_.append(d)
@@ -363,8 +355,7 @@ class Stage1TrainEngine:
             conv.conv.bias.grad.copy_(db)
             conv.wgrad(tp["ts"][i - 1], g, self.ws)
             dt = ops.conv2d(g, conv.dgrad_params())
-            if tp["ds"][i - 1] is not None:
-                dt = dt * tp["ds"][i - 1].view(nimg, h, w, 1)
+            dt = self._dropblock_bwd(dt, tp["ds"][i - 1])
             dz = self._new(nimg, h, w, dt.shape[-1])
             dgamma, dbeta = T.bn_bwd(dt, None, tp["xb"], tp["mean_x"], tp["invstd_x"], bn.bn.weight.data, dz, relu=False, ws_cache=self.ws)
             bn.write_grads(dgamma, dbeta)
@@ -379,21 +370,18 @@ class Stage1TrainEngine:
         conv0.conv.bias.grad.copy_(db)
         conv0.wgrad(tp["t0d"].view(nimg, 1, 1, -1), g, self.ws)
         dt0 = ops.conv2d(g, conv0.dgrad_params()).view(nimg, -1)
-        if tp["d0"] is not None:
-            dt0 = dt0 * tp["d0"].view(nimg, 1)
+        dt0 = self._dropblock_bwd(dt0, tp["d0"])
         dgap = self._new(nimg, dt0.shape[1])
         dgamma, dbeta = T.bn_bwd(dt0, None, tp["gap"], tp["m0"], tp["i0"], bn0.bn.weight.data, dgap, relu=False, ws_cache=self.ws)
         bn0.write_grads(dgamma, dbeta)
         T.gap_bwd_add(dgap, dxb)
         # purifier.3 and purifier.0 (conv + bias + ReLU (+ DropBlock))
-        if tp["db"] is not None:
-            dxb = dxb * tp["db"].view(nimg, h, w, 1)
+        dxb = self._dropblock_bwd(dxb, tp["db"])
         g = torch.empty_like(tp["yb"])
         self.p3.conv.bias.grad.copy_(T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws))
         self.p3.wgrad(tp["xa"], g, self.ws)
         dxa = ops.conv2d(g, self.p3.dgrad_params())
-        if tp["da"] is not None:
-            dxa = dxa * tp["da"].view(nimg, h, w, 1)
+        dxa = self._dropblock_bwd(dxa, tp["da"])
         g = torch.empty_like(tp["ya"])
         self.p0.conv.bias.grad.copy_(T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws))
         self.p0.wgrad(tp["p0_in"], g, self.ws)

@@ -149,6 +149,74 @@ def gap_bwd_add(v, dst):
     return dst
 
 
+class RandomStream:
+    """(seed, offset) of the Philox stream the regulariser kernels draw from; every mask advances the offset,
+    so successive layers and steps see different numbers and a re-seeded run repeats exactly."""
+
+    def __init__(self, seed=0, device=None):
+        self.seed, self.offset = int(seed) & (2 ** 64 - 1), 0
+        # device-side step counter (added to the offset as step << 20 inside the kernels): lets a captured
+        # hipGraph, whose kernel arguments are frozen, draw new numbers on every replay
+        self.step = torch.zeros(1, dtype=torch.int64, device=device) if device is not None else None
+
+    def next(self):
+        self.offset += 1
+        return self.seed, self.offset
+
+    def begin_step(self):
+        """Call once per training step (outside any graph capture)."""
+        self.offset = 0
+        if self.step is not None:
+            self.step += 1
+
+
+def dropblock_mask(n, h, w, drop_prob, block_size, rs, device, uniforms=None):
+    """-> (mask fp32 [n,h,w] in {0,1}, kept_count int32 [1]) of one DropBlock2D call."""
+    lib = _lib.load()
+    mask = torch.empty((n, h, w), dtype=torch.float32, device=device)
+    cnt = torch.empty(1, dtype=torch.int32, device=device)
+    seed, off = rs.next()
+    _lib.check(lib.pemp_dropblock_mask_f32(_p(mask), _p(cnt), _p(uniforms), n, h, w, float(drop_prob), int(block_size),
+                                           seed, off, _p(rs.step), _stream()), "dropblock_mask")
+    return mask, cnt
+
+
+def pixel_scale(x, mask, cnt, out=None):
+    """((x * mask[pixel]) * numel(mask)) / sum(mask): DropBlock2D forward and backward."""
+    lib = _lib.load()
+    _chk_dev(x, mask, cnt)
+    m, c, ldx = _rows(x, "x")
+    if mask.numel() != m:
+        raise ValueError("pixel_scale: mask has a different pixel count")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.check(lib.pemp_pixel_scale_f32(_p(x), ldx, _p(mask), _p(cnt), _p(out), _rows(out, "out")[2], m, c, _stream()),
+               "pixel_scale")
+    return out
+
+
+def dropout2d_mask(n, c, p, rs, device, uniforms=None):
+    lib = _lib.load()
+    mask = torch.empty((n, c), dtype=torch.float32, device=device)
+    seed, off = rs.next()
+    _lib.check(lib.pemp_dropout2d_mask_f32(_p(mask), _p(uniforms), n, c, float(p), seed, off, _p(rs.step), _stream()),
+               "dropout2d_mask")
+    return mask
+
+
+def channel_scale(x, mask, out=None):
+    """x[n,h,w,c] * mask[n,c]: Dropout2d forward and backward."""
+    lib = _lib.load()
+    _chk_dev(x, mask)
+    from .ops import _nhwc
+    n, h, w, c = x.shape
+    if tuple(mask.shape) != (n, c):
+        raise ValueError("channel_scale: mask must be [N, C]")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.check(lib.pemp_channel_scale_f32(_p(x), _nhwc(x, "x"), _p(mask), _p(out), _nhwc(out, "out"), n, h * w, c, _stream()),
+               "channel_scale")
+    return out
+
+
 def cm_bwd_add(x, mask, dstat, dx):
     """Backward of ``ops.cm_reduce``'s statistics: dx += mask * (dmean/HW + onehot(argmax) * dmax).
     x, dx: NHWC [N,h,w,C]; mask: the pooled mask cm_reduce returned [N,h,w]; dstat [N,2,C]."""

@@ -14,7 +14,7 @@ What differs from stage 1 (pemp_amd/train_engine.py), and how it is laid out her
   are differentiated explicitly (``pemp_cm_bwd_add_f32`` routes the max gradient to the arg-max pixel);
 * the block BatchNorms are trainable here (only the stem / downsample BNs are frozen, backbones.py:175-202);
 * the purifier uses ``ASPP`` (conv -> ReLU -> Dropout2d, no BN; backbones.py:279-321) and Dropout2d(drop_rate2);
-  the channel masks come from torch's device RNG (parity unpinned, like DropBlock in stage 1);
+  the channel masks are drawn by the Philox kernels of dropout.hip (draws parity-unpinned, like DropBlock);
 * gradients are clipped only for the VGG variant (entry/pemp_stage2.py:79-81), i.e. never for ResNet-50.
 """
 import torch
@@ -60,13 +60,6 @@ class _ConvCM(_Conv):
         """colsum [N,Cout] = per-image sums of dz; writes the grads of the comm columns, returns dfeat_img [N,2]."""
         self.flat.krsc_grad(self.conv.weight)[:, self.creal:].copy_(colsum.t() @ feat_img)
         return colsum @ self.wext
-
-
-def dropout2d_scale(n, c, p, device):
-    """nn.Dropout2d(p) in train(): one Bernoulli(1-p)/(1-p) multiplier per (image, channel), or None."""
-    if p <= 0.0:
-        return None
-    return torch.bernoulli(torch.full((n, c), 1.0 - p, device=device)) / (1.0 - p)
 
 
 class Stage2TrainEngine(Stage1TrainEngine):
@@ -150,8 +143,15 @@ class Stage2TrainEngine(Stage1TrainEngine):
 
     # -- purifier: conv+ReLU+Dropout2d twice, ASPP (no BN), layer6 ------------------------------
     def _drop(self, y, n, c):
-        m = dropout2d_scale(n, c, self.drop_rate2, self.device)
-        return (y if m is None else y * m.view(n, 1, 1, c)), m
+        """nn.Dropout2d(drop_rate2) in train(): one Bernoulli(1-p)/(1-p) multiplier per (image, channel)."""
+        if self.drop_rate2 <= 0.0:
+            return y, None
+        m = T.dropout2d_mask(n, c, self.drop_rate2, self.rng, self.device)
+        return T.channel_scale(y, m), m
+
+    @staticmethod
+    def _drop_bwd(dy, m):
+        return dy if m is None else T.channel_scale(dy, m)
 
     def _tail_forward(self, x, tape):
         nimg, h, w, _ = x.shape
@@ -168,11 +168,9 @@ class Stage2TrainEngine(Stage1TrainEngine):
         w6g = ConvParams(w6[:, :midc].contiguous(), None, self.l6.bias.data, midc, l6w.shape[0], 1, 1, 1, 0, 1, midc, False, False)
         bias6 = ops.conv2d(g0d, w6g)
         cat = self._new(nimg, h, w, 4 * midc)                                 # post-ReLU branch outputs u_i
-        ms = []
         for i in range(1, 5):
             ops.conv2d(xb, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
-            ms.append(dropout2d_scale(nimg, midc, self.drop_rate2, self.device))
-        catd = cat if ms[0] is None else cat * torch.cat(ms, dim=1).view(nimg, 1, 1, 4 * midc)
+        catd, ms = self._drop(cat, nimg, 4 * midc)                            # the four branch Dropout2d layers at once
         w6m = ConvParams(w6[:, midc:].contiguous(), None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False)
         feat = ops.conv2d(catd, w6m, shift_override=bias6.view(nimg, -1), per_image_shift=True)
         tape.update(p0_in=x, ya=ya, ma=ma, xa=xa, yb=yb, mb=mb, xb=xb, gap=gap, g0=g0, m0=m0, g0d=g0d, cat=cat, catd=catd,
@@ -200,8 +198,7 @@ class Stage2TrainEngine(Stage1TrainEngine):
         dw6[:, :midc].copy_(dw6g)
         dg0 = ops.conv2d(s.view(nimg, 1, 1, -1), ConvParams(T.dgrad_weight(w6[:, :midc].contiguous(), 1, 1), None, None, cout,
                                                             midc, 1, 1, 1, 0, 1, cout, False, False))
-        if tp["ms"][0] is not None:
-            dcat = dcat * torch.cat(tp["ms"], dim=1).view(nimg, 1, 1, 4 * midc)
+        dcat = self._drop_bwd(dcat, tp["ms"])
         dxb = None
         for i in range(1, 5):
             conv = self.aspp_conv[i]
@@ -211,20 +208,17 @@ class Stage2TrainEngine(Stage1TrainEngine):
             conv.wgrad(tp["xb"], g, self.ws)
             dxb = ops.conv2d(g, conv.dgrad_params(), residual=dxb)            # branch gradients accumulate in the epilogue
         conv0 = self.aspp_conv[0]
-        if tp["m0"] is not None:
-            dg0 = dg0 * tp["m0"].view(nimg, 1, 1, midc)
+        dg0 = self._drop_bwd(dg0, tp["m0"])
         g = self._new(nimg, 1, 1, midc)
         conv0.conv.bias.grad.copy_(T.relu_bias_bwd(dg0, tp["g0"], g, relu=True, ws_cache=self.ws))
         conv0.wgrad(tp["gap"].view(nimg, 1, 1, -1), g, self.ws)
         T.gap_bwd_add(ops.conv2d(g, conv0.dgrad_params()).view(nimg, -1), dxb)
-        if tp["mb"] is not None:
-            dxb = dxb * tp["mb"].view(nimg, 1, 1, -1)
+        dxb = self._drop_bwd(dxb, tp["mb"])
         g = torch.empty_like(tp["yb"])
         self.p3.conv.bias.grad.copy_(T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws))
         self.p3.wgrad(tp["xa"], g, self.ws)
         dxa = ops.conv2d(g, self.p3.dgrad_params())
-        if tp["ma"] is not None:
-            dxa = dxa * tp["ma"].view(nimg, 1, 1, -1)
+        dxa = self._drop_bwd(dxa, tp["ma"])
         g = torch.empty_like(tp["ya"])
         self.p0.conv.bias.grad.copy_(T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws))
         self.p0.wgrad(tp["p0_in"], g, self.ws)
