@@ -222,6 +222,15 @@ int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, int ldf, con
                       int Ho, int Wo, int c, int p, int map_full_res /* Baseline: fwd_ws from full_res=1 */,
                       float dist_scalar, void* stream);
 
+/* The same backward for an ARBITRARY upstream gradient of the model output (what autograd's loss.backward()
+ * hands to `model(sup, msk, qry, out_shape)`, entry/pemp_stage1.py:59-61): dlogits [B][2][Ho][Wo] replaces
+ * (pred, target, weight, stats); the adjoint of the bilinear upsample is applied to it directly.             */
+int pemp_head_bwd_dlogits_f32(const float* sup_feat, const float* qry_feat, int ldf, const float* mask,
+                              const float* ctr, const void* fwd_ws, const float* protos, const float* dlogits,
+                              float* dsup, float* dqry, int ldd, float* dctr, void* ws, size_t ws_bytes,
+                              int B, int S, int h, int w, int H, int W, int Ho, int Wo, int c, int p,
+                              int map_full_res, float dist_scalar, void* stream);
+
 /* nn.utils.clip_grad_norm_(params, max_norm) + SGD(momentum, weight_decay).step() on flat buffers
  * (entry/pemp_stage1.py:63-64, core/solver.py:87-91).  grad_scale multiplies the gradients first
  * (1/world after a SUM all-reduce); max_norm <= 0 disables clipping; grad_norm_out[0] = ||g||_2.  */

@@ -85,6 +85,8 @@ SYMBOLS = {
     "pemp_head_bwd_workspace_bytes": (c_size, [c_int] * 5),
     "pemp_head_bwd_f32": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int,
                                   c_fp, c_fp, c_size] + [c_int] * 11 + [C.c_float, c_fp]),
+    "pemp_head_bwd_dlogits_f32": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int,
+                                          c_fp, c_fp, c_size] + [c_int] * 11 + [C.c_float, c_fp]),
     "pemp_eval_tail_weighted_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size] + [c_int] * 5 + [c_fp]),
     "pemp_cedt_workspace_bytes": (c_size, [c_int] * 3),
     "pemp_cedt_weight_f32": (c_int, [c_fp, c_fp, c_fp, c_size, c_int, c_int, c_int, C.c_float, c_fp]),

@@ -79,6 +79,42 @@ __global__ void ce_upsample_bwd_kernel(const float* __restrict__ pred, const int
     dpred[((size_t)b * 2 + 1) * n + i] = g1;
 }
 
+// Adjoint of F.interpolate(pred, (Ho,Wo), "bilinear", align_corners=True) for an arbitrary upstream gradient:
+// dpred[b][ch][i] = sum_P W[P][i] * dlogits[b][ch][P]   (same gather as above, dlogits read instead of derived).
+__global__ void upsample_bwd_kernel(const float* __restrict__ dlogits, float* __restrict__ dpred, int h, int w, int Ho,
+                                    int Wo) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = h * w;
+    if (i >= n) return;
+    const int y = i / w, x = i - y * w;
+    const float sh = (Ho > 1 && h > 1) ? (float)(h - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = (Wo > 1 && w > 1) ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+    const int Y0 = sh > 0.f ? max(0, (int)floorf((float)(y - 1) / sh) - 1) : 0;
+    const int Y1 = sh > 0.f ? min(Ho - 1, (int)ceilf((float)(y + 1) / sh) + 1) : Ho - 1;
+    const int X0 = sw > 0.f ? max(0, (int)floorf((float)(x - 1) / sw) - 1) : 0;
+    const int X1 = sw > 0.f ? min(Wo - 1, (int)ceilf((float)(x + 1) / sw) + 1) : Wo - 1;
+    const float* d0 = dlogits + (size_t)b * 2 * Ho * Wo;
+    const float* d1 = d0 + (size_t)Ho * Wo;
+    float g0 = 0.f, g1 = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        const Bilin by = bilin(Y, h, Ho);
+        const float wy = (by.i0 == y ? 1.f - by.l : 0.f) + (by.i1 == y && by.i1 != by.i0 ? by.l : 0.f) +
+                         (by.i1 == by.i0 && by.i0 == y ? by.l : 0.f);
+        if (wy == 0.f) continue;
+        for (int X = X0; X <= X1; ++X) {
+            const Bilin bx = bilin(X, w, Wo);
+            const float wx = (bx.i0 == x ? 1.f - bx.l : 0.f) + (bx.i1 == x && bx.i1 != bx.i0 ? bx.l : 0.f) +
+                             (bx.i1 == bx.i0 && bx.i0 == x ? bx.l : 0.f);
+            if (wx == 0.f) continue;
+            g0 += wy * wx * d0[(size_t)Y * Wo + X];
+            g1 += wy * wx * d1[(size_t)Y * Wo + X];
+        }
+    }
+    dpred[((size_t)b * 2 + 0) * n + i] = g0;
+    dpred[((size_t)b * 2 + 1) * n + i] = g1;
+}
+
 // -----------------------------------------------------------------------------------------------
 // cosine + group-max backward.  One wave per query pixel.
 //   dY_i   = sum_g k*gp_g(i) * (v_j - cos_ij u_i) / |y_i|          j = argmax_{j in g} L_ij, u = y/|y|, v = P/|P|
@@ -459,13 +495,14 @@ extern "C" size_t pemp_head_bwd_workspace_bytes(int B, int S, int n, int c, int 
 //   target   int64 [B][Ho][Wo]; weight [B][Ho][Wo] per-pixel CE weights or NULL (CELossDT);
 //   stats    [B][8] from pemp_eval_tail(_weighted)_f32 (loss denominator per episode at index 1)
 //   dsup [B*S][n][ldd], dqry [B][n][ldd] out; dctr [c][2p] out (ignored when p == 0: plain MAP)
-extern "C" int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, int ldf, const float* mask,
-                                 const float* ctr, const void* fwd_ws, const float* protos, const float* pred,
-                                 const int64_t* target, const float* weight, const double* stats, float* dsup,
-                                 float* dqry, int ldd,
-                                 float* dctr, void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W,
-                                 int Ho, int Wo, int c, int p, int map_full_res, float dist_scalar, void* stream) {
-    PEMP_REQUIRE(sup_feat && qry_feat && mask && fwd_ws && protos && pred && target && stats && dsup && dqry && ws,
+static int head_bwd_impl(const float* sup_feat, const float* qry_feat, int ldf, const float* mask,
+                         const float* ctr, const void* fwd_ws, const float* protos, const float* pred,
+                         const int64_t* target, const float* weight, const double* stats, const float* dlogits,
+                         float* dsup, float* dqry, int ldd,
+                         float* dctr, void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W,
+                         int Ho, int Wo, int c, int p, int map_full_res, float dist_scalar, void* stream) {
+    PEMP_REQUIRE(sup_feat && qry_feat && mask && fwd_ws && protos && dsup && dqry && ws &&
+                     (dlogits || (pred && target && stats)),
                  "head_bwd: null pointer");
     PEMP_REQUIRE(B > 0 && S > 0 && h > 0 && w > 0 && Ho > 0 && Wo > 0 && p >= 0 && 2 * p <= MAXJ, "head_bwd: bad dims");
     PEMP_REQUIRE(c > 0 && c % 4 == 0 && c <= 64 * MAXCL && ldf >= c && ldd >= c && ldf % 4 == 0 && ldd % 4 == 0,
@@ -486,8 +523,11 @@ extern "C" int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, i
     hipLaunchKernelGGL(pool_shot_kernel, dim3(J, BS, cdiv(c, 64)), dim3(64), 0, st, (const float*)L.part,
                        (const float*)L.asum, map_full_res ? (const float*)L.msum : (const float*)nullptr, Pps, Dps, c, J,
                        nck, p > 0 ? 1e-6f : 1e-5f);
-    hipLaunchKernelGGL(ce_upsample_bwd_kernel, dim3(cdiv(n, 128), B), dim3(128), 0, st, pred, target, weight, stats, B,
-                       dpred, h, w, Ho, Wo);
+    if (dlogits)
+        hipLaunchKernelGGL(upsample_bwd_kernel, dim3(cdiv(n, 128), B), dim3(128), 0, st, dlogits, dpred, h, w, Ho, Wo);
+    else
+        hipLaunchKernelGGL(ce_upsample_bwd_kernel, dim3(cdiv(n, 128), B), dim3(128), 0, st, pred, target, weight, stats, B,
+                           dpred, h, w, Ho, Wo);
     hipLaunchKernelGGL(cosine_bwd_kernel, dim3(HB_BLOCKS, B), dim3(256), 0, st, qry_feat, ldf, protos, (const float*)dpred,
                        dqry, ldd, cpart, n, c, p > 0 ? p : 1, dist_scalar);
     hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(J * c, 256), B), dim3(256), 0, st, (const float*)cpart, HB_BLOCKS, J * c,
@@ -506,4 +546,27 @@ extern "C" int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, i
                            (const float*)dP, (const float*)Pps, (const float*)Dps, dsup, ldd, mpart, S, n, h, w, H, W, c, 1);
     }
     return launch_status("head_bwd/mpm");
+}
+
+extern "C" int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, int ldf, const float* mask,
+                                 const float* ctr, const void* fwd_ws, const float* protos, const float* pred,
+                                 const int64_t* target, const float* weight, const double* stats, float* dsup,
+                                 float* dqry, int ldd,
+                                 float* dctr, void* ws, size_t ws_bytes, int B, int S, int h, int w, int H, int W,
+                                 int Ho, int Wo, int c, int p, int map_full_res, float dist_scalar, void* stream) {
+    PEMP_REQUIRE(pred && target && stats, "head_bwd: null pointer");
+    return head_bwd_impl(sup_feat, qry_feat, ldf, mask, ctr, fwd_ws, protos, pred, target, weight, stats, nullptr, dsup, dqry,
+                         ldd, dctr, ws, ws_bytes, B, S, h, w, H, W, Ho, Wo, c, p, map_full_res, dist_scalar, stream);
+}
+
+// The same backward for an ARBITRARY gradient of the logits (autograd hands dL/dlogits to the model's output):
+// dlogits [B][2][Ho][Wo] replaces (pred, target, weight, stats).
+extern "C" int pemp_head_bwd_dlogits_f32(const float* sup_feat, const float* qry_feat, int ldf, const float* mask,
+                                         const float* ctr, const void* fwd_ws, const float* protos, const float* dlogits,
+                                         float* dsup, float* dqry, int ldd, float* dctr, void* ws, size_t ws_bytes, int B,
+                                         int S, int h, int w, int H, int W, int Ho, int Wo, int c, int p, int map_full_res,
+                                         float dist_scalar, void* stream) {
+    PEMP_REQUIRE(dlogits, "head_bwd_dlogits: null pointer");
+    return head_bwd_impl(sup_feat, qry_feat, ldf, mask, ctr, fwd_ws, protos, nullptr, nullptr, nullptr, nullptr, dlogits, dsup,
+                         dqry, ldd, dctr, ws, ws_bytes, B, S, h, w, H, W, Ho, Wo, c, p, map_full_res, dist_scalar, stream);
 }

@@ -32,8 +32,18 @@ class BaseModel(nn.Module):
                 prm.requires_grad = False
 
     # any change of the parameters invalidates the packed device copies used by the engine
-    def _invalidate(self):
+    def _invalidate(self, bridge=False):
         self.__dict__["_engine"] = None
+        if bridge:                       # parameters were re-created (device / dtype move): the flat buffers are stale
+            self.__dict__["_bridge"] = None
+
+    def _train_bridge(self, kind, device):
+        """The train()-mode forward as an autograd node over the explicit HIP training engine (pemp_amd.autograd)."""
+        br = self.__dict__.get("_bridge")
+        if br is None:
+            from ..autograd import TrainBridge
+            br = self.__dict__["_bridge"] = TrainBridge(self, kind, device)
+        return br
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
@@ -42,7 +52,7 @@ class BaseModel(nn.Module):
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._invalidate()
+        self._invalidate(bridge=True)
         return out
 
     def train(self, mode=True):

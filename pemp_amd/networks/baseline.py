@@ -83,7 +83,9 @@ class Baseline(_HeadMixin, backbones.BaseModel):
         return ops.cosine_proto_max(f[B * S:], pro, dist_scalar), None
 
     def forward(self, sup_img, sup_mask, qry_img, out_shape=None):
-        """Same contract as the reference (baseline.py:69-118): logits [BQ,2,Ho,Wo]."""
+        """Same contract as the reference (baseline.py:69-118): logits [BQ,2,Ho,Wo]; differentiable in train()."""
+        if self.training:
+            return self._train_bridge("baseline", sup_img.device)(sup_img, sup_mask, qry_img, out_shape)
         self._require_eval_gpu(self, sup_img, sup_mask, qry_img)
         pred, _ = self.lowres(sup_img, sup_mask, qry_img)
         return self._finish(pred, None, out_shape if out_shape is not None else tuple(sup_img.shape[-2:]))

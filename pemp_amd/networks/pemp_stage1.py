@@ -76,9 +76,8 @@ class _HeadMixin:
     @staticmethod
     def _require_eval_gpu(model, *tensors):
         if model.training:
-            raise NotImplementedError(
-                "pemp_amd: the training (batch-statistics BN / DropBlock / backward) path is not built yet; "
-                "call model.eval()")
+            raise RuntimeError("pemp_amd: lowres()/graph replay are inference paths; call model.eval() "
+                               "(model(...) itself works in train() mode and is differentiable)")
         for t in tensors:
             if not t.is_cuda:
                 raise RuntimeError("pemp_amd: inputs must live on the GPU; there is no CPU fallback")
@@ -151,6 +150,7 @@ class PEMPStage1(_HeadMixin, backbones.BaseModel):
             raise ValueError(backbone_error.format(backbone))
         pretrained = pretrained_weights[backbone]
         self.backbone_name = backbone
+        self.drop_rate, self.block_size = drop_rate, block_size          # DropBlock of the purifier / ASPPV2 (train only)
         if backbone == "vgg16":
             trunk = backbones.VGG16Params(init_channels, last_relu=False)
             self.encoder = nn.Sequential(OrderedDict([("backbone", trunk)]))
@@ -197,7 +197,12 @@ class PEMPStage1(_HeadMixin, backbones.BaseModel):
     @net_ingredient.capture
     def forward(self, sup_img, sup_mask, qry_img, out_shape=None, ret_ind=False, protos=3, dist_scalar=20):
         """Same contract as the reference (pemp_stage1.py:111-163): returns logits [BQ,2,Ho,Wo]
-        (+ int64 response map [BQ,Ho,Wo] when ``ret_ind``)."""
+        (+ int64 response map [BQ,Ho,Wo] when ``ret_ind``).  In ``train()`` mode the logits carry a grad_fn:
+        ``loss.backward()`` runs the explicit HIP backward and fills ``p.grad`` (entry/pemp_stage1.py:59-61)."""
+        if self.training:
+            if ret_ind:
+                raise ValueError("ret_ind is an inference option (entry/pemp_stage1.py:213-217); call model.eval()")
+            return self._train_bridge("stage1", sup_img.device)(sup_img, sup_mask, qry_img, out_shape)
         self._require_eval_gpu(self, sup_img, sup_mask, qry_img)
         pred, resp = self.lowres(sup_img, sup_mask, qry_img, ret_ind, protos, dist_scalar)
         H, W = sup_img.shape[-2:]

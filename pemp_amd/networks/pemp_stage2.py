@@ -51,6 +51,7 @@ class PEMPStage2(_HeadMixin, backbones.BaseModel):
                 "VGG16CM is broken in the reference as shipped (init_weights reads an undefined self.cm, "
                 "networks/backbones.py:518) and is not reproduced")
         self.spq = shot + query
+        self.drop_rate2 = drop_rate2                                    # Dropout2d of the purifier / ASPP (train only)
         trunk = backbones.ResNetCMParams(init_channels + 1, _RES_LAYERS[backbone2], freeze_bn=True, shot_query=self.spq)
         self.encoder = nn.Sequential(OrderedDict([
             ("backbone", trunk), ("purifier", backbones.purifier_params(out_channels, v2=False))]))
@@ -99,7 +100,11 @@ class PEMPStage2(_HeadMixin, backbones.BaseModel):
         return out if ret_ind else (out, None)
 
     def forward(self, sup_img, sup_mask, qry_img, qry_prior, out_shape=None, ret_ind=False):
-        """Same contract as the reference (pemp_stage2.py:104-162)."""
+        """Same contract as the reference (pemp_stage2.py:104-162); differentiable in train()."""
+        if self.training:
+            if ret_ind:
+                raise ValueError("ret_ind is an inference option; call model.eval()")
+            return self._train_bridge("stage2", sup_img.device)(sup_img, sup_mask, qry_img, out_shape, qry_prior)
         self._require_eval_gpu(self, sup_img, sup_mask, qry_img, qry_prior)
         pred, resp = self.lowres(sup_img, sup_mask, qry_img, qry_prior, ret_ind)
         return self._finish(pred, resp, out_shape if out_shape is not None else tuple(sup_img.shape[-2:]))

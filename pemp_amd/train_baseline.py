@@ -77,6 +77,7 @@ class _VGGEngine(Stage1TrainEngine):
 
 class BaselineTrainer(Stage1Trainer):
     """``train_step`` of the Baseline: forward, CE, backward, SGD step -- no clipping (entry/baseline.py:54-62)."""
+    map_full_res = True
 
     def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=5e-4, device=None, loss="ce", sigma=5.0,
                  use_graph=False):
@@ -119,6 +120,7 @@ class BaselineTrainer(Stage1Trainer):
         eng = self.eng
         B, S, ch, H, W = sup_img.shape
         Q = qry_img.shape[1]
+        eng.flat.attach_grads()
         eng.flat.grad.zero_()
-        feat = eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)])
+        feat = self.encode(sup_img, sup_mask, qry_img)
         return self._head_hip(feat, sup_mask, qry_msk, B, S, Q)

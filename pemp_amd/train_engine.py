@@ -49,15 +49,37 @@ class FlatParams:
         self.first_step = True
         for p, o in zip(self.params, offs):
             src = p.detach().to(device)
-            if p.dim() == 4:
-                co, ci, kh, kw = p.shape
-                self.data[o:o + p.numel()].view(co, kh, kw, ci).copy_(src.permute(0, 2, 3, 1))
-                p.data = self.data[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
-                p.grad = self.grad[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
-            else:
-                self.data[o:o + p.numel()].view(p.shape).copy_(src)
-                p.data = self.data[o:o + p.numel()].view(p.shape)
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            self._view(self.data, p, o).copy_(src)
+            p.data = self._view(self.data, p, o)
+        self.grad_views = [self._view(self.grad, p, o) for p, o in zip(self.params, offs)]
+        self.attach_grads()
+
+    @staticmethod
+    def _view(buf, p, o):
+        """The slice of flat buffer ``buf`` that holds parameter ``p``, shaped like ``p`` (conv weights: KRSC storage
+        seen through a channels_last view of the reference's [Cout,Cin,KH,KW] shape)."""
+        if p.dim() == 4:
+            co, ci, kh, kw = p.shape
+            return buf[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return buf[o:o + p.numel()].view(p.shape)
+
+    def attach_grads(self):
+        """(Re)attach every ``p.grad`` as a view of the flat gradient buffer (``zero_grad(set_to_none=True)`` drops them)."""
+        for p, v in zip(self.params, self.grad_views):
+            p.grad = v
+
+    def gather_grads(self):
+        """Flat copy of the gradients currently held in ``p.grad`` (None when there are none): lets a backward pass
+        ADD to them, as autograd does."""
+        if all(p.grad is None for p in self.params):
+            return None
+        if all(p.grad is v for p, v in zip(self.params, self.grad_views)):
+            return self.grad.clone()
+        prev = torch.zeros_like(self.grad)
+        for p, o in zip(self.params, self.offs):
+            if p.grad is not None:
+                self._view(prev, p, o).copy_(p.grad)
+        return prev
 
     def build_dgrad_mirror(self):
         """One int32 permutation that turns the flat parameter buffer into a second buffer holding, for every
@@ -453,9 +475,13 @@ class Stage1Trainer:
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.model = model
         model.train()
-        self.eng = Stage1TrainEngine(model, self.device)
-        self.eng.drop_rate = cfg["drop_rate"] if drop_rate is None else drop_rate
-        self.eng.block_size = cfg["block_size"] if block_size is None else block_size
+        if getattr(model, "backbone_name", "resnet50") == "vgg16":     # stage 1 on VGG-16: conv+bias+ReLU chain, no purifier
+            from .train_baseline import _VGGEngine
+            self.eng = _VGGEngine(model, self.device)
+        else:
+            self.eng = Stage1TrainEngine(model, self.device)
+        self.eng.drop_rate = getattr(model, "drop_rate", cfg["drop_rate"]) if drop_rate is None else drop_rate
+        self.eng.block_size = getattr(model, "block_size", cfg["block_size"]) if block_size is None else block_size
         self.lr, self.momentum, self.wd, self.max_norm = lr, momentum, weight_decay, max_norm
         self.protos = 0 if model.ctr is None else model.ctr.shape[1] // 2
         self.dist_scalar = cfg["dist_scalar"]
@@ -467,6 +493,14 @@ class Stage1Trainer:
         from .core import losses
         self.loss_obj = losses.get({"loss": loss, "sigma": sigma})
 
+    map_full_res = False          # Baseline: masked average pooling over bilinearly up-sampled features
+
+    def encode(self, sup_img, sup_mask, qry_img, qry_prior=None):
+        """Train-mode encoder forward -> NHWC features [B*S + B*Q, h, w, c] (supports first); tape kept in the engine."""
+        B, S, ch, H, W = sup_img.shape
+        Q = qry_img.shape[1]
+        return self.eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)])
+
     def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, head="hip"):
         """Fills the flat gradient buffer; returns (loss, logits).  ``head="hip"`` runs the prototype head
         and its backward on libpemp_hip.so (logits are then produced only on request: returns the low-res
@@ -474,8 +508,9 @@ class Stage1Trainer:
         eng = self.eng
         B, S, ch, H, W = sup_img.shape
         Q = qry_img.shape[1]
+        eng.flat.attach_grads()
         eng.flat.grad.zero_()
-        feat = eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)])
+        feat = self.encode(sup_img, sup_mask, qry_img)
         if head == "hip":
             return self._head_hip(feat, sup_mask, qry_msk, B, S, Q)
         leaf = feat.detach().requires_grad_(True)
@@ -563,6 +598,15 @@ class Stage1Trainer:
             self.lr, self.momentum, self.wd = g["lr"], g.get("momentum", 0.0), g.get("weight_decay", 0.0)
             self.nesterov = bool(g.get("nesterov", False))
         scale = allreduce_gradients(f.grad)
+        if self.optimizer is not None and not isinstance(self.optimizer, torch.optim.SGD):
+            # any other torch optimizer (tr.opt=adam, core/solver.py:92-96) steps on the parameter views itself
+            if scale != 1.0:
+                f.grad.mul_(scale)
+            f.attach_grads()
+            if self.max_norm > 0:
+                self.last_grad_norm = torch.nn.utils.clip_grad_norm_(f.params, self.max_norm)
+            self.optimizer.step()
+            return
         self.last_grad_norm = T.sgd_clip_step(f.data, f.grad, f.mom, self.max_norm, self.lr, self.momentum, self.wd,
                                               f.first_step, grad_scale=scale, ws_cache=self.eng.ws, nesterov=self.nesterov)
         f.first_step = False

@@ -247,6 +247,29 @@ def sgd_clip_step(params, grads, buf, max_norm, lr, momentum, weight_decay, firs
     return norm
 
 
+def head_bwd_dlogits(sup_feat, qry_feat, sup_mask, ctr, fwd_ws, protos, dlogits, dfeat, B, S, p, dist_scalar,
+                     ws_cache=None, map_full_res=False):
+    """``head_bwd`` for an arbitrary gradient of the logits ``dlogits`` [B,2,Ho,Wo] (autograd's grad_output)."""
+    lib = _lib.load()
+    _chk_dev(sup_feat, qry_feat, sup_mask, ctr, fwd_ws, protos, dlogits, dfeat)
+    from .ops import _nhwc
+    ldf = _nhwc(sup_feat, "sup_feat")
+    bs, h, w, c = sup_feat.shape
+    H, W = sup_mask.shape[-2:]
+    if dlogits.dtype != torch.float32 or not dlogits.is_contiguous() or dlogits.shape[:2] != (B, 2):
+        raise ValueError("head_bwd_dlogits: dlogits must be contiguous fp32 [B,2,Ho,Wo]")
+    ho, wo = dlogits.shape[-2:]
+    ldd = _nhwc(dfeat, "dfeat")
+    dctr = torch.empty((c, 2 * p), dtype=torch.float32, device=sup_feat.device) if p > 0 else None
+    nbytes = lib.pemp_head_bwd_workspace_bytes(B, S, h * w, c, p)
+    ws = _ws(nbytes, sup_feat.device, ws_cache, ("head_bwd", B, S, h, w, c, p))
+    _lib.check(lib.pemp_head_bwd_dlogits_f32(_p(sup_feat), _p(qry_feat), ldf, _p(sup_mask), _p(ctr), _p(fwd_ws), _p(protos),
+                                             _p(dlogits), _p(dfeat[:bs]), _p(dfeat[bs:]), ldd, _p(dctr), _p(ws), ws.numel(),
+                                             B, S, h, w, H, W, ho, wo, c, p, 1 if map_full_res else 0, float(dist_scalar),
+                                             _stream()), "head_bwd_dlogits")
+    return dctr
+
+
 def head_bwd(sup_feat, qry_feat, sup_mask, ctr, fwd_ws, protos, pred, target, stats, dfeat, B, S, p, dist_scalar,
              ws_cache=None, weight=None, map_full_res=False):
     """Gradient of the mean CE loss w.r.t. the features (written into ``dfeat`` [B*S + B, h, w, c], supports

@@ -240,7 +240,7 @@ class Stage2Trainer(Stage1Trainer):
             stage1.eval()
         model.train()
         self.eng = Stage2TrainEngine(model, self.device)
-        self.eng.drop_rate2 = cfg["drop_rate2"] if drop_rate2 is None else drop_rate2
+        self.eng.drop_rate2 = getattr(model, "drop_rate2", cfg["drop_rate2"]) if drop_rate2 is None else drop_rate2
         self.lr, self.momentum, self.wd, self.max_norm = lr, momentum, weight_decay, 0.0
         self.protos = 0 if model.ctr is None else model.ctr.shape[1] // 2
         self.dist_scalar = cfg["dist_scalar"]
@@ -256,24 +256,32 @@ class Stage2Trainer(Stage1Trainer):
             am, _, _ = ops.eval_tail(pred, None, out_hw=tuple(sup_img.shape[-2:]), ws_cache=self.eng.ws)   # fused upsample+argmax
             return am.unsqueeze(1)
 
-    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, qry_prior=None, head="hip"):
-        if head != "hip":
-            raise ValueError("Stage2Trainer: only the HIP head is available")
-        eng = self.eng
+    def encode(self, sup_img, sup_mask, qry_img, qry_prior=None):
+        """4-channel input (RGB + prior: support fg mask / query prior, pemp_stage2.py:130-138) -> features."""
         B, S, ch, H, W = sup_img.shape
         Q = qry_img.shape[1]
         if S + Q != self.model.spq:
             raise ValueError(f"model was built for shot+query={self.model.spq}, got {S + Q}")
         if qry_prior is None:
-            qry_prior = self.prior(sup_img, sup_mask, qry_img)
+            raise ValueError("stage 2 needs qry_prior (the stage-1 argmax, entry/pemp_stage2.py:74-77)")
         key = (B, S, Q)
         if key not in self._groups:
             g = torch.cat((torch.arange(B).repeat_interleave(S), torch.arange(B).repeat_interleave(Q)))
             self._groups[key] = (g.to(self.device), torch.full((B, 1), float(S + Q), device=self.device))
-        eng.flat.grad.zero_()
         priors = [sup_mask[:, :, 0].reshape(B * S, H, W).float(), qry_prior.reshape(B * Q, H, W).float()]
-        feat = eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)], priors=priors,
-                           group=self._groups[key][0], cnt=self._groups[key][1])
+        return self.eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)], priors=priors,
+                                group=self._groups[key][0], cnt=self._groups[key][1])
+
+    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, qry_prior=None, head="hip"):
+        if head != "hip":
+            raise ValueError("Stage2Trainer: only the HIP head is available")
+        B, S = sup_img.shape[:2]
+        Q = qry_img.shape[1]
+        if qry_prior is None:
+            qry_prior = self.prior(sup_img, sup_mask, qry_img)
+        self.eng.flat.attach_grads()
+        self.eng.flat.grad.zero_()
+        feat = self.encode(sup_img, sup_mask, qry_img, qry_prior)
         return self._head_hip(feat, sup_mask, qry_msk, B, S, Q)
 
     def train_step(self, sup_img, sup_mask, qry_img, qry_msk=None, qry_prior=None):

@@ -272,8 +272,8 @@ def test_solver_surface_and_schedules():
         opt.step()
         sch.step()
     assert seq == pytest.approx([1e-3, 1e-3, 1e-4, 1e-4, 1e-5])
-    with pytest.raises(NotImplementedError):
-        solver.get(lin, dict(cfg, opt="adam"))
+    adam, _ = solver.get(lin, dict(cfg, opt="adam", adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8))
+    assert isinstance(adam, torch.optim.Adam) and adam.param_groups[0]["weight_decay"] == cfg["weight_decay"]
     with pytest.raises(ValueError, match="Not supported optimizer"):
         solver.get(lin, dict(cfg, opt="lamb"))
 
