@@ -76,9 +76,10 @@ __global__ __launch_bounds__(NW * 64) void conv_dma_kernel(ConvArgs a) {
     for (int i = 0; i < BL; ++i) pb0[i] = pb[i] = a.w + (size_t)(n0 + r + RPI * i) * a.Kpad + sq * 4;
     int cur_tap = 0, cur_cb = 0;
 
-#ifndef PEMP_KORDER
-#define PEMP_KORDER 0   // (1 measured no better: L2 reuse is not the limiter, per-step tap decode costs) K-step order of multi-tap convs: 0 = tap outer / channel chunk inner, 1 = chunk outer / tap inner
-#endif
+    // K-step order of multi-tap convs: channel chunk OUTER, tap INNER -- the 9 taps of one 32-channel chunk re-read
+    // almost the same cache lines back to back (L2 hits) instead of streaming the whole input once per tap.
+    // Measured on the 3x3 256->256 layer (50 x 51 x 51, 256x256 tile): L2 fill traffic 1120 MB -> 166 MB per
+    // launch at unchanged speed.  Every conv kernel uses this order, so variants stay bit-identical.
 #define PEMP_SET_TAP(tap_, cb_)                                                                      \
     do {                                                                                             \
         const int tap__ = (tap_);                                                                    \
@@ -121,9 +122,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dma_kernel(ConvArgs a) {
     do {                                                                                             \
         if constexpr (STEM) {                                                                        \
             _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] += 32;                              \
-        } else if (PEMP_KORDER == 1 && a.ntaps > 1) {                                                \
-            /* chunk outer, tap inner: the 9 taps of one 32-channel chunk re-read almost the same   \
-               cache lines back to back (L2 hits) instead of streaming the whole tensor per tap */   \
+        } else if (a.ntaps > 1) {                                                \
             if (++cur_tap == a.ntaps) {                                                              \
                 cur_tap = 0;                                                                         \
                 ++cur_cb;                                                                            \

@@ -92,9 +92,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < BL; ++i) pb[i] = wrow[i];
     int cur_tap = 0, cur_cb = 0;
-#define PEMP_SET_TAP(tap_)                                                                           \
+#define PEMP_SET_TAP(tap_, cb_)                                                                      \
     do {                                                                                             \
         const int tap__ = (tap_);                                                                    \
+        const int coff__ = (cb_) * 32 + q * 4;                                                       \
         const int kh = tap__ / a.KW, kw = tap__ - kh * a.KW;                                         \
         const int dh = kh * a.dil, dw = kw * a.dil;                                                  \
         const bool tok = tap__ < a.ntaps;                                                            \
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                             \
             const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                        \
             const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;     \
-            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + q * 4 : a.x;          \
+            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + coff__ : a.x;         \
             okmask |= (ok ? 1u : 0u) << i;                                                           \
         }                                                                                            \
     } while (0)
@@ -132,15 +133,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // move the cursor one K step forward
 #define PEMP_ADVANCE()                                                                               \
     do {                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] += 32;                                  \
-        if constexpr (!STEM) {                                                                       \
-            if (++cur_cb == a.cin_steps) {                                                           \
-                cur_cb = 0;                                                                          \
-                ++cur_tap;                                                                           \
-                PEMP_SET_TAP(cur_tap);                                                               \
-            } else {                                                                                 \
-                _Pragma("unroll") for (int i = 0; i < AL; ++i) pa[i] += 32;                          \
+        if constexpr (STEM) {                                                                        \
+            _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] += 32;                              \
+        } else if (a.ntaps > 1) {                                                                    \
+            /* multi-tap convs: channel chunk outer, tap inner (same order as conv_dma.hip: the taps \
+               of one chunk re-read the same lines back to back -> L2 hits) */                       \
+            if (++cur_tap == a.ntaps) {                                                              \
+                cur_tap = 0;                                                                         \
+                ++cur_cb;                                                                            \
             }                                                                                        \
+            PEMP_SET_TAP(cur_tap, cur_cb);                                                           \
+            const int koff = cur_tap * a.Cin + cur_cb * 32;                                          \
+            _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] = wrow[i] + koff;                   \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < BL; ++i) pb[i] += 32;                              \
+            _Pragma("unroll") for (int i = 0; i < AL; ++i) pa[i] += 32;                              \
         }                                                                                            \
     } while (0)
 
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    if constexpr (!STEM) PEMP_SET_TAP(0);
+    if constexpr (!STEM) PEMP_SET_TAP(0, 0);
     PEMP_GLOAD(0);
     PEMP_LSTORE(0);
     __syncthreads();

@@ -6,6 +6,8 @@ tensors ``[N,H,W,C]`` whose last-dim stride is 1; a channel slice of a wider buf
 as a view (its pixel stride ``ld`` is taken from ``stride(2)``).
 """
 import ctypes as C
+import json
+import os
 
 import torch
 
@@ -68,6 +70,12 @@ TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15
 AUTOTUNE = True
 DEFAULT_TILE = 13
 _TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared by every ConvParams object
+#: optional JSON file the picks are loaded from / saved to (PEMP_TILE_CACHE=path): a profiling run can then replay a
+#: previous process' choices instead of timing the variants again under the profiler
+_TILE_CACHE_FILE = os.environ.get("PEMP_TILE_CACHE")
+if _TILE_CACHE_FILE and os.path.exists(_TILE_CACHE_FILE):
+    with open(_TILE_CACHE_FILE) as _f:
+        _TILE_CACHE.update({tuple(json.loads(k)): int(v) for k, v in json.load(_f).items()})
 
 
 def _pick_tile(launch, p, key, cout):
@@ -87,6 +95,9 @@ def _pick_tile(launch, p, key, cout):
         if best_ms is None or ms < best_ms * 0.98:  # prefer earlier (default) variants on ties
             best, best_ms = t, ms
     _TILE_CACHE[key] = best
+    if _TILE_CACHE_FILE:
+        with open(_TILE_CACHE_FILE, "w") as f:
+            json.dump({json.dumps([int(v) for v in k]): t for k, t in _TILE_CACHE.items()}, f)
     return best
 
 
