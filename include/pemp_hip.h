@@ -145,6 +145,26 @@ int pemp_eval_tail_f32(const float* pred, const int64_t* target, uint8_t* pred_o
 int pemp_cm_reduce_f32(const float* x, int ldx, const float* mask_in, float* mask_out, float* stat,
                        int N, int Hm, int Wm, int Hx, int Wx, int C, int stride, void* stream);
 
+/* ResNetCM.comm after the statistics (networks/backbones.py:213-221): per episode g the mean over its S+Q images
+ * of (mean, max), then Linear(2C -> 2):
+ *   agg[g][k] = mean_{n: group[n]==g} stat[n][k];   feat[g][e] = lin_b[e] + sum_k agg[g][k] * lin_w[e][k]
+ * stat [N][C2] (C2 = 2C: means then maxes, the layout pemp_cm_reduce_f32 writes), group int32 [N], G <= 64.      */
+int pemp_cm_linear_f32(const float* stat, const int32_t* group, const float* lin_w, const float* lin_b,
+                       float* agg, float* feat, int N, int G, int C2, void* stream);
+/* The two broadcast channels enter the stage's first 1x1 convs (backbones.py:194,201,231,236,241) as a per-image bias:
+ *   out[n][co] = base[co] + alpha[co] * (feat[g][0] * wext[co*ldw] + feat[g][1] * wext[co*ldw + 1]),  g = group[n]
+ * (alpha/base: the folded eval BatchNorm, or NULL = 1 / 0 in training where BN follows separately).             */
+int pemp_cm_bias_f32(const float* feat, const int32_t* group, const float* wext, int ldw, const float* alpha,
+                     const float* base, float* out, int N, int Cout, void* stream);
+/* Backward of the two (entry/pemp_stage2.py:78).  colsum [N][Cout] = per-image sums of the conv-output gradient:
+ *   dwext[co][e] = sum_n colsum[n][co] * feat[g(n)][e];   dfeat_img[n][e] (+)= sum_co colsum[n][co] * wext[co][e]
+ *   dlin_w[e][k] = sum_g dfeat[g][e] * agg[g][k], dlin_b[e] = sum_g dfeat[g][e]   (dfeat[g] = sum_{n in g} dfeat_img[n])
+ *   dstat[n][k]  = (sum_e dfeat[g(n)][e] * lin_w[e][k]) / |episode g(n)|                                        */
+int pemp_cm_bias_bwd_f32(const float* colsum, const float* feat, const int32_t* group, const float* wext, int ldw,
+                         float* dwext, int lddw, float* dfeat_img, int accumulate, int N, int Cout, void* stream);
+int pemp_cm_linear_bwd_f32(const float* dfeat_img, const int32_t* group, const float* agg, const float* lin_w,
+                           float* dlin_w, float* dlin_b, float* dstat, int N, int G, int C2, void* stream);
+
 /* Backward of the comm statistics through loss.backward() in stage-2 training (entry/pemp_stage2.py:78;
  * networks/backbones.py:209-215): given dstat [N][2][C] (gradients of the per-image mean and max),
  *   dx[n][i][c] += mask[n][i] * (dstat[n][0][c] / HW + [i == argmax_i x*mask] * dstat[n][1][c])

@@ -57,6 +57,10 @@ SYMBOLS = {
     "pemp_eval_tail_workspace_bytes": (c_size, [c_int] * 3),
     "pemp_eval_tail_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size] + [c_int] * 5 + [c_fp]),
     "pemp_cm_reduce_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp]),
+    "pemp_cm_linear_f32": (c_int, [c_fp] * 6 + [c_int] * 3 + [c_fp]),
+    "pemp_cm_bias_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
+    "pemp_cm_bias_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int, c_int, c_fp]),
+    "pemp_cm_linear_bwd_f32": (c_int, [c_fp] * 7 + [c_int] * 3 + [c_fp]),
     # episode input pipeline
     "pemp_episode_plan": (c_size, [C.POINTER(SampleDesc), c_int, c_int, c_int]),
     "pemp_episode_preprocess": (c_int, [c_fp, C.POINTER(SampleDesc), c_fp, c_int, c_int, c_int, C.POINTER(C.c_float),

@@ -139,17 +139,10 @@ class ResNetCMEngine(ResNetEngine):
         self.group = None   # LongTensor [N]: episode id of every image (set by the caller)
 
     def _comm(self, x, mask, lin, stride):
-        """-> (feat [N,2] per image, pooled mask).  Statistics on HIP, the 2c->2 GEMV in torch."""
+        """-> (feat [episodes,2], pooled mask): statistics, episode mean and the 2C -> 2 Linear on HIP kernels."""
         mask, stat = ops.cm_reduce(x, mask, stride)
-        n, _, c = stat.shape
-        g = self.group
-        ng = self.n_groups
-        agg = torch.zeros((ng, 2 * c), dtype=torch.float32, device=x.device)
-        cnt = torch.zeros((ng, 1), dtype=torch.float32, device=x.device)
-        agg.index_add_(0, g, stat.reshape(n, 2 * c))
-        cnt.index_add_(0, g, torch.ones((n, 1), device=x.device))
-        feat = torch.addmm(lin[1], agg / cnt, lin[0].t())     # [episodes, 2]
-        return feat[g], mask
+        _, feat = ops.cm_linear(stat, self.group, lin[0], lin[1], self.n_groups)
+        return feat, mask
 
     def forward(self, x4, prior):
         """x4: NHWC4 input (RGB + prior); prior: [N,H,W] fp32 mask plane."""
@@ -159,8 +152,8 @@ class ResNetCMEngine(ResNetEngine):
         for si, blocks in enumerate(self.stages):
             feat, mask = self._comm(x, mask, self.lin[si], strides[si])
             b0 = blocks[0]
-            c1_shift = (b0.c1.shift[None, :] + feat @ b0.c1_extra.t()).contiguous()
-            ds_shift = (b0.ds.shift[None, :] + feat @ b0.ds_extra.t()).contiguous()
+            c1_shift = ops.cm_bias(feat, self.group, b0.c1_extra, base=b0.c1.shift)
+            ds_shift = ops.cm_bias(feat, self.group, b0.ds_extra, base=b0.ds.shift)
             x = self._block(x, b0, (si, 0), c1_shift, ds_shift)
             for bi, bp in enumerate(blocks[1:], start=1):
                 x = self._block(x, bp, (si, bi & 1))

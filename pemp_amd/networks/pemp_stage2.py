@@ -91,7 +91,7 @@ class PEMPStage2(_HeadMixin, backbones.BaseModel):
         key = ("group", B, S, Q)
         if key not in a.ws:
             g = torch.cat((torch.arange(B).repeat_interleave(S), torch.arange(B).repeat_interleave(Q)))
-            a.ws[key] = g.to(sup_img.device)
+            a.ws[key] = g.to(device=sup_img.device, dtype=torch.int32)
         trunk.group, trunk.n_groups = a.ws[key], B
         f = eng["purifier"].forward(trunk.forward(x4, prior))
         self.__dict__["_last_feats"] = f

@@ -373,3 +373,33 @@ def cm_reduce(x, mask_in, stride):
     _lib.check(lib.pemp_cm_reduce_f32(_p(x), ldx, _p(mask_in.contiguous()), _p(mask_out), _p(stat), n, hm, wm, h, w, c,
                                       stride, _stream()), "cm_reduce")
     return mask_out, stat
+
+
+def cm_linear(stat, group, lin_w, lin_b, n_groups):
+    """ResNetCM.comm after the statistics: stat [N,2,C] (or [N,2C]) -> (agg [G,2C] episode means, feat [G,2])."""
+    lib = _lib.load()
+    _chk_dev(stat, group, lin_w, lin_b)
+    n = stat.shape[0]
+    c2 = stat.numel() // n
+    if group.dtype != torch.int32 or group.numel() != n or tuple(lin_w.shape) != (2, c2):
+        raise ValueError("cm_linear: group must be int32 [N], lin_w [2, 2C]")
+    agg = torch.empty((n_groups, c2), dtype=torch.float32, device=stat.device)
+    feat = torch.empty((n_groups, 2), dtype=torch.float32, device=stat.device)
+    _lib.check(lib.pemp_cm_linear_f32(_p(stat.contiguous()), _p(group), _p(lin_w.contiguous()), _p(lin_b.contiguous()), _p(agg),
+                                      _p(feat), n, n_groups, c2, _stream()), "cm_linear")
+    return agg, feat
+
+
+def cm_bias(feat, group, wext, alpha=None, base=None):
+    """Per-image bias of the two communication channels: [N, Cout] = base + alpha * (feat[group] @ wext^T).
+    ``wext`` [Cout, 2] may be a strided column slice of the [Cout, C+2] weight matrix."""
+    lib = _lib.load()
+    _chk_dev(feat, group, wext, alpha, base)
+    cout = wext.shape[0]
+    if wext.dim() != 2 or wext.shape[1] != 2 or wext.stride(1) != 1:
+        raise ValueError("cm_bias: wext must be [Cout, 2] with unit column stride")
+    n = group.numel()
+    out = torch.empty((n, cout), dtype=torch.float32, device=feat.device)
+    _lib.check(lib.pemp_cm_bias_f32(_p(feat), _p(group), _p(wext), wext.stride(0), _p(alpha), _p(base), _p(out), n, cout,
+                                    _stream()), "cm_bias")
+    return out

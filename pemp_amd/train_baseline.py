@@ -114,9 +114,7 @@ class BaselineTrainer(Stage1Trainer):
         eng.backward(dfeat)
         return loss.float(), pred
 
-    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, head="hip"):
-        if head != "hip":
-            raise ValueError("BaselineTrainer: only the HIP head is available")
+    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk):
         eng = self.eng
         B, S, ch, H, W = sup_img.shape
         Q = qry_img.shape[1]

@@ -15,13 +15,12 @@ gradient in a second flat buffer of the same layout -- that buffer is the single
 The encoder (99.9 % of the flops) runs entirely on libpemp_hip.so: raw conv -> batch statistics ->
 normalise(+residual)(+ReLU) forward; BN backward -> MFMA wgrad -> dgrad (the forward kernel with
 flipped/transposed weights) backward.  The prototype head (MPM / cosine / upsample / CE; 0.1 % of
-the flops) runs forward and backward on the HIP head kernels (head.hip, head_bwd.hip); a torch-autograd
-restatement of the head (head_loss) is kept only as the cross-check the tests use.
+the flops) runs forward and backward on the HIP head kernels (head.hip, head_bwd.hip); the torch-autograd
+restatement of the head that cross-checks them lives with the tests (tests/util.py).
 """
 import torch
 import torch.distributed as dist
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops, train_ops as T
 from .ops import ConvParams
@@ -418,42 +417,6 @@ class Stage1TrainEngine:
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
 
 
-# ---------------------------------------------------------------------------------------------
-# head on torch ops (GPU), differentiated by autograd -- reference networks/pemp_stage1.py:142-163,195-261
-# ---------------------------------------------------------------------------------------------
-def head_loss(feat_nhwc, sup_mask, qry_mask, ctr, B, S, Q, protos, dist_scalar, out_shape, weight=None):
-    n, h, w, c = feat_nhwc.shape
-    f = feat_nhwc.permute(0, 3, 1, 2)
-    sup = f[:B * S].reshape(B, S, c, h * w).reshape(B * S, c, h * w)
-    qry = f[B * S:].reshape(B * Q, c, 1, h, w)
-    H, W = sup_mask.shape[-2:]
-    m = F.interpolate(sup_mask.reshape(B * S, 2, H, W), (h, w), mode="nearest")
-    fg, bg = m[:, 0].reshape(B * S, 1, h * w), m[:, 1].reshape(B * S, 1, h * w)
-    if protos > 0:
-        cc = ctr.view(1, c, protos * 2)
-        mask = torch.stack((fg, bg), dim=1)
-        D = -((sup.unsqueeze(2) - cc.unsqueeze(3)) ** 2).sum(dim=1)
-        D = (torch.softmax(D.view(-1, 2, protos, h * w), dim=2) * mask).view(-1, 1, protos * 2, h * w)
-        new = ((sup.view(-1, c, 1, h * w) * D).sum(dim=3) / (D.sum(dim=3) + 1e-6)).view(B, S, c, 2, protos)
-        new = new.transpose(3, 4).reshape(B, S, c * protos, 2).mean(dim=1)
-        fgp, bgp = new.view(B, c, protos, 2).unbind(dim=3)
-        fgd = F.cosine_similarity(qry, fgp[..., None, None], dim=1) * dist_scalar
-        bgd = F.cosine_similarity(qry, bgp[..., None, None], dim=1) * dist_scalar
-        pred = torch.stack((bgd, fgd), dim=1).max(dim=2).values
-    else:
-        fgv = (sup * fg).sum(-1) / (fg.sum(-1) + 1e-5)
-        bgv = (sup * bg).sum(-1) / (bg.sum(-1) + 1e-5)
-        fgp, bgp = fgv.view(B, S, c).mean(1), bgv.view(B, S, c).mean(1)
-        q = qry.view(-1, c, h, w)
-        pred = torch.stack((F.cosine_similarity(q, bgp[..., None, None], dim=1) * dist_scalar,
-                            F.cosine_similarity(q, fgp[..., None, None], dim=1) * dist_scalar), dim=1)
-    logits = F.interpolate(pred, out_shape, mode="bilinear", align_corners=True)
-    if weight is not None:          # CELossDT: sum(CE * w) / sum(w), core/losses.py:33-43
-        ce = F.cross_entropy(logits, qry_mask, ignore_index=255, reduction="none")
-        return (ce * weight).sum() / weight.sum(), logits
-    return F.cross_entropy(logits, qry_mask, ignore_index=255), logits
-
-
 def allreduce_gradients(flat_grad):
     """The one collective of a training step: SUM all-reduce of the flat gradient bucket (47.8 MB for
     stage 1) over RCCL (gloo on CPU in tests).  Returns the factor that turns the sum into the mean;
@@ -501,33 +464,16 @@ class Stage1Trainer:
         Q = qry_img.shape[1]
         return self.eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)])
 
-    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, head="hip"):
-        """Fills the flat gradient buffer; returns (loss, logits).  ``head="hip"`` runs the prototype head
-        and its backward on libpemp_hip.so (logits are then produced only on request: returns the low-res
-        prediction instead); ``head="torch"`` is the autograd cross-check used by the tests."""
-        eng = self.eng
-        B, S, ch, H, W = sup_img.shape
+    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk):
+        """Fills the flat gradient buffer; returns (loss, low-resolution prediction): encoder, prototype head and
+        their backward all on libpemp_hip.so (the logits are never materialised: CE and its gradient are fused
+        with the bilinear upsample)."""
+        B, S = sup_img.shape[:2]
         Q = qry_img.shape[1]
-        eng.flat.attach_grads()
-        eng.flat.grad.zero_()
+        self.eng.flat.attach_grads()
+        self.eng.flat.grad.zero_()
         feat = self.encode(sup_img, sup_mask, qry_img)
-        if head == "hip":
-            return self._head_hip(feat, sup_mask, qry_msk, B, S, Q)
-        leaf = feat.detach().requires_grad_(True)
-        ctr = self.model.ctr
-        if ctr is not None:
-            ctr.grad = None
-        tgt_ = qry_msk.reshape(-1, *qry_msk.shape[-2:]).contiguous()
-        with torch.enable_grad():
-            loss, logits = head_loss(leaf, sup_mask, tgt_, ctr, B, S, Q, self.protos,
-                                     self.dist_scalar, tuple(qry_msk.shape[-2:]), weight=self.loss_obj.weight_map(tgt_))
-            grads = torch.autograd.grad(loss, [leaf] + ([ctr] if ctr is not None else []))
-        if ctr is not None:
-            off = eng.flat.offs[[id(p) for p in eng.flat.params].index(id(ctr))]
-            eng.flat.grad[off:off + ctr.numel()].view(ctr.shape).copy_(grads[1])
-            ctr.grad = eng.flat.grad[off:off + ctr.numel()].view(ctr.shape)
-        eng.backward(grads[0].contiguous())
-        return loss.detach(), logits.detach()
+        return self._head_hip(feat, sup_mask, qry_msk, B, S, Q)
 
     def _head_hip(self, feat, sup_mask, qry_msk, B, S, Q):
         """MPM / cosine / upsample + CE forward and backward on the HIP kernels."""

@@ -217,6 +217,31 @@ def channel_scale(x, mask, out=None):
     return out
 
 
+def cm_bias_bwd(colsum, feat, group, wext, dwext, dfeat_img, accumulate):
+    """Backward of ``ops.cm_bias`` (training form, alpha = 1): writes dwext ([Cout,2] strided view of the weight
+    gradient) and sets / adds to dfeat_img [N,2]."""
+    lib = _lib.load()
+    _chk_dev(colsum, feat, group, wext, dwext, dfeat_img)
+    n, cout = colsum.shape
+    if not colsum.is_contiguous() or wext.stride(1) != 1 or dwext.stride(1) != 1 or tuple(dfeat_img.shape) != (n, 2):
+        raise ValueError("cm_bias_bwd: bad layouts")
+    _lib.check(lib.pemp_cm_bias_bwd_f32(_p(colsum), _p(feat), _p(group), _p(wext), wext.stride(0), _p(dwext), dwext.stride(0),
+                                        _p(dfeat_img), 1 if accumulate else 0, n, cout, _stream()), "cm_bias_bwd")
+
+
+def cm_linear_bwd(dfeat_img, group, agg, lin_w, dlin_w, dlin_b):
+    """Backward of ``ops.cm_linear``: writes dlin_w [2,2C], dlin_b [2]; returns dstat [N,2C]."""
+    lib = _lib.load()
+    _chk_dev(dfeat_img, group, agg, lin_w, dlin_w, dlin_b)
+    n, (g, c2) = group.numel(), agg.shape
+    if not (dlin_w.is_contiguous() and lin_w.is_contiguous() and agg.is_contiguous() and dfeat_img.is_contiguous()):
+        raise ValueError("cm_linear_bwd: contiguous tensors required")
+    dstat = torch.empty((n, c2), dtype=torch.float32, device=agg.device)
+    _lib.check(lib.pemp_cm_linear_bwd_f32(_p(dfeat_img), _p(group), _p(agg), _p(lin_w), _p(dlin_w), _p(dlin_b), _p(dstat),
+                                          n, g, c2, _stream()), "cm_linear_bwd")
+    return dstat
+
+
 def cm_bwd_add(x, mask, dstat, dx):
     """Backward of ``ops.cm_reduce``'s statistics: dx += mask * (dmean/HW + onehot(argmax) * dmax).
     x, dx: NHWC [N,h,w,C]; mask: the pooled mask cm_reduce returned [N,h,w]; dstat [N,2,C]."""

@@ -56,10 +56,11 @@ class _ConvCM(_Conv):
         T.conv_wgrad(x, g, prm, dw, ws_cache=ws)
         self.flat.krsc_grad(self.conv.weight)[:, :self.creal].copy_(dw)
 
-    def ext_backward(self, colsum, feat_img):
-        """colsum [N,Cout] = per-image sums of dz; writes the grads of the comm columns, returns dfeat_img [N,2]."""
-        self.flat.krsc_grad(self.conv.weight)[:, self.creal:].copy_(colsum.t() @ feat_img)
-        return colsum @ self.wext
+    def ext_backward(self, colsum, feat, group, dfeat_img, accumulate):
+        """colsum [N,Cout] = per-image sums of dz: writes the gradient of the two comm columns and sets / adds to
+        dfeat_img [N,2] (the gradient of the broadcast comm features)."""
+        T.cm_bias_bwd(colsum, feat, group, self.wext, self.flat.krsc_grad(self.conv.weight)[:, self.creal:], dfeat_img,
+                      accumulate)
 
 
 class Stage2TrainEngine(Stage1TrainEngine):
@@ -88,31 +89,25 @@ class Stage2TrainEngine(Stage1TrainEngine):
 
     # -- trunk --------------------------------------------------------------------------------
     def _trunk_forward(self, images_list, tape, priors=None, group=None, cnt=None):
-        """priors: per entry of images_list a [n_i,H,W] fp32 plane; group: LongTensor [N] episode of each image;
-        cnt: fp32 [episodes,1] images per episode (= shot + query)."""
-        n_groups = cnt.shape[0]
+        """priors: per entry of images_list a [n_i,H,W] fp32 plane; group: int32 [N] episode of each image;
+        cnt: number of episodes."""
+        n_groups = int(cnt)
         prior = torch.cat([p.reshape(-1, *p.shape[-2:]) for p in priors]).contiguous()
         mask = ops.cm_reduce(None, prior, 2)[0]                               # backbones.py:227
         y, tape["stem"] = self._cbn_fwd(self._pack(images_list, priors), *self.stem, relu=True)
         x = ops.maxpool2d(y, 3, 2, 1, ceil_mode=True)
         tape["pool_in"], tape["blocks"], tape["cm"] = y, [], []
-        tape["group"], tape["n_groups"] = group, n_groups
-        tape["cnt"] = cnt
+        tape["group"] = group
         for bi, b in enumerate(self.blocks):
             if bi in self.stage_first:
                 si = self.stage_first.index(bi)
                 lin = self.lin[si]
                 mask, stat = ops.cm_reduce(x, mask, _CM_STRIDES[si])
-                n, _, c = stat.shape
-                agg = torch.zeros((n_groups, 2 * c), dtype=torch.float32, device=x.device)
-                agg.index_add_(0, group, stat.view(n, 2 * c))
-                agg = agg / cnt                                                # episode mean of (mean, max)
-                feat = torch.addmm(lin.bias.data, agg, lin.weight.data.t())    # [episodes, 2]
-                feat_img = feat[group].contiguous()                            # [N, 2]
+                agg, feat = ops.cm_linear(stat, group, lin.weight.data, lin.bias.data, n_groups)   # episode mean, Linear(2C->2)
                 c1, ds = b["c1"].split(), b["ds"][0].split()
-                tape["cm"].append(dict(x=x, mask=mask, agg=agg, feat_img=feat_img))
-                x, rec = self._block_fwd(x, b, bias_c1=(feat_img @ c1.wext.t()).contiguous(),
-                                         bias_ds=(feat_img @ ds.wext.t()).contiguous())
+                tape["cm"].append(dict(x=x, mask=mask, agg=agg, feat=feat))
+                x, rec = self._block_fwd(x, b, bias_c1=ops.cm_bias(feat, group, c1.wext),
+                                         bias_ds=ops.cm_bias(feat, group, ds.wext))
             else:
                 x, rec = self._block_fwd(x, b)
             tape["blocks"].append(rec)
@@ -120,7 +115,7 @@ class Stage2TrainEngine(Stage1TrainEngine):
 
     def _trunk_backward(self, dx):
         tp = self.tape
-        group, n_groups, cnt = tp["group"], tp["n_groups"], tp["cnt"]
+        group = tp["group"]
         for bi in range(len(self.blocks) - 1, -1, -1):
             b, rec = self.blocks[bi], tp["blocks"][bi]
             dx = self._block_bwd(dx, b, rec)
@@ -130,14 +125,12 @@ class Stage2TrainEngine(Stage1TrainEngine):
             cm, lin = tp["cm"][si], self.lin[si]
             dz1, dzd = rec["r1"]["dz"], rec["rd"]["dz"]
             hw_out = float(dz1.shape[1] * dz1.shape[2])
-            dfeat_img = b["c1"].ext_backward(ops.global_avgpool(dz1) * hw_out, cm["feat_img"]) \
-                + b["ds"][0].ext_backward(ops.global_avgpool(dzd) * hw_out, cm["feat_img"])
-            dfeat = torch.zeros((n_groups, 2), dtype=torch.float32, device=dx.device).index_add_(0, group, dfeat_img)
-            lin.weight.grad.copy_(dfeat.t() @ cm["agg"])
-            lin.bias.grad.copy_(dfeat.sum(dim=0))
-            dstat = ((dfeat @ lin.weight.data) / cnt)[group]                   # [N, 2C]: d(mean), d(max) per image
             n, h, w, c = cm["x"].shape
-            T.cm_bwd_add(cm["x"], cm["mask"], dstat.view(n, 2, c).contiguous(), dx)
+            dfi = torch.empty((n, 2), dtype=torch.float32, device=dx.device)
+            b["c1"].ext_backward(ops.global_avgpool(dz1) * hw_out, cm["feat"], group, dfi, accumulate=False)
+            b["ds"][0].ext_backward(ops.global_avgpool(dzd) * hw_out, cm["feat"], group, dfi, accumulate=True)
+            dstat = T.cm_linear_bwd(dfi, group, cm["agg"], lin.weight.data, lin.weight.grad, lin.bias.grad)
+            T.cm_bwd_add(cm["x"], cm["mask"], dstat.view(n, 2, c), dx)         # [N,2,C]: d(mean), d(max) per image
         dy = T.maxpool_bwd(tp["pool_in"], dx, 3, 2, 1)
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
 
@@ -267,14 +260,12 @@ class Stage2Trainer(Stage1Trainer):
         key = (B, S, Q)
         if key not in self._groups:
             g = torch.cat((torch.arange(B).repeat_interleave(S), torch.arange(B).repeat_interleave(Q)))
-            self._groups[key] = (g.to(self.device), torch.full((B, 1), float(S + Q), device=self.device))
+            self._groups[key] = (g.to(device=self.device, dtype=torch.int32), B)
         priors = [sup_mask[:, :, 0].reshape(B * S, H, W).float(), qry_prior.reshape(B * Q, H, W).float()]
         return self.eng.forward([sup_img.reshape(B * S, ch, H, W), qry_img.reshape(B * Q, ch, H, W)], priors=priors,
                                 group=self._groups[key][0], cnt=self._groups[key][1])
 
-    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, qry_prior=None, head="hip"):
-        if head != "hip":
-            raise ValueError("Stage2Trainer: only the HIP head is available")
+    def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk, qry_prior=None):
         B, S = sup_img.shape[:2]
         Q = qry_img.shape[1]
         if qry_prior is None:

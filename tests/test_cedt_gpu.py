@@ -31,7 +31,7 @@ def test_cedt_weight_matches_scipy(hip_lib, dev, idx):
 def test_cedt_loss_and_gradient(hip_lib, dev):
     from oracle import ref_cpu
     from pemp_amd import ops, train_ops as T
-    from pemp_amd.train_engine import head_loss
+    from tests.util import head_loss
     B, S, p, c, h, w, H = 2, 1, 3, 512, 13, 13, 97
     g = torch.Generator().manual_seed(3)
     feat = (torch.rand(B * S + B, h, w, c, generator=g) * 4 - 2).requires_grad_()
@@ -77,8 +77,8 @@ def test_train_step_with_cedt_runs(hip_lib, dev):
     net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
     tr = Stage1Trainer(net, device=dev, drop_rate=0.0, loss="cedt", sigma=5.0)
     sup, msk, qry, gt = _batch(dev)
-    l_hip, _ = tr.forward_backward(sup, msk, qry, gt, head="hip")
+    l_hip, _ = tr.forward_backward(sup, msk, qry, gt)
     g_hip = tr.eng.flat.grad.clone()
-    l_t, _ = tr.forward_backward(sup, msk, qry, gt, head="torch")
+    l_t, _ = util.torch_head_step(tr, sup, msk, qry, gt)
     assert abs(l_hip.item() - l_t.item()) < 2e-5
     assert (g_hip - tr.eng.flat.grad).abs().max().item() < 2e-2 * g_hip.abs().max().item()

@@ -174,7 +174,7 @@ def test_sgd_clip_step_matches_torch(hip_lib, dev):
 def test_head_backward_matches_autograd(hip_lib, dev, B, S, p, c, h, w, H, W, Ho, Wo):
     """pemp_head_bwd_f32 vs torch autograd through the torch restatement of the head (CPU)."""
     from pemp_amd import ops, train_ops as T
-    from pemp_amd.train_engine import head_loss
+    from tests.util import head_loss
     feat = (_rand(B * S + B, h, w, c, seed=1) * 2).requires_grad_()
     m = (_rand(B, S, 1, H, W, seed=3) > 0.1).float()
     mask = torch.cat((m, 1 - m), dim=2)
@@ -204,3 +204,41 @@ def test_head_backward_matches_autograd(hip_lib, dev, B, S, p, c, h, w, H, W, Ho
     if p > 0:
         cs = grads[1].abs().max().item()
         assert (dctr.cpu() - grads[1]).abs().max().item() < 5e-4 * cs + 1e-9, (dctr.cpu() - grads[1]).abs().max().item() / cs
+
+
+def test_cm_linear_bias_and_backward_match_autograd(hip_lib, dev):
+    """ResNetCM.comm's small linear algebra (episode mean, Linear(2C->2), per-image conv bias of the two constant
+    channels) and its backward vs torch autograd on the reference's formulation (backbones.py:213-221)."""
+    from pemp_amd import ops, train_ops as T
+    torch.manual_seed(3)
+    N, G, C, co = 9, 3, 64, 48
+    group = torch.tensor([0, 0, 1, 2, 1, 0, 2, 2, 1], dtype=torch.int32, device=dev)       # uneven episodes, any order
+    stat = torch.randn(N, 2, C, device=dev)
+    W = torch.randn(2, 2 * C, device=dev, requires_grad=True)
+    b = torch.randn(2, device=dev, requires_grad=True)
+    wfull = torch.randn(co, C + 2, device=dev, requires_grad=True)                          # [Cout, C+2]: last two = comm columns
+    alpha, base = torch.rand(co, device=dev) + 0.5, torch.randn(co, device=dev)
+    st = stat.clone().requires_grad_(True)
+    g64 = group.long()
+    cnt = torch.bincount(g64, minlength=G).float()[:, None]
+    agg_ref = torch.zeros(G, 2 * C, device=dev).index_add(0, g64, st.view(N, -1)) / cnt
+    feat_ref = torch.addmm(b, agg_ref, W.t())
+    bias_ref = feat_ref[g64] @ wfull[:, C:].t()
+    agg, feat = ops.cm_linear(stat, group, W.detach(), b.detach(), G)
+    assert torch.allclose(agg, agg_ref.detach(), atol=1e-6) and torch.allclose(feat, feat_ref.detach(), atol=1e-5)
+    wext = wfull.detach()[:, C:]
+    assert torch.allclose(ops.cm_bias(feat, group, wext), bias_ref.detach(), atol=1e-5)
+    assert torch.allclose(ops.cm_bias(feat, group, wext, alpha=alpha, base=base), base + alpha * bias_ref.detach(), atol=1e-5)
+    colsum = torch.randn(N, co, device=dev)
+    (bias_ref * colsum).sum().backward()
+    dwfull = torch.zeros(co, C + 2, device=dev)
+    dfi = torch.empty(N, 2, device=dev)
+    T.cm_bias_bwd(colsum, feat, group, wext, dwfull[:, C:], dfi, accumulate=False)
+    assert torch.allclose(dwfull[:, C:], wfull.grad[:, C:], rtol=1e-4, atol=1e-5) and not dwfull[:, :C].any()
+    dW, db = torch.empty_like(W), torch.empty_like(b)
+    dstat = T.cm_linear_bwd(dfi, group, agg, W.detach(), dW, db)
+    assert torch.allclose(dW, W.grad, rtol=1e-4, atol=1e-5) and torch.allclose(db, b.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(dstat.view(N, 2, C), st.grad, rtol=1e-4, atol=1e-6)
+    dfi2 = dfi.clone()
+    T.cm_bias_bwd(colsum, feat, group, wext, dwfull[:, C:], dfi2, accumulate=True)
+    assert torch.allclose(dfi2, 2 * dfi, rtol=1e-6)
