@@ -294,6 +294,32 @@ def gen_train_step_baseline(tmp):
         print("wrote", tag, "train step; loss", float(loss))
 
 
+def gen_train_step_stage1_vgg(tmp):
+    """G12: one training step of stage 1 on VGG-16 (no purifier, MPM head with learnable ctr), as G9."""
+    from networks import pemp_stage1 as m
+    cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="vgg16", protos=3, drop_rate=0.0, block_size=4)
+    model = _build(m, "PEMPStage1", cfg, (), tmp)
+    _load_wgen(model)
+    model.train()
+    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    logits = model(_t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"]), (97, 97))
+    loss = torch.nn.functional.cross_entropy(logits, _t(b["qry_mask"][:, 0]), ignore_index=255)
+    loss.backward()
+    res = {"loss": np.array(float(loss.detach()), np.float64)}
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+    res["grad_names"], res["grad_norms"] = np.array(names), np.array(norms, np.float64)
+    plist = dict(model.named_parameters())
+    for k in ("ctr", "encoder.backbone.features.0.weight", "encoder.backbone.features.28.bias",
+              "encoder.backbone.features.14.weight"):
+        g = plist[k].grad
+        res["grad__" + k] = g.numpy() if g.numel() <= 40000 else g.reshape(-1)[::37].numpy()
+    np.savez_compressed(OUT / "stage1_vgg16_trainstep.npz", **res)
+    print("wrote stage-1 VGG16 train step; loss", float(loss.detach()))
+
+
 def stage2_train_prior(qry_mask):
     """Deterministic stand-in for the stage-1 argmax prior of the stage-2 train-step fixture: the query
     foreground shifted by (3, 5) pixels (the real prior path is pinned by the stage-2 eval fixtures)."""
@@ -386,6 +412,8 @@ def main():
             gen_train_step(tmp)
         if only in ("", "trainbase"):
             gen_train_step_baseline(tmp)
+        if only in ("", "trainvgg"):
+            gen_train_step_stage1_vgg(tmp)
         if only in ("", "train2"):
             gen_train_step_stage2(tmp)
         if only in ("", "facts"):

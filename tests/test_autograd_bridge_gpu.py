@@ -127,11 +127,19 @@ def test_reference_trainer_body_runs_on_baseline_and_stage2(hip_lib, dev):
 
 
 def test_stage1_vgg16_trains_through_the_bridge(hip_lib, dev):
-    """Stage 1 on VGG-16 (no purifier; MPM head): loss decreases over a few plain-SGD steps."""
+    """Stage 1 on VGG-16 (no purifier; MPM head): loss and gradients vs the reference's
+    (tests/golden/stage1_vgg16_trainstep.npz), then the loss decreases over a few plain-SGD steps."""
     from pemp_amd.networks import pemp_stage1 as m
     net = m.ModelClass(None, backbone="vgg16").to(dev)
     net.load_state_dict(util.wgen_state_dict("stage1_vgg16"))
     net.train()
+    g = util.gold("stage1_vgg16_trainstep")
+    sup, msk, qry, gt, _ = _batch(dev)
+    loss = F.cross_entropy(net(sup, msk, qry, (97, 97)), gt, ignore_index=255)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    _check_grads(net, g, 1e-2, 1.5e-2)
+    net.zero_grad()
     opt = torch.optim.SGD(net.parameters(), lr=2e-3, momentum=0.9, weight_decay=5e-4)
     sup, msk, qry, gt, _ = _batch(dev)
     losses = []
