@@ -34,6 +34,35 @@ def synthetic_batches(bs, shot, n_steps, seed, rank, height=401, width=401):
             torch.from_numpy(b["qry_mask"])
 
 
+def decoded_batches(bs, shot, n_steps, seed, rank, height=401, width=401):
+    """Training episodes as the loader holds them right after ``Image.open`` (uint8 images / label images at their
+    own sizes) plus the reference's augmentation draws (random scale, flip, ColorJitter, crop_obj window;
+    data_kits/pascal_voc.py:194-226) from a per-rank Python ``random`` stream.  Yields Sample lists for
+    ``pemp_amd.data_kits.episode.EpisodeLoader``: every pixel operation then runs on the device."""
+    import random
+    from ..data_kits import synth_u8
+    from ..data_kits.episode import train_samples
+    sizes = ((375, 500), (333, 500), (500, 375), (366, 500), (457, 500))
+    rng = random.Random(seed * 7919 + rank)
+    for step in range(n_steps):
+        samples = []
+        for i in range(bs):
+            s = seed + (step * 1000003 + rank * 7919 + i) % 2 ** 30
+            hs, ws = sizes[s % len(sizes)]
+            hs, ws = max(hs, height), max(ws, width)          # the reference's images are at least as large as its crops
+            pairs = [(synth_u8.image(s * 8 + k, hs, ws), synth_u8.mask(s * 8 + k, hs, ws)) for k in range(shot + 1)]
+            samples += train_samples(pairs[:shot], pairs[shot:], height, width, rng)
+        yield samples
+
+
+def device_batches(loader, bs, shot, height, width):
+    """EpisodeLoader outputs -> ((sup_img, sup_mask, qry_img), qry_mask) in the reference's batch layout, on the device."""
+    for img, planes, labels in loader:
+        img = img.view(bs, shot + 1, 3, height, width)
+        yield (img[:, :shot].contiguous(), planes.view(bs, shot, 2, height, width), img[:, shot:].contiguous()), \
+            torch.stack(labels).view(bs, 1, height, width)
+
+
 def broadcast_model(model, src=0):
     """Identical start on every rank (parameters and BN buffers)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -56,7 +85,7 @@ def build_trainer(model_name, shot, lr, dev):
     raise ValueError(f"unknown model {model_name!r}")
 
 
-def main(steps=20, bs=4, shot=1, lr=1e-3, seed=1234, log_every=5, model="stage1"):
+def main(steps=20, bs=4, shot=1, lr=1e-3, seed=1234, log_every=5, model="stage1", decoded=0, height=401, width=401):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -70,8 +99,14 @@ def main(steps=20, bs=4, shot=1, lr=1e-3, seed=1234, log_every=5, model="stage1"
     broadcast_model(model)
     if getattr(trainer, "stage1", None) is not None:
         broadcast_model(trainer.stage1)
+    if decoded:      # uint8 "decoded" episodes -> device-side resize / jitter / flip / crop / normalise, prefetched
+        from ..data_kits.episode import EpisodeLoader, EpisodeTransform
+        loader = EpisodeLoader(decoded_batches(bs, shot, steps, seed, rank, height, width), EpisodeTransform(height, width, device=dev))
+        batches = device_batches(loader, bs, shot, height, width)
+    else:
+        batches = synthetic_batches(bs, shot, steps, seed, rank, height, width)
     t0 = time.time()
-    for i, (inputs, qry_msk) in enumerate(synthetic_batches(bs, shot, steps, seed, rank)):
+    for i, (inputs, qry_msk) in enumerate(batches):
         loss = trainer.train_step(*inputs, qry_msk=qry_msk)
         if rank == 0 and (i + 1) % log_every == 0:
             print(f"step {i + 1}/{steps} loss {loss.item():.5f} |g| {trainer.last_grad_norm.item():.4f} "

@@ -183,3 +183,17 @@ def test_evaluator_on_decoded_episodes_equals_host_preprocessing(hip_lib, dev):
         res.append(ev.start_eval_loop(cls_(6, 5678, 1, split=0, height=97, width=97), 20, 0, te_epochs=2))
     (l0, m0, b0), (l1, m1, b1) = res
     assert l0 == l1 and np.array_equal(m0, m1) and np.array_equal(b0, b1)
+
+
+def test_training_main_on_decoded_episodes(hip_lib, dev):
+    """Training harness fed by the device-side input pipeline (augmentation draws on the host, pixels on the GPU)."""
+    from pemp_amd.entry import train_stage1 as t
+    model = t.main(steps=3, bs=2, shot=1, lr=1e-3, seed=11, log_every=100, model="stage1", decoded=1, height=97, width=97)
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    # the generator alone: shapes and value ranges of one device batch
+    from pemp_amd.data_kits.episode import EpisodeLoader, EpisodeTransform
+    loader = EpisodeLoader(t.decoded_batches(2, 1, 1, 5, 0, 97, 97), EpisodeTransform(97, 97, device=dev))
+    (sup, msk, qry), lab = next(t.device_batches(loader, 2, 1, 97, 97))
+    assert tuple(sup.shape) == (2, 1, 3, 97, 97) and tuple(msk.shape) == (2, 1, 2, 97, 97) and tuple(lab.shape) == (2, 1, 97, 97)
+    assert torch.equal(msk[:, :, 0] + msk[:, :, 1], torch.ones_like(msk[:, :, 0])) and set(lab.unique().tolist()) <= {0, 1}
+    assert lab.dtype == torch.int64 and sup.abs().max() < 3.0
