@@ -89,6 +89,24 @@ def test_stage1_matches_cpu_oracle_batched(model, dev):
     assert (got.cpu().argmax(1) == ref.argmax(1)).float().mean().item() > 0.998
 
 
+def test_stage1_non_square_and_odd_sizes(model, dev):
+    """Non-square inputs whose feature maps are not multiples of anything (65 x 131 -> 9 x 17 features; 130 x 73):
+    every conv / pool / resize index map, the head and the tail vs the oracle."""
+    from oracle import ref_cpu
+    from pemp_amd import synth
+    sd = util.wgen_state_dict("stage1_rn50")
+    for seed, (H, W), out in ((41, (65, 131), (50, 203)), (42, (130, 73), (130, 73))):
+        ep = synth.make_episode(seed, shot=1, height=H, width=W, out_hw=out)
+        t = lambda a: torch.from_numpy(a)[None]
+        sup, msk, qry = t(ep["sup_img"]), t(ep["sup_mask"]), t(ep["qry_img"])
+        with torch.no_grad():
+            ref = ref_cpu.stage1_forward(sd, sup, msk, qry, out)
+            got = model(sup.to(dev), msk.to(dev), qry.to(dev), out)
+        assert got.shape == ref.shape
+        assert (got.cpu() - ref).abs().max().item() < 5e-3, (H, W)
+        assert (got.cpu().argmax(1) == ref.argmax(1)).float().mean().item() > 0.998
+
+
 def test_stage1_default_out_shape_and_errors(model, dev):
     t = util.episode_tensors(3, 1, 97, (97, 97), dev)
     with torch.no_grad():
