@@ -240,8 +240,6 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
         const int h = (int)(t % H);
         const int n = (int)(t / H);
         const int C = C4 * 4;
-        const float4 xv4 = *(const float4*)(x + (((long long)n * H + h) * W + w) * C + c);
-        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         // output windows (ho, wo) with ho*s - p <= h < ho*s - p + k
         const int ho_lo = max(0, (h + p - k + s) / s), ho_hi = min(Ho - 1, (h + p) / s);
@@ -252,21 +250,23 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
                 const int w0 = max(wo * s - p, 0), w1 = min(wo * s - p + k, W);
                 const float4 g4 = *(const float4*)(dy + (((long long)n * Ho + ho) * Wo + wo) * C + c);
                 const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+                // first (scan-order) maximum of this window per channel, one 16-byte load per window element
+                float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int bpos[4] = {-1, -1, -1, -1};
+                for (int hh = h0; hh < h1; ++hh)
+                    for (int ww = w0; ww < w1; ++ww) {
+                        const float4 v4 = *(const float4*)(x + (((long long)n * H + hh) * W + ww) * C + c);
+                        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // is (h,w) the first maximum of this window for channel c+e ?
-                    bool win = true;
-                    for (int hh = h0; hh < h1 && win; ++hh)
-                        for (int ww = w0; ww < w1; ++ww) {
-                            const float v = x[(((long long)n * H + hh) * W + ww) * C + c + e];
-                            const bool before = hh < h || (hh == h && ww < w);
-                            if (v > xv[e] || (before && v == xv[e])) {
-                                win = false;
-                                break;
+                        for (int e = 0; e < 4; ++e)
+                            if (v[e] > best[e] || bpos[e] < 0) {
+                                best[e] = v[e];
+                                bpos[e] = hh * W + ww;
                             }
-                        }
-                    if (win) acc[e] += gv[e];
-                }
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (bpos[e] == h * W + w) acc[e] += gv[e];
             }
         *(float4*)(dx + (((long long)n * H + h) * W + w) * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }

@@ -166,6 +166,10 @@ class _BN:
     def stats(self, z, ws):
         return T.bn_stats(z, self.bn.eps, BN_MOM, self.bn.running_mean, self.bn.running_var, ws_cache=ws)
 
+    def grad_out(self):
+        """(dgamma, dbeta) destinations inside the flat gradient buffer, or None for a frozen BatchNorm."""
+        return (self.bn.weight.grad, self.bn.bias.grad) if self.bn.weight.requires_grad else None
+
     def write_grads(self, dgamma, dbeta):
         if self.bn.weight.requires_grad:
             self.bn.weight.grad.copy_(dgamma)
@@ -239,9 +243,8 @@ class Stage1TrainEngine:
         gradient at the conv output stays in rec["dz"]."""
         dz = torch.empty_like(rec["z"])
         gout = torch.empty_like(rec["z"]) if want_gout else None
-        dgamma, dbeta = T.bn_bwd(dy, rec["y"], rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, dz, gout=gout,
-                                 relu=rec["relu"], ws_cache=self.ws)
-        bn.write_grads(dgamma, dbeta)
+        T.bn_bwd(dy, rec["y"], rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, dz, gout=gout, relu=rec["relu"],
+                 ws_cache=self.ws, out=bn.grad_out())            # dgamma / dbeta go straight into the flat gradient buffer
         conv.wgrad(rec["x"], dz, self.ws)
         rec["dz"] = dz
         dx = ops.conv2d(dz, conv.dgrad_params(), residual=add_to) if need_dx else None

@@ -48,8 +48,9 @@ def bn_apply(z, mean, invstd, gamma, beta, out, residual=None, relu=True):
     return out
 
 
-def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=None):
-    """-> (dgamma, dbeta); writes dz (and gout = dy*(y>0), the gradient of the residual branch)."""
+def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=None, out=None):
+    """-> (dgamma, dbeta); writes dz (and gout = dy*(y>0), the gradient of the residual branch).
+    ``out=(dgamma, dbeta)``: contiguous [C] tensors to write into (e.g. the flat-buffer gradient views)."""
     lib = _lib.load()
     _chk_dev(dy, y, z, dz, gout)
     m, c, lddy = _rows(dy, "dy")
@@ -57,8 +58,13 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=Non
     ldz = _rows(z, "z")[2]
     lddz = _rows(dz, "dz")[2]
     ldg = _rows(gout, "gout")[2] if gout is not None else 0
-    dgamma = torch.empty(c, dtype=torch.float32, device=dy.device)
-    dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
+    if out is not None:
+        dgamma, dbeta = out
+        if not (dgamma.is_contiguous() and dbeta.is_contiguous() and dgamma.numel() == c and dbeta.numel() == c):
+            raise ValueError("bn_bwd: out tensors must be contiguous [C]")
+    else:
+        dgamma = torch.empty(c, dtype=torch.float32, device=dy.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
     ws = _ws(lib.pemp_colsum_workspace_bytes(m, c), dy.device, ws_cache, ("colsum", m, c))
     _lib.check(lib.pemp_bn_bwd_f32(_p(dy), lddy, _p(y), ldy, _p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(dz), lddz,
                                    _p(gout), ldg, _p(dgamma), _p(dbeta), m, c, 1 if relu else 0, _p(ws), ws.numel(),
@@ -66,15 +72,18 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=Non
     return dgamma, dbeta
 
 
-def relu_bias_bwd(dy, y, g, add=None, relu=True, want_dbias=True, ws_cache=None):
-    """g = (dy (+ add)) * (y > 0 if relu); returns dbias = column sums of g (or None)."""
+def relu_bias_bwd(dy, y, g, add=None, relu=True, want_dbias=True, ws_cache=None, out=None):
+    """g = (dy (+ add)) * (y > 0 if relu); returns dbias = column sums of g (or None); ``out``: contiguous [C]
+    tensor to write dbias into (e.g. the bias gradient view of the flat buffer)."""
     lib = _lib.load()
     _chk_dev(dy, y, g, add)
     m, c, lddy = _rows(dy, "dy")
     ldy = _rows(y, "y")[2] if y is not None else 0
     lda = _rows(add, "add")[2] if add is not None else 0
     ldg = _rows(g, "g")[2]
-    dbias = torch.empty(c, dtype=torch.float32, device=dy.device) if want_dbias else None
+    if out is not None and not (out.is_contiguous() and out.numel() == c):
+        raise ValueError("relu_bias_bwd: out must be a contiguous [C] tensor")
+    dbias = (out if out is not None else torch.empty(c, dtype=torch.float32, device=dy.device)) if want_dbias else None
     ws = _ws(lib.pemp_colsum_workspace_bytes(m, c), dy.device, ws_cache, ("colsum", m, c)) if want_dbias else None
     _lib.check(lib.pemp_relu_bias_bwd_f32(_p(dy), lddy, _p(y), ldy, _p(add), lda, _p(g), ldg, _p(dbias), m, c,
                                           1 if relu else 0, _p(ws), ws.numel() if ws is not None else 0, _stream()),
