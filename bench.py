@@ -39,8 +39,9 @@ def parse():
                     help="episodes per step (the reference evaluates 1 per step); 25 -> 50 x 2601 feature rows, "
                          "which fill the 256-row conv tiles and the 256 CUs almost exactly")
     ap.add_argument("--shot", type=int, default=1)
-    ap.add_argument("--model", choices=("stage1", "stage2"), default="stage1",
-                    help="stage1 = headline; stage2 = stage-1 prior + stage-2 (use with --shot 5 for configs[3])")
+    ap.add_argument("--model", choices=("stage1", "stage2", "baseline"), default="stage1",
+                    help="stage1 = headline; stage2 = stage-1 prior + stage-2 (use with --shot 5 for configs[3]); "
+                         "baseline = Baseline VGG-16 (configs[0])")
     ap.add_argument("--mode", choices=("eval", "train"), default="eval",
                     help="eval (headline metric, BASELINE.json configs[1]) or train (configs[2])")
     ap.add_argument("--no-graph", action="store_true")
@@ -317,7 +318,15 @@ def main():
         dist.barrier()
     if args.mode == "train":
         return main_train(args, world, rank, dev)
-    net, sd = build_model(dev)
+    if args.model == "baseline":        # BASELINE.json configs[0]: Baseline, VGG-16, 1-shot
+        from pemp_amd.networks import baseline as mb
+        from tests import util
+        sd = util.wgen_state_dict("baseline_vgg16")
+        net = mb.Baseline(None, backbone="vgg16")
+        net.load_state_dict(sd)
+        net = net.to(dev).eval()
+    else:
+        net, sd = build_model(dev)
     pool = episode_pool(dev, args.shot, args.batch, rank)
     ws = {}
     stats_log = torch.zeros((args.steps, args.batch, 8), dtype=torch.float64, device=dev)
@@ -372,21 +381,26 @@ def main():
     if rank == 0:
         eps_total = args.steps * args.batch * world
         out = {
-            "metric": "episodes/sec (PEMP %s eval step, PASCAL-5i-shaped %d-shot, ResNet-50)" % (
-                "stage-1" if stage2 is None else "stage-1 prior + stage-2", args.shot),
+            "metric": "episodes/sec (%s eval step, PASCAL-5i-shaped %d-shot, %s)" % (
+                "Baseline" if args.model == "baseline" else "PEMP stage-1" if stage2 is None else "PEMP stage-1 prior + stage-2",
+                args.shot, "VGG-16" if args.model == "baseline" else "ResNet-50"),
             "value": round(eps_total / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "pemp_%s eval test_step, ResNet-50, %d-shot, 401x401, %d episode(s)/step, "
-                                   "synthetic E(seed) episodes + Wgen(1234) weights" % (args.model, args.shot, args.batch),
+            "config": {"workload": "%s eval test_step, %s, %d-shot, 401x401, %d episode(s)/step, "
+                                   "synthetic E(seed) episodes + Wgen(1234) weights" % (
+                                       "baseline" if args.model == "baseline" else "pemp_" + args.model,
+                                       "VGG-16" if args.model == "baseline" else "ResNet-50", args.shot, args.batch),
                        "episodes_per_step": args.batch, "shot": args.shot, "hipgraph": not args.no_graph,
                        "mean_ce_loss": round(mean_loss, 6)},
         }
         if not args.no_roofline and stage2 is None:
             out["roofline"] = conv_roofline(net, pool)
-        if world == 1 and stage2 is None and not args.no_graph and not args.no_e2e:
+            if args.model != "stage1":
+                out["roofline"]["traffic"] = None        # the committed PMC run is the stage-1 workload
+        if world == 1 and args.model == "stage1" and not args.no_graph and not args.no_e2e:
             out["end_to_end"] = end_to_end(net, args, dev)
-        if world == 1 and args.cpu_episodes > 0:
+        if world == 1 and args.cpu_episodes > 0 and args.model != "baseline":
             out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in sd.items()}, args.shot, args.cpu_episodes)
     if world > 1:
         dist.barrier()
