@@ -203,5 +203,69 @@ def test(_config, split, shot, seed, test_n, test_seed, te_epochs):
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
 
 
+#: response-map palette of the reference's viewer (core/base_trainer.py:348-349, listed there in BGR for cv2): rows 0-2 =
+#: background prototypes, 3-5 = foreground prototypes; RGB here (PIL writes RGB)
+RESPONSE_PALETTE_RGB = np.array([[25, 70, 147], [30, 116, 179], [112, 172, 207],
+                                 [100, 11, 12], [193, 32, 38], [247, 178, 78]], np.uint8)
+PASCAL_CLASSES = ("background", "aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow",
+                  "diningtable", "dog", "horse", "motorbike", "person", "potted plant", "sheep", "sofa", "train", "tv/monitor")
+
+
+def evaluate_and_save(model, dataset, out_dir, n_episodes, device=None):
+    """Counterpart of ``evaluate_and_save`` (reference core/base_trainer.py:311-403, driven by ``visualize``,
+    entry/pemp_stage1.py:199-222): per episode run ``model(..., ret_ind=True)`` and write, under
+    ``<out_dir>/<i>_<cls>/``, the support / query images and label images, the binary prediction, the
+    response map coloured with the viewer's palette and ``data.json`` (Dice "acc", class id / name, sample names).
+    ``dataset`` provides ``decoded_task(i)`` (uint8 sources).  Returns the list of Dice scores."""
+    import json
+    from pathlib import Path
+    from PIL import Image
+    from ..data_kits.episode import EpisodeTransform, test_samples
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    tf = EpisodeTransform(dataset.height, dataset.width, device=device)
+    dataset.reset_sampler()
+    dataset.sample_tasks()
+    S, accs = dataset.shot, []
+    model.eval()
+    for i in range(n_episodes):
+        sup, qry, cls = dataset.decoded_task(i)
+        img, planes, labels = tf(test_samples(sup, qry, dataset.height, dataset.width))
+        label = labels[0]
+        with torch.no_grad():
+            logits, indices = model(img[:S][None], planes[None], img[S:][None], out_shape=tuple(label.shape), ret_ind=True)
+        pred = logits.argmax(dim=1)[0]
+        acc = float((pred * label).sum() * 2) / max(float(pred.sum() + label.sum()), 1.0)
+        accs.append(acc)
+        cname = PASCAL_CLASSES[cls].replace("/", "_") if 0 <= cls < len(PASCAL_CLASSES) else str(cls)
+        save = Path(out_dir) / f"{i:03d}_{cls:02d}"
+        save.mkdir(parents=True, exist_ok=True)
+        data = {"acc": str(round(acc, 3)), "cls_id": int(cls), "cls_name": cname, "qry": f"q{i}"}
+        for j, (im, lab) in enumerate(sup):
+            key = "sup" if S == 1 else f"sup{j + 1}"
+            data[key] = f"s{i}_{j}"
+            Image.fromarray(im).save(save / f"{cname}_sup_img_{data[key]}.jpg")
+            Image.fromarray(lab).save(save / f"{cname}_sup_msk_{data[key]}.png")
+        Image.fromarray(qry[0][0]).save(save / f"{cname}_qry_img_{data['qry']}.jpg")
+        Image.fromarray(qry[0][1]).save(save / f"{cname}_qry_msk_{data['qry']}.png")
+        Image.fromarray((pred.cpu().numpy() * 255).astype(np.uint8)).save(save / f"{cname}_qry_pred_{data['qry']}.png")
+        Image.fromarray(RESPONSE_PALETTE_RGB[indices[0].cpu().numpy()]).save(save / f"{cname}_qry_color_{data['qry']}.png")
+        (save / "data.json").write_text(json.dumps(data))
+    return accs
+
+
+@ex.command
+def visualize(_config, split, shot, seed, test_n, test_seed, tag, exp_id):
+    """``python -m pemp_amd.entry.pemp_stage1 visualize with split=0 test_n=20``: predictions and response maps of
+    the first ``test_n`` evaluation episodes into ``http/static/<exp>`` (the layout the reference's html viewer reads)."""
+    if split < 0:
+        raise ValueError("Argument `split` is required!")
+    torch.manual_seed(seed)
+    model = ModelClass(None).cuda().eval()
+    data = SyntheticDecodedEpisodes(test_n, test_seed, shot, split)
+    out = f"http/static/{exp_id}_pascal_{shot}shot_{tag}_s{split}"
+    accs = evaluate_and_save(model, data, out, test_n)
+    return f"saved {len(accs)} episodes to {out}; mean Dice {np.mean(accs):.3f}"
+
+
 if __name__ == "__main__":
     print(ex.run_commandline())

@@ -197,3 +197,35 @@ def test_training_main_on_decoded_episodes(hip_lib, dev):
     assert tuple(sup.shape) == (2, 1, 3, 97, 97) and tuple(msk.shape) == (2, 1, 2, 97, 97) and tuple(lab.shape) == (2, 1, 97, 97)
     assert torch.equal(msk[:, :, 0] + msk[:, :, 1], torch.ones_like(msk[:, :, 0])) and set(lab.unique().tolist()) <= {0, 1}
     assert lab.dtype == torch.int64 and sup.abs().max() < 3.0
+
+
+def test_visualize_writes_predictions_and_response_maps(hip_lib, dev, tmp_path):
+    """evaluate_and_save (reference core/base_trainer.py:311-403): files, palette, Dice and ret_ind consistency."""
+    import json
+    from PIL import Image
+    from pemp_amd.entry import pemp_stage1 as e
+    net = e.ModelClass(None)
+    net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    net = net.to(dev).eval()
+
+    class Small(e.SyntheticDecodedEpisodes):
+        SIZES = ((90, 120), (97, 97))
+
+    accs = e.evaluate_and_save(net, Small(2, 5678, 1, split=0, height=97, width=97), tmp_path, 2, device=dev)
+    dirs = sorted(p for p in tmp_path.iterdir())
+    assert len(dirs) == 2 and len(accs) == 2 and all(0.0 <= a <= 1.0 for a in accs)
+    for d in dirs:
+        meta = json.loads((d / "data.json").read_text())
+        names = sorted(p.name for p in d.iterdir())
+        assert len(names) == 7 and abs(float(meta["acc"]) - accs[dirs.index(d)]) < 1e-3
+        cname = meta["cls_name"]
+        pred = np.asarray(Image.open(d / f"{cname}_qry_pred_{meta['qry']}.png"))
+        color = np.asarray(Image.open(d / f"{cname}_qry_color_{meta['qry']}.png"))
+        lab = np.asarray(Image.open(d / f"{cname}_qry_msk_{meta['qry']}.png"))
+        assert pred.shape == lab.shape and color.shape == lab.shape + (3,) and set(np.unique(pred)) <= {0, 255}
+        # every pixel carries one of the six palette colours; foreground-prototype colours (rows 3..5) sit where the
+        # prediction is foreground, up to the boundary band where nearest (response) and bilinear (logits) upsampling differ
+        pal = e.RESPONSE_PALETTE_RGB
+        assert (color[..., None, :] == pal[None, None]).all(-1).any(-1).all()
+        is_fg_color = (color[..., None, :] == pal[3:][None, None]).all(-1).any(-1)
+        assert (is_fg_color == (pred == 255)).mean() > 0.9
