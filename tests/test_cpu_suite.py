@@ -343,3 +343,79 @@ def test_episode_plan_and_host_draws(hip_lib):
     assert [(s.scaled, s.crop, s.flip, s.jitter) for s in a] == [(s.scaled, s.crop, s.flip, s.jitter) for s in b]
     assert 97 <= a[0].scaled[0] <= 145 and a[1].scaled == (97, 97) and a[1].mask_mode == 2
     assert sorted(a[0].jitter[0]) == ["brightness", "contrast", "saturation"]
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoint / pretrained-weight compatibility (reference backbones.py:22-39,138-157,
+# 249-276,407-421): torchvision-layout files import by the reference's rules, checkpoints round-trip
+# ---------------------------------------------------------------------------------------------
+def _torchvision_like_resnet50():
+    """Key layout of torchvision's resnet50 state_dict (conv1, bn1, layer1..4, fc), random values."""
+    g = torch.Generator().manual_seed(7)
+    sd = {}
+
+    def bn(prefix, c):
+        for k, v in (("weight", torch.rand(c, generator=g)), ("bias", torch.randn(c, generator=g)),
+                     ("running_mean", torch.randn(c, generator=g)), ("running_var", torch.rand(c, generator=g) + 0.5),
+                     ("num_batches_tracked", torch.tensor(3))):
+            sd[f"{prefix}.{k}"] = v
+
+    sd["conv1.weight"] = torch.randn(64, 3, 7, 7, generator=g)
+    bn("bn1", 64)
+    cin = 64
+    for li, (planes, nblk) in enumerate(((64, 3), (128, 4), (256, 6), (512, 3)), start=1):
+        for b in range(nblk):
+            p = f"layer{li}.{b}"
+            sd[p + ".conv1.weight"] = torch.randn(planes, cin if b == 0 else planes * 4, 1, 1, generator=g)
+            bn(p + ".bn1", planes)
+            sd[p + ".conv2.weight"] = torch.randn(planes, planes, 3, 3, generator=g)
+            bn(p + ".bn2", planes)
+            sd[p + ".conv3.weight"] = torch.randn(planes * 4, planes, 1, 1, generator=g)
+            bn(p + ".bn3", planes * 4)
+            if b == 0:
+                sd[p + ".downsample.0.weight"] = torch.randn(planes * 4, cin, 1, 1, generator=g)
+                bn(p + ".downsample.1", planes * 4)
+        cin = planes * 4
+    sd["fc.weight"], sd["fc.bias"] = torch.randn(1000, 2048, generator=g), torch.randn(1000, generator=g)
+    return sd
+
+
+def test_pretrained_import_and_checkpoint_roundtrip(tmp_path):
+    import logging
+    from pemp_amd.networks import pemp_stage1 as m1, pemp_stage2 as m2
+    tv = _torchvision_like_resnet50()
+    f = tmp_path / "resnet50-19c8e357.pth"
+    torch.save(tv, f)
+    old = dict(m1.pretrained_weights)
+    try:
+        m1.pretrained_weights["resnet50"] = f
+        s1 = m1.ModelClass(None)
+        s2 = m2.ModelClass(1, 1, None)
+    finally:
+        m1.pretrained_weights.update(old)
+    sd1, sd2 = s1.state_dict(), s2.state_dict()
+    for k, v in tv.items():                                     # everything before layer4 is taken as is (backbones.py:138-157)
+        if k.split(".")[0] in ("layer4", "fc"):
+            assert "encoder.backbone." + k not in sd1
+            continue
+        assert torch.equal(sd1["encoder.backbone." + k], v), k
+    # ResNetCM: 4th stem channel and the two comm channels of each stage's first convs are zero-padded (backbones.py:249-276)
+    w = sd2["encoder.backbone.conv1.weight"]
+    assert w.shape == (64, 4, 7, 7) and torch.equal(w[:, :3], tv["conv1.weight"]) and not w[:, 3].any()
+    for k in ("layer1.0.conv1.weight", "layer2.0.downsample.0.weight", "layer3.0.conv1.weight"):
+        w = sd2["encoder.backbone." + k]
+        c = tv[k].shape[1]
+        assert w.shape[1] == c + 2 and torch.equal(w[:, :c], tv[k]) and not w[:, c:].any(), k
+    assert torch.equal(sd2["encoder.backbone.layer2.1.conv1.weight"], tv["layer2.1.conv1.weight"])
+    # checkpoints: both on-disk forms the reference writes/reads (bare state_dict, {"state_dict": ...}) load back
+    logger = logging.getLogger("t")
+    for wrap in (False, True):
+        ck = tmp_path / f"bestckpt_{wrap}.pth"
+        torch.save({"state_dict": sd1, "epoch": 3} if wrap else sd1, ck)
+        fresh = m1.ModelClass(None)
+        fresh.load_weights(ck, logger)
+        for k, v in fresh.state_dict().items():
+            assert torch.equal(v, sd1[k]), k
+    # stage-1 freezing for stage-2 training (entry/pemp_stage2.py:126-129)
+    s1.maybe_fix_params(True)
+    assert not any(p.requires_grad for p in s1.parameters())
