@@ -38,6 +38,7 @@ def ex_config():
     test_n = 1000               # int, episodes per evaluation round (data.test_n in the reference)
     test_seed = 5678            # int, evaluation sampler seed (data.test_seed)
     te_epochs = 5               # int, evaluation rounds (te.epochs)
+    test_bs = 1                 # int, episodes per evaluation step (data.test_bs = 1 in the reference; metrics are identical for any value)
 
 
 def get_val_labels(split, dataset="PASCAL"):
@@ -123,6 +124,25 @@ class Evaluator:
             am, stats, _ = ops.eval_tail(pred, tgt, ws_cache=self._ws)
         return am, stats
 
+    def test_step_batch(self, episodes):
+        """``episodes``: list of (inputs, qry_msk) with one episode each (any query-label sizes).  One encoder + head
+        pass for all of them, then one fused tail launch per distinct label size.  -> stats f64 [len(episodes), 8] on
+        the GPU, rows in the given order.  Per-episode results are identical to ``test_step_device`` on each episode
+        alone (every image's rows are independent in the conv GEMMs and all kernel variants are bit-identical)."""
+        dev_in = [torch.cat([ep[0][k].to(self.device, non_blocking=True) for ep in episodes]) for k in range(3)]
+        labels = [ep[1].view(-1, *ep[1].shape[-2:]).to(self.device, non_blocking=True) for ep in episodes]
+        with torch.no_grad():
+            pred, _ = self.model.lowres_graphed(*dev_in) if self.use_graph else self.model.lowres(*dev_in)
+            stats = torch.empty((len(episodes), 8), dtype=torch.float64, device=self.device)
+            by_size = {}
+            for i, lab in enumerate(labels):
+                by_size.setdefault(tuple(lab.shape[-2:]), []).append(i)
+            for idx in by_size.values():
+                sel = torch.tensor(idx, device=self.device)
+                _, st, _ = ops.eval_tail(pred.index_select(0, sel), torch.cat([labels[i] for i in idx]), ws_cache=self._ws)
+                stats.index_copy_(0, sel, st)
+        return stats
+
     def test_step(self, inputs, qry_msk, **kwargs):
         """Reference contract (entry/pemp_stage1.py:48-53): -> (qry_pred numpy [B,H,W], loss float)."""
         am, stats = self.test_step_device(inputs, qry_msk)
@@ -151,8 +171,9 @@ class Evaluator:
         for k, (img, planes, labels) in enumerate(EpisodeLoader(batches(), EpisodeTransform(H, W, device=self.device))):
             yield (img[:S][None], planes[None], img[S:][None]), labels[0][None, None], torch.tensor([classes[k]])
 
-    def start_eval_loop(self, dataset, num_classes, split, te_epochs=5, logger=None):
-        """Reference loop (core/base_trainer.py:59-102), sharded over ranks."""
+    def start_eval_loop(self, dataset, num_classes, split, te_epochs=5, logger=None, batch=1):
+        """Reference loop (core/base_trainer.py:59-102), sharded over ranks.  ``batch`` > 1 evaluates that many
+        episodes per step (the reference uses test_bs = 1, data_kits/datasets.py:23); the metrics are identical."""
         self.model.eval()
         dataset.reset_sampler()
         world = dist.get_world_size() if dist.is_initialized() else 1
@@ -164,13 +185,24 @@ class Evaluator:
             metric = FewShotMetric(num_classes)
             dataset.sample_tasks()
             rows, classes = [], []
+            group = []
             for inputs, qry_msk, cls in self._episodes(dataset, shard_indices(len(dataset), rank, world)):
-                t0 = time.time()
-                _, stats = self.test_step_device(inputs, qry_msk)
-                timed += time.time() - t0
-                calls += 1
-                rows.append(stats)
                 classes += [int(c) for c in cls]
+                if batch > 1:
+                    group.append((inputs, qry_msk))
+                    if len(group) < batch:
+                        continue
+                t0 = time.time()
+                stats = self.test_step_batch(group) if batch > 1 else self.test_step_device(inputs, qry_msk)[1]
+                timed += time.time() - t0
+                calls += max(len(group), 1)
+                group = []
+                rows.append(stats)
+            if group:
+                t0 = time.time()
+                rows.append(self.test_step_batch(group))
+                timed += time.time() - t0
+                calls += len(group)
             t0 = time.time()
             st = torch.cat(rows).cpu().numpy() if rows else np.zeros((0, 8))
             timed += time.time() - t0
@@ -188,7 +220,7 @@ class Evaluator:
 
 
 @ex.command
-def test(_config, split, shot, seed, test_n, test_seed, te_epochs):
+def test(_config, split, shot, seed, test_n, test_seed, te_epochs, test_bs):
     """``python -m pemp_amd.entry.pemp_stage1 test with split=0`` on synthetic episodes."""
     import logging
     logging.basicConfig(level=logging.INFO, format="%(message)s")
@@ -199,7 +231,7 @@ def test(_config, split, shot, seed, test_n, test_seed, te_epochs):
     model = ModelClass(logger).cuda().eval()
     data = SyntheticEpisodes(test_n, test_seed, shot, split)
     ev = Evaluator(model)
-    loss, miou, biou = ev.start_eval_loop(data, 20, split, te_epochs, logger)
+    loss, miou, biou = ev.start_eval_loop(data, 20, split, te_epochs, logger, batch=test_bs)
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
 
 

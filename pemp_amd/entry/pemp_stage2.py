@@ -7,15 +7,19 @@ import torch
 from .. import ops
 from ..core.metrics import Accumulator, FewShotMetric  # noqa: F401
 from ..networks.pemp_stage2 import ModelClass, PriorNet, net_ingredient  # noqa: F401
+from .pemp_stage1 import Evaluator as _Stage1Evaluator
 from .pemp_stage1 import SyntheticEpisodes, allreduce_round, get_val_labels, shard_indices  # noqa: F401
 
 
-class Evaluator:
+class Evaluator(_Stage1Evaluator):
+    """Inherits the sharded evaluation loop (``start_eval_loop``); a step is stage-1 prior -> stage 2."""
+
     def __init__(self, stage1, model, device=None, use_graph=True):
-        self.stage1, self.model = stage1, model
-        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.use_graph = use_graph
-        self._ws = {}
+        super().__init__(model, device=device, use_graph=use_graph)
+        self.stage1 = stage1
+
+    def test_step_batch(self, episodes):
+        return torch.cat([self.test_step_device(inputs, qry_msk)[1] for inputs, qry_msk in episodes])
 
     def prior(self, dev_in):
         """Stage-1 argmax at the input size as the float plane the stage-2 stem consumes."""

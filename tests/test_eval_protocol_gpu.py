@@ -46,3 +46,18 @@ def test_eval_round_miou_matches_cpu_oracle(hip_lib, dev):
     assert abs(got_miou - ref_miou) <= 1e-4
     assert abs(got_biou - ref_biou) <= 1e-4
     assert abs(loss - float(np.mean(losses))) <= 1e-4
+
+
+def test_batched_evaluation_gives_identical_metrics(hip_lib, dev):
+    """start_eval_loop(batch=4) (several episodes per encoder pass, one tail launch per label size, ragged last
+    group) returns exactly the metrics of the reference-style one-episode-per-step loop."""
+    from pemp_amd.entry import pemp_stage1 as e
+    net = e.ModelClass(None)
+    net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    net = net.to(dev).eval()
+    res = []
+    for batch in (1, 4):
+        ev = e.Evaluator(net, device=dev)
+        res.append(ev.start_eval_loop(e.SyntheticEpisodes(10, 5678, 1, split=0, height=97, width=97), 20, 0, te_epochs=1, batch=batch))
+    (l0, m0, b0), (l1, m1, b1) = res
+    assert l0 == l1 and np.array_equal(m0, m1) and np.array_equal(b0, b1)
