@@ -183,3 +183,25 @@ class Experiment(Ingredient):
             print("commands:", ", ".join(self.commands))
             return None
         return self.run(command, updates)
+
+
+# ---------------------------------------------------------------------------------------------
+# global / device ingredients of the reference (config.py:13-63): accepted for command-line compatibility
+# ---------------------------------------------------------------------------------------------
+global_ingredient = Ingredient("g")
+device_ingredient = Ingredient("d")
+
+
+@global_ingredient.config
+def global_config():
+    model_dir = "model_dir"         # str, directory of checkpoints / file-storage observers
+    fileStorage = False             # bool, Sacred FileStorage observer (not built: no observers here)
+    mongodb = True                  # bool, Sacred MongoDB observer (not built)
+    mongo_port = 7000               # int
+
+
+@device_ingredient.config
+def device_config():
+    enable_gpu = True               # bool; the HIP path has no CPU fallback, False raises at model use
+    num_threads = 1                 # int, torch CPU threads
+    cudnn = {"enabled": True, "benchmark": True}    # accepted, meaningless on MI355X

@@ -4,10 +4,10 @@ stage 1; the model is ``pemp_amd.networks.baseline.Baseline`` (full-resolution m
 through the adjoint of the bilinear upsample)."""
 from ..config import Experiment
 from ..networks.baseline import ModelClass, net_ingredient  # noqa: F401
-from .pemp_stage1 import Evaluator, SyntheticEpisodes, get_val_labels  # noqa: F401
+from .pemp_stage1 import INGREDIENTS, Evaluator, SyntheticEpisodes, get_val_labels  # noqa: F401
 
 NAME = "Baseline"
-ex = Experiment(name=NAME, ingredients=[net_ingredient])
+ex = Experiment(name=NAME, ingredients=[net_ingredient] + INGREDIENTS[1:])      # own ``net`` (backbone = vgg16) + data, tr, te, g, d
 
 
 @ex.config
@@ -21,13 +21,10 @@ def ex_config():
     exp_id = -1                 # experiment id to load checkpoint
     loss = "ce"                 # str, loss type [ce/cedt]
     sigma = 5.                  # float, sigma of the DT loss
-    test_n = 1000               # int, episodes per evaluation round
-    test_seed = 5678            # int, evaluation sampler seed
-    te_epochs = 5               # int, evaluation rounds
 
 
 @ex.command
-def test(_config, split, shot, test_n, test_seed, te_epochs):
+def test(_config, split, shot):
     import logging
     import numpy as np
     logging.basicConfig(level=logging.INFO, format="%(message)s")
@@ -36,7 +33,10 @@ def test(_config, split, shot, test_n, test_seed, te_epochs):
         raise ValueError("Argument `split` is required! For example: `python -m pemp_amd.entry.baseline test with split=0`")
     model = ModelClass(logger).cuda().eval()
     ev = Evaluator(model)
-    loss, miou, biou = ev.start_eval_loop(SyntheticEpisodes(test_n, test_seed, shot, split), 20, split, te_epochs, logger)
+    d = _config["data"]
+    data = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"])
+    loss, miou, biou = ev.start_eval_loop(data, 20 if d["dataset"] == "PASCAL" else 80, split, _config["te"]["epochs"], logger,
+                                          batch=d["test_bs"], dataset_name=d["dataset"])
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
 
 

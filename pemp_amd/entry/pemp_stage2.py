@@ -7,8 +7,27 @@ import torch
 from .. import ops
 from ..core.metrics import Accumulator, FewShotMetric  # noqa: F401
 from ..networks.pemp_stage2 import ModelClass, PriorNet, net_ingredient  # noqa: F401
+from ..config import Experiment
 from .pemp_stage1 import Evaluator as _Stage1Evaluator
-from .pemp_stage1 import SyntheticEpisodes, allreduce_round, get_val_labels, shard_indices  # noqa: F401
+from .pemp_stage1 import INGREDIENTS, SyntheticEpisodes, allreduce_round, get_val_labels, shard_indices  # noqa: F401
+
+NAME = "PEMP_Stage2"
+ex = Experiment(name=NAME, ingredients=INGREDIENTS)
+
+
+@ex.config
+def ex_config():
+    tag = "pemp_stage2"         # str, configuration tag
+    shot = 1                    # int, support samples per episode
+    query = 1                   # int, query samples per episode (must stay 1)
+    split = -1                  # int, split number [0, 1, 2, 3], required
+    seed = 1234                 # int, random seed
+    ckpt = "bestckpt.pth"       # str, checkpoint file of stage 2
+    exp_id = -1                 # experiment id to load checkpoint
+    loss = "ce"                 # str, loss type [ce/cedt]
+    sigma = 5.                  # float, sigma of the DT loss
+    s1 = {"ckpt": "bestckpt.pth", "id": -1}         # checkpoint / experiment id of the stage-1 model (entry/pemp_stage2.py:39-42)
+    p = {"cls": -1, "sup": "", "qry": ""}
 
 
 class Evaluator(_Stage1Evaluator):
@@ -59,3 +78,27 @@ class Trainer:
                 return super().train_step(*inputs, qry_msk=qry_msk.view(-1, *qry_msk.shape[-2:]))
 
         return _Trainer(stage1, model, **kw)
+
+
+@ex.command
+def test(_config, split, shot, seed):
+    """``python -m pemp_amd.entry.pemp_stage2 test with split=0 shot=5``: stage-1 prior -> stage 2 on synthetic episodes."""
+    import logging
+    import numpy as np
+    logging.basicConfig(level=logging.INFO, format="%(message)s")
+    logger = logging.getLogger(NAME)
+    if split < 0:
+        raise ValueError("Argument `split` is required! For example: `python -m pemp_amd.entry.pemp_stage2 test with split=0`")
+    torch.manual_seed(seed)
+    stage1 = PriorNet(logger).cuda().eval()
+    model = ModelClass(shot, _config["query"], logger).cuda().eval()
+    d = _config["data"]
+    data = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"])
+    ev = Evaluator(stage1, model)
+    loss, miou, biou = ev.start_eval_loop(data, 20 if d["dataset"] == "PASCAL" else 80, split, _config["te"]["epochs"], logger,
+                                          batch=d["test_bs"], dataset_name=d["dataset"])
+    return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
+
+
+if __name__ == "__main__":
+    print(ex.run_commandline())

@@ -214,6 +214,24 @@ def test_entry_config_surface():
     assert cfg["net"] == dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
                               drop_rate=0.1, block_size=4)
     assert e.get_val_labels(0) == [1, 2, 3, 4, 5] and e.get_val_labels(1, "COCO") == list(range(21, 41))
+    # the reference's complete key surface: data / tr / te / g / d ingredients, p, and s1 for stage 2
+    assert cfg["p"] == {"cls": -1, "sup": "", "qry": ""}
+    assert cfg["data"] == dict(dataset="PASCAL", base_dir="", mean=[.485, .456, .406], std=[.229, .224, .225], height=401, width=401,
+                               bs=4, test_bs=1, num_workers=4, pin_memory=True, train_n=5000, test_n=1000, seed=1234,
+                               test_seed=5678, one_cls=0, cache=True)
+    assert cfg["te"] == {"epochs": 5} and cfg["tr"]["lr"] == 1e-3 and cfg["tr"]["lrp"] == "period_step" and cfg["tr"]["opt"] == "sgd"
+    assert cfg["g"]["model_dir"] == "model_dir" and cfg["d"]["cudnn"] == {"enabled": True, "benchmark": True}
+    upd = e.ex.apply_updates({"data.test_n": 50, "data.bs": 2, "tr.lr": 0.01, "te.epochs": 1, "net.protos": 0})
+    assert upd["data"]["test_n"] == 50 and upd["data"]["num_workers"] == 2 and upd["tr"]["lr"] == 0.01 and upd["te"]["epochs"] == 1
+    for ing, key in ((e.data_ingredient, "test_n"), (e.data_ingredient, "bs"), (e.train_ingredient, "lr"), (e.test_ingredient, "epochs")):
+        ing._updates.pop(key, None)
+        ing._cfg = None
+    e.net_ingredient._updates.pop("protos", None)
+    e.net_ingredient._cfg = None
+    from pemp_amd.entry import pemp_stage2 as e2, baseline as eb
+    c2, cb = e2.ex.full_config(), eb.ex.full_config()
+    assert c2["s1"] == {"ckpt": "bestckpt.pth", "id": -1} and c2["tag"] == "pemp_stage2" and c2["net"]["protos2"] == 3
+    assert cb["net"]["backbone"] == "vgg16" and cb["tag"] == "baseline" and cb["data"]["test_n"] == 1000
 
 
 # ---------------------------------------------------------------------------------------------
