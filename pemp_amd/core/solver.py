@@ -75,8 +75,10 @@ class PolyLR:
             step = self.last_step
         else:
             self.last_step = step
+        # the reference's constructor already consumes one step, so its last call has step = max_iter + 1 and a negative
+        # base (a complex number in Python 3); clamped here
         self.optimizer.param_groups[0]["lr"] = \
-            (self.init_lr - self.lr_end) * (1 - step / self.max_iter) ** self.power + self.lr_end
+            (self.init_lr - self.lr_end) * max(1 - step / self.max_iter, 0.0) ** self.power + self.lr_end
 
 
 def get(model, _config=None, max_steps=200001):

@@ -233,6 +233,40 @@ def test(_config, split, shot, seed):
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
 
 
+@ex.command
+def train(_config, split, shot, seed, loss, sigma, exp_id):
+    """``python -m pemp_amd.entry.pemp_stage1 train with split=0 tr.total_epochs=3 data.train_n=5000``: the reference's
+    training procedure (entry/pemp_stage1.py:68-113, core/base_trainer.py:183-294) on synthetic episodes: fused HIP train
+    steps, per-epoch evaluation, ``ckpt.pth`` / ``bestckpt.pth`` under ``<g.model_dir>/<tag>/<id>``.  One process per GPU
+    under torchrun (gradients all-reduced over RCCL, evaluation sharded)."""
+    import logging
+    import os
+    from ..core.base_trainer import TrainingLoop
+    from .train_stage1 import Trainer, broadcast_model, synthetic_batches
+    logging.basicConfig(level=logging.INFO, format="%(message)s")
+    logger = logging.getLogger(NAME)
+    if split < 0:
+        raise ValueError("Argument `split` is required! For example: `python -m pemp_amd.entry.pemp_stage1 train with split=0`")
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(seed + rank)
+    d = _config["data"]
+    model = ModelClass(logger if rank == 0 else None)
+    trainer = Trainer(model, lr=_config["tr"]["lr"], device=dev, loss=loss, sigma=sigma)
+    broadcast_model(model)
+    loop = TrainingLoop(_config, trainer, Evaluator(model, device=dev), logger, run_id=exp_id if exp_id >= 0 else None)
+    val = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"])
+
+    def batches(epoch):
+        return synthetic_batches(d["bs"], shot, loop.steps_per_epoch, d["seed"] + 7919 * epoch, rank, d["height"], d["width"])
+
+    hist = loop.start_training_loop(batches, val, 20 if d["dataset"] == "PASCAL" else 80, split)
+    return f"best val mIoU {loop.best_iou * 100:.2f} at epoch {loop.best_epoch}; checkpoints in {loop.model_dir}" if hist else "no epochs"
+
+
 #: response-map palette of the reference's viewer (core/base_trainer.py:348-349, listed there in BGR for cv2): rows 0-2 =
 #: background prototypes, 3-5 = foreground prototypes; RGB here (PIL writes RGB)
 RESPONSE_PALETTE_RGB = np.array([[25, 70, 147], [30, 116, 179], [112, 172, 207],

@@ -223,3 +223,35 @@ def test_stage2_train_steps_with_stage1_prior_and_dropout(hip_lib, dev):
     assert all(np.isfinite(losses)) and min(losses[4:]) < losses[0], losses
     fresh = m2.ModelClass(1, 1, None)
     fresh.load_state_dict({k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()})
+
+
+def test_training_loop_epochs_eval_and_checkpoints(hip_lib, dev, tmp_path):
+    """start_training_loop (reference core/base_trainer.py:183-294): epochs of fused train steps, evaluation every epoch,
+    ckpt.pth / bestckpt.pth written as plain state_dicts that load back into a fresh model; poly LR steps per iteration."""
+    import logging
+    from pemp_amd.core.base_trainer import TrainingLoop
+    from pemp_amd.entry import pemp_stage1 as e
+    from pemp_amd.entry.train_stage1 import Trainer, synthetic_batches
+    cfg = e.ex.apply_updates({"split": 0, "g.model_dir": str(tmp_path), "tr.total_epochs": 2, "tr.lrp": "poly", "tr.lr": 2e-3,
+                              "data.train_n": 6, "data.bs": 2, "data.test_n": 10, "data.height": 97, "data.width": 97,
+                              "te.epochs": 1, "data.test_bs": 2})
+    try:
+        net = e.ModelClass(None)
+        net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+        tr = Trainer(net, lr=cfg["tr"]["lr"], device=dev)
+        loop = TrainingLoop(cfg, tr, e.Evaluator(net, device=dev), logging.getLogger("t"), run_id=7)
+        assert loop.steps_per_epoch == 3
+        val = e.SyntheticEpisodes(10, 5678, 1, 0, 97, 97)          # 10 episodes cover the 5 validation classes of the split
+        hist = loop.start_training_loop(lambda ep: synthetic_batches(2, 1, 3, 100 + ep, 0, 97, 97), val, 20, 0)
+    finally:
+        for ing in e.INGREDIENTS + [e.ex]:
+            ing._updates.clear()
+            ing._cfg = None
+    assert len(hist) == 2 and all(np.isfinite(h["train_loss"]) and 0 <= h["val_mIoU"] <= 1 for h in hist) and hist[0]["best"]
+    assert loop.optimizer.param_groups[0]["lr"] < 2e-3                       # poly decays per iteration
+    d = tmp_path / "pemp_stage1" / "7"
+    assert sorted(p.name for p in d.iterdir()) == ["bestckpt.pth", "ckpt.pth"]
+    fresh = e.ModelClass(None)
+    fresh.load_weights(d / "ckpt.pth", logging.getLogger("t"))
+    for (k, a), (_, b) in zip(fresh.state_dict().items(), net.state_dict().items()):
+        assert torch.equal(a, b.cpu()), k
