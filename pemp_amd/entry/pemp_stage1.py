@@ -127,7 +127,7 @@ class Evaluator:
         dev_in = [torch.cat([ep[0][k].to(self.device, non_blocking=True) for ep in episodes]) for k in range(3)]
         labels = [ep[1].view(-1, *ep[1].shape[-2:]).to(self.device, non_blocking=True) for ep in episodes]
         with torch.no_grad():
-            pred, _ = self.model.lowres_graphed(*dev_in) if self.use_graph else self.model.lowres(*dev_in)
+            pred = self._lowres(dev_in)
             stats = torch.empty((len(episodes), 8), dtype=torch.float64, device=self.device)
             by_size = {}
             for i, lab in enumerate(labels):
@@ -137,6 +137,10 @@ class Evaluator:
                 _, st, _ = ops.eval_tail(pred.index_select(0, sel), torch.cat([labels[i] for i in idx]), ws_cache=self._ws)
                 stats.index_copy_(0, sel, st)
         return stats
+
+    def _lowres(self, dev_in):
+        """Feature-resolution prediction of a batch of episodes (stage 2 overrides: stage-1 prior first)."""
+        return (self.model.lowres_graphed(*dev_in) if self.use_graph else self.model.lowres(*dev_in))[0]
 
     def test_step(self, inputs, qry_msk, **kwargs):
         """Reference contract (entry/pemp_stage1.py:48-53): -> (qry_pred numpy [B,H,W], loss float)."""

@@ -37,8 +37,9 @@ class Evaluator(_Stage1Evaluator):
         super().__init__(model, device=device, use_graph=use_graph)
         self.stage1 = stage1
 
-    def test_step_batch(self, episodes):
-        return torch.cat([self.test_step_device(inputs, qry_msk)[1] for inputs, qry_msk in episodes])
+    def _lowres(self, dev_in):
+        prior = self.prior(dev_in)
+        return (self.model.lowres_graphed(*dev_in, prior) if self.use_graph else self.model.lowres(*dev_in, prior))[0]
 
     def prior(self, dev_in):
         """Stage-1 argmax at the input size as the float plane the stage-2 stem consumes."""

@@ -61,3 +61,20 @@ def test_batched_evaluation_gives_identical_metrics(hip_lib, dev):
         res.append(ev.start_eval_loop(e.SyntheticEpisodes(10, 5678, 1, split=0, height=97, width=97), 20, 0, te_epochs=1, batch=batch))
     (l0, m0, b0), (l1, m1, b1) = res
     assert l0 == l1 and np.array_equal(m0, m1) and np.array_equal(b0, b1)
+
+
+def test_stage2_batched_evaluation_gives_identical_metrics(hip_lib, dev):
+    """The stage-2 evaluator (stage-1 prior -> stage 2) through the same sharded loop: batch 3 == batch 1."""
+    from pemp_amd.entry import pemp_stage2 as e2
+    s1 = e2.PriorNet(None)
+    s1.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    s1 = s1.to(dev).eval()
+    net = e2.ModelClass(1, 1, None)
+    net.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+    net = net.to(dev).eval()
+    res = []
+    for batch in (1, 3):
+        ev = e2.Evaluator(s1, net, device=dev)
+        res.append(ev.start_eval_loop(e2.SyntheticEpisodes(10, 5678, 1, split=0, height=97, width=97), 20, 0, te_epochs=1, batch=batch))
+    (l0, m0, b0), (l1, m1, b1) = res
+    assert l0 == l1 and np.array_equal(m0, m1) and np.array_equal(b0, b1)
