@@ -53,14 +53,12 @@ def conv_out_size(i, k, s, p, d):
 
 class ConvParams:
     """Device-resident, pre-packed parameters of one conv (+ folded per-channel affine)."""
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "kh", "kw", "stride", "pad", "dil", "kpad", "stem", "relu",
-                 "tiles")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "kh", "kw", "stride", "pad", "dil", "kpad", "stem", "relu")
 
     def __init__(self, w, scale, shift, cin, cout, kh, kw, stride, pad, dil, kpad, stem, relu):
         self.w, self.scale, self.shift = w, scale, shift
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.stride, self.pad, self.dil, self.kpad, self.stem, self.relu = stride, pad, dil, kpad, stem, relu
-        self.tiles = None        # (kept for ABI of the slot list; the autotune cache is global, keyed by geometry)
 
 
 #: kernel variants the autotuner may pick: id -> (BM, BN); ids >= 11 stage through LDS-DMA.  All variants
