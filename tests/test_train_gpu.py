@@ -255,3 +255,26 @@ def test_training_loop_epochs_eval_and_checkpoints(hip_lib, dev, tmp_path):
     fresh.load_weights(d / "ckpt.pth", logging.getLogger("t"))
     for (k, a), (_, b) in zip(fresh.state_dict().items(), net.state_dict().items()):
         assert torch.equal(a, b.cpu()), k
+
+
+def test_five_shot_training_steps_stage1_and_stage2(hip_lib, dev):
+    """5-shot episodes (6 images per episode; the MPM mean over shots, comm-module episode means over S + Q = 6):
+    a few fused steps stay finite and reduce the loss on a fixed batch."""
+    from pemp_amd import synth
+    from pemp_amd.networks import pemp_stage1 as m1, pemp_stage2 as m2
+    from pemp_amd.train_engine import Stage1Trainer
+    from pemp_amd.train_stage2 import Stage2Trainer
+    b = synth.make_batch([41, 42], shot=5, height=97, width=97, out_hw=(97, 97))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    sup, msk, qry, gt = t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0])
+    assert sup.shape[1] == 5
+    net1 = m1.ModelClass(None)
+    net1.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    tr1 = Stage1Trainer(net1, device=dev, lr=2e-3, drop_rate=0.0)
+    l1 = [tr1.train_step(sup, msk, qry, gt).item() for _ in range(6)]
+    assert all(np.isfinite(l1)) and min(l1[3:]) < l1[0], l1
+    net2 = m2.ModelClass(5, 1, None)
+    net2.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+    tr2 = Stage2Trainer(net1.eval(), net2, device=dev, lr=2e-3, drop_rate2=0.0)
+    l2 = [tr2.train_step(sup, msk, qry, gt).item() for _ in range(6)]
+    assert all(np.isfinite(l2)) and min(l2[3:]) < l2[0], l2
