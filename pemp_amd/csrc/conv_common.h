@@ -63,10 +63,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
                     if (per_img) add += *(const v4f*)(a.shift + (size_t)(m / a.HoWo) * a.Cout + n);
                     if (a.res) add += *(const v4f*)(a.res + (size_t)m * a.ldr + n);
                     v4f o;
-                    o.x = v.x * sc.x + add.x;
-                    o.y = v.y * sc.y + add.y;
-                    o.z = v.z * sc.z + add.z;
-                    o.w = v.w * sc.w + add.w;
+                    o.x = __builtin_fmaf(v.x, sc.x, add.x);      // explicit: every epilogue variant must round identically
+                    o.y = __builtin_fmaf(v.y, sc.y, add.y);
+                    o.z = __builtin_fmaf(v.z, sc.z, add.z);
+                    o.w = __builtin_fmaf(v.w, sc.w, add.w);
                     if (relu) {
                         o.x = fmaxf(o.x, 0.f);
                         o.y = fmaxf(o.y, 0.f);
