@@ -91,7 +91,8 @@ def conv_roofline(net, pool, reps=3):
         cin_real = 3 if (p.stem and p.cin == 4 and not getattr(p, "real4", False)) else p.cin
         nbytes = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * p.cin + n * ho * wo * co * (2 if kw.get("residual") is not None else 1)
                         + p.w.numel())
-        records.append((e0, e1, 2.0 * n * ho * wo * co * p.kh * p.kw * cin_real, nbytes))
+        records.append((e0, e1, 2.0 * n * ho * wo * co * p.kh * p.kw * cin_real, nbytes,
+                        (n * ho * wo, co, p.kh * p.kw * cin_real, kw.get("residual") is not None)))
         return y
 
     cos_rec = []
@@ -147,13 +148,22 @@ def conv_roofline(net, pool, reps=3):
             rec = json.load(f)
         if rec.get("episodes_per_step") == len(pool[0]["seeds"]):
             traffic = rec.get("hbm_bytes_per_launch")
+    # where the time goes: the six GEMM shapes (rows M, Cout N, K, with shortcut) with the largest share of conv time
+    by = {}
+    for r in records:
+        t = by.setdefault(r[4], [0.0, 0.0])
+        t[0] += r[0].elapsed_time(r[1])
+        t[1] += r[2]
+    top = sorted(by.items(), key=lambda kv: -kv[1][0])[:6]
+    by_layer = [{"M": k[0], "N": k[1], "K": k[2], "shortcut": k[3], "share": round(v[0] / ms, 3),
+                 "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)} for k, v in top]
     return {"bound": "mfma", "kernel": "conv_dma_kernel + conv_igemm_kernel (all conv launches of a step)",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(abytes / n),
             "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
             "gflop_per_step": round(flops / reps / 1e9, 2), "conv_ms_per_step": round(ms / reps, 4),
-            "cosine_kernel": cos}
+            "by_layer": by_layer, "cosine_kernel": cos}
 
 
 def cpu_baseline(sd, shot, n_eps):
