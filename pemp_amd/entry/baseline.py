@@ -40,8 +40,17 @@ def test(_config, split, shot):
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
 
 
-if __name__ == "__main__":
-    print(ex.run_commandline())
+@ex.command
+def train(_config, split, shot, seed, loss, sigma, exp_id):
+    """Baseline training procedure (entry/baseline.py:54-62,65-110): no gradient clipping; VGG-16 or ResNet-50 per net.backbone."""
+    from .pemp_stage1 import run_training
+
+    def make_trainer(logger, dev):
+        return Trainer(ModelClass(logger), lr=_config["tr"]["lr"], device=dev, loss=loss, sigma=sigma)
+
+    return run_training(_config, NAME, make_trainer, lambda tr, dev: Evaluator(tr.model, device=dev), split, shot, seed, exp_id)
+
+
 
 
 class Trainer:
@@ -55,3 +64,7 @@ class Trainer:
                 return super().train_step(*inputs, qry_msk=qry_msk.view(-1, *qry_msk.shape[-2:]))
 
         return _Trainer(model, **kw)
+
+
+if __name__ == "__main__":
+    print(ex.run_commandline())

@@ -237,18 +237,14 @@ def test(_config, split, shot, seed):
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
 
 
-@ex.command
-def train(_config, split, shot, seed, loss, sigma, exp_id):
-    """``python -m pemp_amd.entry.pemp_stage1 train with split=0 tr.total_epochs=3 data.train_n=5000``: the reference's
-    training procedure (entry/pemp_stage1.py:68-113, core/base_trainer.py:183-294) on synthetic episodes: fused HIP train
-    steps, per-epoch evaluation, ``ckpt.pth`` / ``bestckpt.pth`` under ``<g.model_dir>/<tag>/<id>``.  One process per GPU
-    under torchrun (gradients all-reduced over RCCL, evaluation sharded)."""
+def run_training(_config, name, make_trainer, make_evaluator, split, shot, seed, exp_id):
+    """Shared body of the three ``train`` commands: process-group setup, model broadcast, TrainingLoop on synthetic episodes."""
     import logging
     import os
     from ..core.base_trainer import TrainingLoop
-    from .train_stage1 import Trainer, broadcast_model, synthetic_batches
+    from .train_stage1 import broadcast_model, synthetic_batches
     logging.basicConfig(level=logging.INFO, format="%(message)s")
-    logger = logging.getLogger(NAME)
+    logger = logging.getLogger(name)
     if split < 0:
         raise ValueError("Argument `split` is required! For example: `python -m pemp_amd.entry.pemp_stage1 train with split=0`")
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -258,10 +254,9 @@ def train(_config, split, shot, seed, loss, sigma, exp_id):
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(seed + rank)
     d = _config["data"]
-    model = ModelClass(logger if rank == 0 else None)
-    trainer = Trainer(model, lr=_config["tr"]["lr"], device=dev, loss=loss, sigma=sigma)
-    broadcast_model(model)
-    loop = TrainingLoop(_config, trainer, Evaluator(model, device=dev), logger, run_id=exp_id if exp_id >= 0 else None)
+    trainer = make_trainer(logger if rank == 0 else None, dev)
+    broadcast_model(trainer.model)
+    loop = TrainingLoop(_config, trainer, make_evaluator(trainer, dev), logger, run_id=exp_id if exp_id >= 0 else None)
     val = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"])
 
     def batches(epoch):
@@ -269,6 +264,20 @@ def train(_config, split, shot, seed, loss, sigma, exp_id):
 
     hist = loop.start_training_loop(batches, val, 20 if d["dataset"] == "PASCAL" else 80, split)
     return f"best val mIoU {loop.best_iou * 100:.2f} at epoch {loop.best_epoch}; checkpoints in {loop.model_dir}" if hist else "no epochs"
+
+
+@ex.command
+def train(_config, split, shot, seed, loss, sigma, exp_id):
+    """``python -m pemp_amd.entry.pemp_stage1 train with split=0 tr.total_epochs=3 data.train_n=5000``: the reference's
+    training procedure (entry/pemp_stage1.py:68-113, core/base_trainer.py:183-294) on synthetic episodes: fused HIP train
+    steps, per-epoch evaluation, ``ckpt.pth`` / ``bestckpt.pth`` under ``<g.model_dir>/<tag>/<id>``.  One process per GPU
+    under torchrun (gradients all-reduced over RCCL, evaluation sharded)."""
+    from .train_stage1 import Trainer
+
+    def make_trainer(logger, dev):
+        return Trainer(ModelClass(logger), lr=_config["tr"]["lr"], device=dev, loss=loss, sigma=sigma)
+
+    return run_training(_config, NAME, make_trainer, lambda tr, dev: Evaluator(tr.model, device=dev), split, shot, seed, exp_id)
 
 
 #: response-map palette of the reference's viewer (core/base_trainer.py:348-349, listed there in BGR for cv2): rows 0-2 =

@@ -101,5 +101,22 @@ def test(_config, split, shot, seed):
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
 
 
+@ex.command
+def train(_config, split, shot, seed, loss, sigma, exp_id):
+    """Stage-2 training procedure (entry/pemp_stage2.py:67-83,86-140): the stage-1 model is frozen
+    (``maybe_fix_params(True)``, :126-129) and only provides the prior; clipping only for VGG (never here)."""
+    from .pemp_stage1 import run_training
+    holder = {}
+
+    def make_trainer(logger, dev):
+        stage1 = PriorNet(logger).to(dev).eval()
+        stage1.maybe_fix_params(True)
+        holder["s1"] = stage1
+        return Trainer(stage1, ModelClass(shot, _config["query"], logger), lr=_config["tr"]["lr"], device=dev, loss=loss, sigma=sigma)
+
+    return run_training(_config, NAME, make_trainer, lambda tr, dev: Evaluator(holder["s1"], tr.model, device=dev),
+                        split, shot, seed, exp_id)
+
+
 if __name__ == "__main__":
     print(ex.run_commandline())
