@@ -404,14 +404,21 @@ def main():
                        "episodes_per_step": args.batch, "shot": args.shot, "hipgraph": not args.no_graph,
                        "mean_ce_loss": round(mean_loss, 6)},
         }
+        # the auxiliary measurements must never cost the headline line: a failure is reported in place
+        def guarded(key, fn):
+            try:
+                out[key] = fn()
+            except Exception as exc:  # noqa: BLE001
+                out[key] = {"error": f"{type(exc).__name__}: {exc}"}
+
         if not args.no_roofline and stage2 is None:
-            out["roofline"] = conv_roofline(net, pool)
-            if args.model != "stage1":
+            guarded("roofline", lambda: conv_roofline(net, pool))
+            if args.model != "stage1" and "traffic" in out["roofline"]:
                 out["roofline"]["traffic"] = None        # the committed PMC run is the stage-1 workload
         if world == 1 and args.model == "stage1" and not args.no_graph and not args.no_e2e:
-            out["end_to_end"] = end_to_end(net, args, dev)
+            guarded("end_to_end", lambda: end_to_end(net, args, dev))
         if world == 1 and args.cpu_episodes > 0 and args.model != "baseline":
-            out["cpu_baseline"] = cpu_baseline({k: v.cpu() for k, v in sd.items()}, args.shot, args.cpu_episodes)
+            guarded("cpu_baseline", lambda: cpu_baseline({k: v.cpu() for k, v in sd.items()}, args.shot, args.cpu_episodes))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
