@@ -131,6 +131,120 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 128 co x 128 columns per block (Cout and Cin multiples of 128): 2x2 waves of 64 x 64 (four MFMA tiles each), so one
+// reduction step of 32 pixels carries 64 MFMAs per wave between barriers (16 in the 64x64 kernel), every operand
+// float read from LDS feeds two MFMAs, and the L2 -> LDS traffic per flop is halved.  Same pixel-major LDS image,
+// same conflict-free ds_read_b32 pattern; the reduction over pixels runs in the same order within a split.
+__global__ __launch_bounds__(256) void conv_wgrad128_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) v4f smem[];
+    v4f* Gs = smem;                  // [2][32 px][32 quads]
+    v4f* Xs = smem + 2 * 32 * 32;    // [2][32 px][32 quads]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;        // wave's 64 x 64 sub-tile: rows co, columns k
+
+    const int co0 = blockIdx.x * 128;
+    const int ky = blockIdx.y;                      // 128-column tile of the weight row: one tap, 128 input channels
+    const int split = blockIdx.z;
+    const int s_begin = split * a.steps_per_split;
+    const int s_end = min(s_begin + a.steps_per_split, a.steps_total);
+
+    // loader role: thread fetches quad q (of 32) of pixel rows rloc + 8 i, i = 0..3
+    const int q = lane & 31;
+    const int rloc = 2 * wave + (lane >> 5);
+    const float* zero = w_zero16;
+
+    const int cin_tiles = a.Cin / 128;
+    const int tap = ky / cin_tiles;
+    const int ci0 = (ky - tap * cin_tiles) * 128;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int dh = kh * a.dil - a.pad, dw = kw * a.dil - a.pad;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // one DMA wave-instruction moves 2 pixel rows x 512 B; wave w owns rows 2w, 2w+1 (+ 8 i)
+#define PEMP_WG_DMA(step_, buf_)                                                                       \
+    do {                                                                                               \
+        v4f* Gd_ = Gs + (buf_) * 1024 + wave * 64;                                                     \
+        v4f* Xd_ = Xs + (buf_) * 1024 + wave * 64;                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+            const int m = (step_) * 32 + rloc + 8 * i;                                                 \
+            const bool mok = m < a.M;                                                                  \
+            const float* gs = mok ? a.g + (size_t)m * a.ldg + co0 + q * 4 : zero;                      \
+            __builtin_amdgcn_global_load_lds((gptr_t)gs, (lptr_t)(Gd_ + i * 256), 16, 0, 0);          \
+            const int mm = mok ? m : 0;                                                                \
+            const int img = mm / a.HoWo;                                                               \
+            const int rem = mm - img * a.HoWo;                                                         \
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;                                           \
+            const int hi = ho * a.stride + dh, wi = wo * a.stride + dw;                                \
+            const bool ok = mok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;       \
+            const float* xs = ok ? a.x + ((size_t)(img * a.H + hi) * a.W + wi) * a.ldx + ci0 + q * 4 : zero; \
+            __builtin_amdgcn_global_load_lds((gptr_t)xs, (lptr_t)(Xd_ + i * 256), 16, 0, 0);          \
+        }                                                                                              \
+    } while (0)
+
+    if (s_begin < s_end) {
+        PEMP_WG_DMA(s_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    const float* Gf = (const float*)Gs;
+    const float* Xf = (const float*)Xs;
+    const int gcol = wr * 64 + lr, xcol = wc * 64 + lr;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) PEMP_WG_DMA(s + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Gb = Gf + buf * 4096 + lh * 128 + gcol;     // pixel 2t + lh, row stride 128 floats
+        const float* Xb = Xf + buf * 4096 + lh * 128 + xcol;
+        float ga[2][2], xa[2][2];
+        ga[0][0] = Gb[0]; ga[0][1] = Gb[32];
+        xa[0][0] = Xb[0]; xa[0][1] = Xb[32];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t < 15) {
+                ga[(t + 1) & 1][0] = Gb[(t + 1) * 256];
+                ga[(t + 1) & 1][1] = Gb[(t + 1) * 256 + 32];
+                xa[(t + 1) & 1][0] = Xb[(t + 1) * 256];
+                xa[(t + 1) & 1][1] = Xb[(t + 1) * 256 + 32];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[t & 1][i], xa[t & 1][j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef PEMP_WG_DMA
+
+    float* out = a.out + (size_t)split * a.Cout * a.Kpad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = ky * 128 + wc * 64 + j * 32 + lr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                out[(size_t)co * a.Kpad + col] = acc[i][j][e];
+            }
+        }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int nsplit,
                                     int accumulate) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n / 4; i += (long long)gridDim.x * blockDim.x) {
@@ -160,10 +274,20 @@ static int pick_split(int tiles, int steps) {
     return s;
 }
 
+// 128 x 128 tiles where they measured faster on MI355X at the training shapes (8 images, 51 x 51): the 3x3 layers with
+// >= 256 output channels (84 -> 93 TFLOP/s) and the large 1x1 layers; the small-output 1x1 layers keep the 64 x 64
+// kernel, whose 4x more blocks per weight matrix fill the chip better.
+static bool wgrad_big_tiles(const pemp_conv_desc* d) {
+    if ((d->flags & PEMP_CONV_STEM4) || d->Cin % 128 || d->Cout % 128 || d->Cout < 256) return false;
+    return d->KH * d->KW > 1 || (long long)d->Cin * d->Cout >= 512ll * 1024;
+}
+
 extern "C" size_t pemp_conv2d_wgrad_workspace_bytes(const pemp_conv_desc* d) {
     if (!d) return 0;
     const int M = d->N * d->Ho * d->Wo;
-    const int tiles = cdiv(d->Cout, 64) * (d->Kpad / 64 > 0 ? cdiv(d->Kpad, 64) : 1);
+    const bool big = wgrad_big_tiles(d);
+    const int tw = big ? 128 : 64;
+    const int tiles = cdiv(d->Cout, tw) * (d->Kpad / tw > 0 ? cdiv(d->Kpad, tw) : 1);
     const int split = pick_split(tiles, cdiv(M, 32));
     return (size_t)split * d->Cout * d->Kpad * sizeof(float) + 256;
 }
@@ -195,8 +319,10 @@ extern "C" int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* 
     a.cin_tiles = stem ? 1 : d->Cin / 64;
     a.steps_total = cdiv(a.M, 32);
     a.stem = stem;
-    const int tiles_k = d->Kpad / 64;
-    const int tiles = (d->Cout / 64) * tiles_k;
+    const bool big = wgrad_big_tiles(d);
+    const int tw = big ? 128 : 64;
+    const int tiles_k = d->Kpad / tw;
+    const int tiles = (d->Cout / tw) * tiles_k;
     a.nsplit = pick_split(tiles, a.steps_total);
     a.steps_per_split = cdiv(a.steps_total, a.nsplit);
     a.nsplit = cdiv(a.steps_total, a.steps_per_split);
@@ -207,10 +333,14 @@ extern "C" int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* 
     }
     a.out = direct ? dw : (float*)ws;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = 2 * 2 * 32 * 16 * sizeof(v4f);
-    dim3 grid(d->Cout / 64, tiles_k, a.nsplit);
-    if (stem) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), lds, st, a);
+    dim3 grid(d->Cout / tw, tiles_k, a.nsplit);
+    if (big) {
+        hipLaunchKernelGGL(conv_wgrad128_kernel, grid, dim3(256), 2 * 2 * 32 * 32 * sizeof(v4f), st, a);
+    } else {
+        const size_t lds = 2 * 2 * 32 * 16 * sizeof(v4f);
+        if (stem) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), lds, st, a);
+    }
     int e = launch_status("conv_wgrad");
     if (e || direct) return e;
     const long long n = (long long)d->Cout * d->Kpad;
