@@ -437,3 +437,22 @@ def test_pretrained_import_and_checkpoint_roundtrip(tmp_path):
     # stage-1 freezing for stage-2 training (entry/pemp_stage2.py:126-129)
     s1.maybe_fix_params(True)
     assert not any(p.requires_grad for p in s1.parameters())
+
+
+def test_committed_bench_line_honours_the_contract():
+    """profiles/r01_bench_b25.json is the line `python bench.py` printed on the MI355X: every key of the bench contract."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_b25.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "episodes/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert isinstance(r["traffic"], int) and r["traffic"] >= r["algorithmic_bytes_per_launch"] * 0.9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "episodes/s" and c["sample"]
+    assert abs(d["value"] - d["steps"] * d["config"]["episodes_per_step"] * d["n_gpus"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1.0
+    t = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_traffic.json")))
+    assert t["episodes_per_step"] == d["config"]["episodes_per_step"] and t["hbm_bytes_per_launch"] == r["traffic"]
