@@ -46,6 +46,7 @@ def parse():
                     help="eval (headline metric, BASELINE.json configs[1]) or train (configs[2])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-episodes", type=int, default=12, help="bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--train-graph", action="store_true", help="--mode train: replay forward/backward from a hipGraph")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the staging-inclusive end_to_end figure")
     return ap.parse_args()
@@ -255,14 +256,17 @@ def main_train(args, world, rank, dev):
     from tests import util
     net = m.ModelClass(None)
     net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    # eager by default: the weight-gradient kernels run on a side stream concurrently with the input-gradient chain
+    # (21.4 ms/step); a hipGraph replay of the same two-stream capture does not overlap its branches (23.6 ms/step)
+    use_graph = args.train_graph
     if args.model == "stage2":          # frozen stage-1 prior + stage-2 step (entry/pemp_stage2.py:72-83)
         from pemp_amd.networks import pemp_stage2 as m2
         from pemp_amd.train_stage2 import Stage2Trainer
         net2 = m2.ModelClass(args.shot, 1, None)
         net2.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
-        tr = Stage2Trainer(net.to(dev).eval(), net2, device=dev, use_graph=not args.no_graph)
+        tr = Stage2Trainer(net.to(dev).eval(), net2, device=dev, use_graph=use_graph)
     else:
-        tr = Stage1Trainer(net, device=dev, use_graph=not args.no_graph)
+        tr = Stage1Trainer(net, device=dev, use_graph=use_graph)
     B = args.batch
     pool = []
     for g in range(3):

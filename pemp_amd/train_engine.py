@@ -52,6 +52,14 @@ class FlatParams:
             p.data = self._view(self.data, p, o)
         self.grad_views = [self._view(self.grad, p, o) for p, o in zip(self.params, offs)]
         self.attach_grads()
+        # weight-gradient kernels run on a side stream (see _Conv.wgrad); own workspace cache, joined by the engine
+        self.side_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.side_ws, self.side_keep = {}, []
+
+    def join_side_stream(self):
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+        self.side_keep.clear()
 
     @staticmethod
     def _view(buf, p, o):
@@ -145,7 +153,21 @@ class _Conv:
                           self.dil, wd.shape[1], False, False)
 
     def wgrad(self, x, g, ws):
-        """Writes conv.weight.grad (and nothing else)."""
+        """Writes conv.weight.grad (and nothing else).  Nothing in the backward pass depends on a weight gradient,
+        so it is enqueued on the engine's side stream (after the event that says ``g`` is ready) and runs concurrently
+        with the input-gradient / BatchNorm chain, filling the CUs those small-M kernels leave idle; the engine joins
+        the side stream at the end of ``backward``."""
+        flat = self.flat
+        if flat.side_stream is None or x.shape[0] * x.shape[1] * x.shape[2] < 64:
+            return self._wgrad_now(x, g, ws)
+        ready = torch.cuda.Event()
+        ready.record()
+        flat.side_keep.append((x, g))                      # operands stay referenced until the join
+        with torch.cuda.stream(flat.side_stream):
+            flat.side_stream.wait_event(ready)
+            self._wgrad_now(x, g, flat.side_ws)
+
+    def _wgrad_now(self, x, g, ws):
         w = self.conv.weight
         if self.stem:
             dw = torch.empty((self.cout, 256), dtype=torch.float32, device=x.device)
@@ -286,7 +308,10 @@ class Stage1TrainEngine:
         return feat
 
     def backward(self, dfeat):
+        if self.flat.side_stream is not None:      # the side stream must not start before this step's gradients were zeroed
+            self.flat.side_stream.wait_stream(torch.cuda.current_stream())
         self._trunk_backward(self._tail_backward(dfeat))
+        self.flat.join_side_stream()               # every weight gradient has landed before the optimizer / all-reduce
         self.tape = None
 
     def _pack(self, images_list, priors=None):

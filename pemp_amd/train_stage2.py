@@ -50,7 +50,7 @@ class _ConvCM(_Conv):
         wd = self.flat.dgrad_krsc(self.conv.weight)[:self.creal]     # rows of the transposed weight = real channels
         return ConvParams(wd, None, None, self.cout, self.creal, 1, 1, 1, 0, 1, self.cout, False, False)
 
-    def wgrad(self, x, g, ws):
+    def _wgrad_now(self, x, g, ws):
         dw = torch.empty((self.cout, self.creal), dtype=torch.float32, device=x.device)
         prm = ConvParams(None, None, None, self.creal, self.cout, 1, 1, self.stride, 0, 1, self.creal, False, False)
         T.conv_wgrad(x, g, prm, dw, ws_cache=ws)
