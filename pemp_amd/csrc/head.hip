@@ -197,121 +197,339 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
     }
 }
 
-// protos[b][j][c] = mean_s ( sum_chunks part / (denominator + eps) )
-__global__ __launch_bounds__(64) void pool_final_kernel(const float* __restrict__ part,
-                                                        const float* __restrict__ asum,
-                                                        const float* __restrict__ den_override,
-                                                        float* __restrict__ protos, int S, int c, int J, int nchunks,
-                                                        float eps) {
+// protos[b][j][c] = mean_s ( sum_chunks part / (denominator + eps) ); block = 64 channels x 4 chunk lanes
+__global__ __launch_bounds__(256) void pool_final_kernel(const float* __restrict__ part,
+                                                         const float* __restrict__ asum,
+                                                         const float* __restrict__ den_override,
+                                                         float* __restrict__ protos, int S, int c, int J, int nchunks,
+                                                         float eps) {
+    __shared__ float red[4][64];
     const int b = blockIdx.y, j = blockIdx.x;
-    for (int ch = blockIdx.z * 64 + threadIdx.x; ch < c; ch += gridDim.z * 64) {
-        float tot = 0.f;
-        for (int s = 0; s < S; ++s) {
-            const int bs = b * S + s;
-            float num = 0.f, den = 0.f;
-            for (int k = 0; k < nchunks; ++k) {
-                num += part[(((size_t)bs * nchunks + k) * J + j) * c + ch];
-                den += asum[((size_t)bs * nchunks + k) * J + j];
-            }
-            if (den_override) den = den_override[bs * J + j];
-            tot += num / (den + eps);
-        }
-        protos[((size_t)b * J + j) * c + ch] = tot / (float)S;
+    const int ch = blockIdx.z * 64 + (threadIdx.x & 63), chl = min(ch, c - 1);
+    float tot = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const int bs = b * S + s;
+        const float num = chunk_sum(part + ((size_t)bs * nchunks * J + j) * c + chl, (size_t)J * c, nchunks, red);
+        float den = chunk_sum(asum + (size_t)bs * nchunks * J + j, (size_t)J, nchunks, red);
+        if (den_override) den = den_override[bs * J + j];
+        tot += num / (den + eps);
     }
+    if (threadIdx.x < 64 && ch < c) protos[((size_t)b * J + j) * c + ch] = tot / (float)S;
+}
+
+// plain masks at feature resolution as pooling weights (MODE 1 of assign_kernel), one thread per pixel
+__global__ void mask_assign_kernel(const float* __restrict__ mask, float* __restrict__ A, int n, int h, int w, int H,
+                                   int W) {
+    const int bs = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int y = i / w, x = i - y * w;
+    const int sy = nearest_src(y, H, h), sx = nearest_src(x, W, w);
+    const float* mk = mask + (size_t)bs * 2 * H * W;
+    A[((size_t)bs * 2 + 0) * n + i] = mk[(size_t)sy * W + sx];
+    A[((size_t)bs * 2 + 1) * n + i] = mk[(size_t)H * W + (size_t)sy * W + sx];
 }
 
 // -----------------------------------------------------------------------------------------------
-// cosine map as an MFMA outer product with fused L2 normalisation (networks/pemp_stage1.py:214-222,
-// 256-260).  One wave owns 32 query pixels: D[32 px][32 cols] += X[32 px][k] * Pn[k][32 cols] on
-// v_mfma_f32_32x32x2_f32, columns 0..2p-1 = the L2-normalised prototypes (rows of an LDS table; the
-// remaining columns read an all-zero row).  Lane (r = l&31, h = l>>5) streams its pixel's row straight
-// from HBM: float4 #h of every 8-float chunk feeds four MFMAs (k = {8t+e, 8t+4+e}), the prototype
-// side reads the same positions from LDS; |x|^2 accumulates on the VALU from the very same registers.
-// The epilogue divides by max(|x|, 1e-8), scales, and takes the group maxima / response index.
-typedef __attribute__((ext_vector_type(16))) float hf32x16;
+// Pixel-row x small-matrix products on the matrix cores.  Both per-pixel passes of the prototype head
+// have the same shape: every pixel's c-vector meets a fixed c x 2p matrix -- the L2-normalised
+// prototypes for the cosine map (networks/pemp_stage1.py:214-222, 256-260), the MPM centres for the
+// soft assignment (pemp_stage1.py:205-207) -- and the feature map is streamed from HBM exactly once.
+// One wave owns 16 pixels: D[16 px][16 cols] += X[16 px][4 k] * T[4 k][16 cols] on
+// v_mfma_f32_16x16x4_f32, columns 0..2p-1 real (rows of an LDS table, padded so the 16-B reads of the
+// 2p+1 rows fall on different banks), the others read an all-zero row.  Lane (r = l&15, q = l>>4)
+// reads float4 #q of every 16-float chunk of pixel r's row -- a wave-wide load is 16 rows x 64
+// contiguous bytes -- and feeds it to four MFMAs (k = {16t + 4q + e}); |x|^2 comes from the same
+// registers.  The kernel is latency-bound unless many loads are in flight: rows are fetched in groups
+// of 8 chunks (8 KB per wave), two groups deep, and the first group is issued before the table is built.
 typedef __attribute__((ext_vector_type(4))) float hv4f;
+constexpr int SQ = 64;                 // channels per stage pass
+constexpr int SLD = SQ + 4;            // stage row stride in floats: 16-B reads of 16 rows hit 64 different banks
+constexpr int NB = 4;                  // passes in flight (4 KB per wave each)
+constexpr int TV = MAXJ * 64 * MAXCL / 256;   // table elements per thread
 
+// 16 pixel rows x c channels through a wave-private LDS stage, SQ channels at a time.  HBM side: lane l reads
+// float4 #(l & 15) of row 4u + (l >> 4), u = 0..3 -- a wave-wide load is 4 rows x 256 contiguous bytes, NB
+// passes (16 KB per wave) in flight.  MFMA side: lane (r = l&15, q = l>>4) reads float4 #q of every 16-float
+// chunk of row r from the stage and the matching table entries, and issues four MFMAs (k = {16t + 4q + e}).
+// NQ = c / SQ is a template parameter: with every load and every pass known at compile time the s_waitcnt
+// vmcnt bookkeeping is exact (a runtime trip count makes the compiler wait for ALL outstanding loads per pass).
+template <int NQ>
+struct RowTile {
+    const float* base;                 // image base + 4 * (l & 15)
+    int off[4];                        // element offset of row 4u + (l >> 4) (clamped to the last pixel)
+    hv4f buf[NB][4];
+    __device__ __forceinline__ void init(const float* img, int ldf, int i0, int n, int lane) {
+        base = img + 4 * (lane & 15);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) off[u] = min(i0 + 4 * u + (lane >> 4), n - 1) * ldf;
+#pragma unroll
+        for (int s = 0; s < NB; ++s)
+            if (s < NQ) load(s, s);
+    }
+    __device__ __forceinline__ void load(int s, int qq) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) buf[s][u] = *(const hv4f*)(base + off[u] + qq * SQ);
+    }
+    template <bool NORM>
+    __device__ __forceinline__ void pass(int s, int qq, float* stage, const float* bp, int lane, hv4f& acc, float& ss) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(hv4f*)(stage + (4 * u + (lane >> 4)) * SLD + 4 * (lane & 15)) = buf[s][u];
+        if (qq + NB < NQ) load(s, qq + NB);
+        __builtin_amdgcn_wave_barrier();
+        const float* xr = stage + (lane & 15) * SLD + 4 * (lane >> 4);
+#pragma unroll
+        for (int t = 0; t < SQ / 16; ++t) {
+            const hv4f xv = *(const hv4f*)(xr + 16 * t);
+            const hv4f pv = *(const hv4f*)(bp + qq * SQ + 16 * t);
+            if (NORM) ss += (xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, pv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, pv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, pv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, pv.w, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    template <bool NORM>
+    __device__ __forceinline__ void run(float* stage, const float* bp, int lane, hv4f& acc, float& ss) {  // first NB passes loaded
+#pragma unroll
+        for (int qq = 0; qq < NQ; qq += NB) {
+#pragma unroll
+            for (int s = 0; s < NB; ++s)
+                if (qq + s < NQ) pass<NORM>(s, qq + s, stage, bp, lane, acc, ss);
+        }
+    }
+};
+// D[i][j] of the 16x16 tile lives in lane 16*(i>>2) + j, register i&3: hand row (l & 15) to lane l.
+__device__ __forceinline__ void rows_to_lanes(const hv4f& acc, int lane, float (&v)[MAXJ]) {
+    const int row = lane & 15, src = 16 * (row >> 2), e = row & 3;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const float t0 = __shfl(acc[0], src + j, 64), t1 = __shfl(acc[1], src + j, 64);
+        const float t2 = __shfl(acc[2], src + j, 64), t3 = __shfl(acc[3], src + j, 64);
+        v[j] = e == 0 ? t0 : e == 1 ? t1 : e == 2 ? t2 : t3;
+    }
+}
+static inline bool mfma_rows_ok(int c) { return c == 512 || c == 256 || c == 128 || c == 64; }   // instantiated NQ
+static inline size_t proj_lds_bytes(int J, int c) { return ((size_t)(J + 1) * (c + 8) + 4 * 16 * SLD) * sizeof(float); }
+// squared norms of the table rows, every wave for itself (lane l of the result holds row l & 7)
+__device__ __forceinline__ float table_sqnorm(const float* tab, int ldt, int J, int c, int lane) {
+    float s[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        s[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXCL / 4; ++k) {                        // branch-free: rows >= J are the zero row
+            const int ch = 4 * lane + 256 * k;
+            const hv4f v = *(const hv4f*)(tab + min(j, J) * ldt + (ch < c ? ch : 0));
+            s[j] += ch < c ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+        }
+    }
+    return wave_sum8(s);
+}
+
+// cosine map x dist_scalar, group maxima, response index: the MFMA outer product with fused L2 normalisation.
+template <int NQ>
 __global__ __launch_bounds__(256) void cosine_mfma_kernel(const float* __restrict__ qry, int ldf,
                                                           const float* __restrict__ protos, float* __restrict__ pred,
                                                           uint8_t* __restrict__ resp, int n, int c, int p,
                                                           float scalar) {
-    extern __shared__ __attribute__((aligned(16))) float pnl[];      // [(2p + 1)][c], last row = zeros
-    __shared__ float nrm[MAXJ];
+    extern __shared__ __attribute__((aligned(16))) float pnl[];      // [(2p + 1)][c + 8] prototypes, last row zeros | stages
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int J = 2 * p;
+    const int J = 2 * p, ldt = c + 8;
+    const int i0 = (blockIdx.x * 4 + wave) * 16;
+    const int r = lane & 15, q = lane >> 4;
+    float* stage = pnl + (J + 1) * ldt + wave * 16 * SLD;
+    // the table's loads go first: waiting for them must not wait for the 16 KB of row data behind them
     const float* pb = protos + (size_t)b * J * c;
-    for (int j = wave; j < J; j += 4) {
-        float s = 0.f;
-        for (int ch = lane; ch < c; ch += 64) {
-            float v = pb[(size_t)j * c + ch];
-            s += v * v;
-        }
-        s = wave_sum(s);
-        if (lane == 0) nrm[j] = fmaxf(sqrtf(s), 1e-8f);
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < (J + 1) * c; t += 256) {
-        int j = t / c;
-        pnl[t] = j < J ? pb[t] / nrm[j] : 0.f;
-    }
-    __syncthreads();
-    const int tile = blockIdx.x * 4 + wave;
-    const int i0 = tile * 32;
-    if (i0 >= n) return;
-    const int r = lane & 31, h = lane >> 5;
-    const int pix = min(i0 + r, n - 1);
-    const float* xp = qry + ((size_t)b * n + pix) * ldf + 4 * h;
-    const float* bp = pnl + (size_t)min(r, J) * c + 4 * h;           // column r (zero row beyond 2p)
-    hf32x16 acc;
+    float tv[TV];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k = 0; k < TV; ++k) tv[k] = pb[min((int)threadIdx.x + 256 * k, J * c - 1)];
+    RowTile<NQ> rt;
+    rt.init(qry + (size_t)b * n * ldf, ldf, i0, n, lane);
+#pragma unroll
+    for (int k = 0; k < TV; ++k) {
+        const int t = threadIdx.x + 256 * k;
+        if (t < J * c) pnl[(t / c) * ldt + t % c] = tv[k];
+    }
+    for (int ch = threadIdx.x; ch < c; ch += 256) pnl[J * ldt + ch] = 0.f;
+    __syncthreads();
+    // cos = x.p / (max(|x|, eps) max(|p|, eps)): the prototype norms are applied in the epilogue
+    const float pn2 = table_sqnorm(pnl, ldt, J, c, lane);
+    hv4f acc = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
-    const int nchunk = c / 8;
-    hv4f xv = *(const hv4f*)xp;
-    for (int t = 0; t < nchunk; ++t) {
-        const hv4f xn = t + 1 < nchunk ? *(const hv4f*)(xp + (t + 1) * 8) : xv;   // prefetch next chunk
-        const hv4f pv = *(const hv4f*)(bp + t * 8);
-        ss += (xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.x, pv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.y, pv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.z, pv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.w, pv.w, acc, 0, 0, 0);
-        xv = xn;
+    rt.template run<true>(stage, pnl + (size_t)min(r, J) * ldt + 4 * q, lane, acc, ss);
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);                                    // lane l: |x|^2 of pixel (l & 15)
+    const float f = scalar / fmaxf(sqrtf(ss), 1e-8f);
+    float v[MAXJ];
+    rows_to_lanes(acc, lane, v);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) v[j] = v[j] / fmaxf(sqrtf(__shfl(pn2, j, 64)), 1e-8f) * f;
+    const int i = i0 + r;
+    if (q == 0 && i < n) {
+        float best[2];
+        int bi[2];
+        for (int g = 0; g < 2; ++g) {          // g = 0: fg rows [0,p), g = 1: bg rows [p,2p)
+            best[g] = v[g * p];
+            bi[g] = 0;
+            for (int j = 1; j < p; ++j)
+                if (v[g * p + j] > best[g]) {
+                    best[g] = v[g * p + j];
+                    bi[g] = j;
+                }
+        }
+        pred[((size_t)b * 2 + 0) * n + i] = best[1];
+        pred[((size_t)b * 2 + 1) * n + i] = best[0];
+        if (resp) resp[(size_t)b * n + i] = (uint8_t)(best[0] > best[1] ? bi[0] + 3 : bi[1]);
     }
-    ss += __shfl_xor(ss, 32, 64);                                    // both k-halves of the pixel's row
-    const float inv = scalar / fmaxf(sqrtf(ss), 1e-8f);               // lane l holds pixel (l & 31)'s factor
-    // D[i][j]: column j = lane & 31, row i = (e&3) + 8*(e>>2) + 4*h.  Columns 0..2p-1 of a row live in
-    // lanes 32h + 0..2p-1: gather them into lane 32h (column 0).
+}
+
+// MPM soft assignment on the same row stream (MODE 0 of assign_kernel): softmax_j(-|x - c_j|^2) within
+// the fg and the bg group equals softmax_j(2 x.c_j - |c_j|^2) -- |x|^2 is common to a group and drops
+// out -- so the MFMA accumulates x.c_j and the epilogue finishes 16 pixels on 16 lanes.
+template <int NQ>
+__global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restrict__ feat, int ldf,
+                                                          const float* __restrict__ mask,
+                                                          const float* __restrict__ ctr, float* __restrict__ A,
+                                                          int n, int h, int w, int H, int W, int c, int p) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];      // [(2p + 1)][c + 8]: centres, last row zeros | stages
+    const int bs = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int J = 2 * p, ldt = c + 8;
+    const int i0 = (blockIdx.x * 4 + wave) * 16;
+    const int r = lane & 15, q = lane >> 4;
+    float* stage = tab + (J + 1) * ldt + wave * 16 * SLD;
+    float tv[TV];                                                    // table loads first (see cosine_mfma_kernel)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float f = __shfl(inv, row, 64);
-        float v[MAXJ];
+    for (int k = 0; k < TV; ++k) tv[k] = ctr[min((int)threadIdx.x + 256 * k, J * c - 1)];
+    RowTile<NQ> rt;
+    rt.init(feat + (size_t)bs * n * ldf, ldf, i0, n, lane);
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) v[j] = __shfl(acc[e], 32 * h + j, 64) * f;
-        if (r == 0 && i0 + row < n) {
-            float best[2];
-            int bi[2];
-            for (int g = 0; g < 2; ++g) {      // g = 0: fg rows [0,p), g = 1: bg rows [p,2p)
-                best[g] = v[g * p];
-                bi[g] = 0;
-                for (int j = 1; j < p; ++j)
-                    if (v[g * p + j] > best[g]) {
-                        best[g] = v[g * p + j];
-                        bi[g] = j;
-                    }
+    for (int k = 0; k < TV; ++k) {                                   // ctr is [c][2p]
+        const int t = threadIdx.x + 256 * k;
+        if (t < J * c) tab[(t % J) * ldt + t / J] = tv[k];
+    }
+    for (int ch = threadIdx.x; ch < c; ch += 256) tab[J * ldt + ch] = 0.f;
+    __syncthreads();
+    const float cn2 = table_sqnorm(tab, ldt, J, c, lane);
+    float cn[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) cn[j] = __shfl(cn2, j, 64);
+    hv4f acc = {0.f, 0.f, 0.f, 0.f};
+    float ss = 0.f;
+    rt.template run<false>(stage, tab + (size_t)min(r, J) * ldt + 4 * q, lane, acc, ss);
+    float v[MAXJ];
+    rows_to_lanes(acc, lane, v);
+    const int i = i0 + r;
+    if (q == 0 && i < n) {
+        const int y = i / w, x = i - y * w;
+        const int sy = nearest_src(y, H, h), sx = nearest_src(x, W, w);
+        const float* mk = mask + (size_t)bs * 2 * H * W;
+        const float mg[2] = {mk[(size_t)sy * W + sx], mk[(size_t)H * W + (size_t)sy * W + sx]};
+        float* out = A + ((size_t)bs * J) * n + i;
+        for (int g = 0; g < 2; ++g) {
+            float l[MAXJ / 2], mx = -INFINITY;
+            for (int j = 0; j < p; ++j) {
+                l[j] = 2.f * v[g * p + j] - cn[g * p + j];
+                mx = fmaxf(mx, l[j]);
             }
-            const int i = i0 + row;
-            pred[((size_t)b * 2 + 0) * n + i] = best[1];
-            pred[((size_t)b * 2 + 1) * n + i] = best[0];
-            if (resp) resp[(size_t)b * n + i] = (uint8_t)(best[0] > best[1] ? bi[0] + 3 : bi[1]);
+            float s = 0.f;
+            for (int j = 0; j < p; ++j) {
+                l[j] = expf(l[j] - mx);
+                s += l[j];
+            }
+            for (int j = 0; j < p; ++j) out[(size_t)(g * p + j) * n] = (l[j] / s) * mg[g];
         }
     }
 }
 
+// Masked pooling on the matrix cores: part[j][ch] = sum_i A[j][i] x[i][ch] over one chunk of PCHUNK pixels
+// as D[16 rows j][16 ch] += A[j][4 px] * X[4 px][16 ch] (v_mfma_f32_16x16x4_f32, rows >= 2p read a zero row
+// of the LDS weight table).  Lane (m = l&15, k = l>>4) reads float4 #m of pixel k's 64-channel slab -- a
+// wave-wide load is 4 pixels x 256 contiguous bytes -- and feeds four MFMAs with four accumulators (channels
+// 4m + e); wave v owns slabs v and v + 4, so a block covers c <= 512 channels and every row is read once.
+// Four pixel-quads (8 KB per wave) are fetched per group, two groups in flight.
+__global__ __launch_bounds__(256) void pool_mfma_kernel(const float* __restrict__ feat, int ldf,
+                                                        const float* __restrict__ A, float* __restrict__ part,
+                                                        float* __restrict__ asum, int n, int c, int J, int nchunks) {
+    __shared__ float As[MAXJ + 1][PCHUNK];
+    constexpr int QG = 4;                                            // pixel quads per prefetch group
+    constexpr int NG = PCHUNK / (4 * QG);
+    const int bs = blockIdx.y, ck = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, k = lane >> 4;
+    const int i0 = ck * PCHUNK;
+    const int np = min(PCHUNK, n - i0);
+    const int nslab = c / 64;
+    const bool s0 = wave < nslab, s1 = wave + 4 < nslab;
+    const float* xb = feat + (size_t)bs * n * ldf + 64 * wave + 4 * m;
+    hv4f buf[2][QG][2];
+    auto load = [&](int s, int g) {
+#pragma unroll
+        for (int u = 0; u < QG; ++u) {
+            const float* xr = xb + (size_t)min(i0 + 4 * (g * QG + u) + k, n - 1) * ldf;
+            if (s0) buf[s][u][0] = *(const hv4f*)xr;
+            if (s1) buf[s][u][1] = *(const hv4f*)(xr + 256);
+        }
+    };
+    load(0, 0);
+    for (int t = threadIdx.x; t < (MAXJ + 1) * PCHUNK; t += 256) {
+        const int j = t / PCHUNK, i = t - j * PCHUNK;
+        As[j][i] = (j < J && i < np) ? A[((size_t)bs * J + j) * n + i0 + i] : 0.f;
+    }
+    __syncthreads();
+    hv4f acc[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[s][e] = (hv4f){0.f, 0.f, 0.f, 0.f};
+    const float* ap = &As[min(m, J)][k];
+    auto mac = [&](int s, int g) {
+#pragma unroll
+        for (int u = 0; u < QG; ++u) {
+            const float a = ap[4 * (g * QG + u)];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+                if (sl == 0 ? s0 : s1) {
+                    const hv4f xv = buf[s][u][sl];
+                    acc[sl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv.x, acc[sl][0], 0, 0, 0);
+                    acc[sl][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv.y, acc[sl][1], 0, 0, 0);
+                    acc[sl][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv.z, acc[sl][2], 0, 0, 0);
+                    acc[sl][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv.w, acc[sl][3], 0, 0, 0);
+                }
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+        if (g + 1 < NG) load(1, g + 1);
+        mac(0, g);
+        if (g + 2 < NG) load(0, g + 2);
+        if (g + 1 < NG) mac(1, g + 1);
+    }
+    // D[j][m]: lane (m, k) holds rows j = 4k + e' of channel 4m + e in acc[.][e][e']
+    float* pb = part + ((size_t)bs * nchunks + ck) * J * c;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+        if (sl == 0 ? s0 : s1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * k + e;
+                if (j < J) {
+                    const hv4f o = {acc[sl][0][e], acc[sl][1][e], acc[sl][2][e], acc[sl][3][e]};
+                    *(hv4f*)(pb + (size_t)j * c + 64 * (wave + 4 * sl) + 4 * m) = o;
+                }
+            }
+    if (threadIdx.x < J) {
+        float s = 0.f;
+        for (int i = 0; i < np; ++i) s += As[threadIdx.x][i];
+        asum[((size_t)bs * nchunks + ck) * J + threadIdx.x] = s;
+    }
+}
+
 // -----------------------------------------------------------------------------------------------
-// cosine map + group max, VALU variant (c not a multiple of 8, or PEMP_COSINE_VALU set): one wave per query pixel.
+// cosine map + group max, VALU variant (c not a multiple of 8, or PEMP_HEAD_VALU set): one wave per query pixel.
 // torch>=2 F.cosine_similarity: each vector is divided by max(||.||, 1e-8), then dotted.
 __global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ qry, int ldf,
                                                      const float* __restrict__ protos, float* __restrict__ pred,
@@ -514,22 +732,38 @@ static int pooled_protos(int mode, const float* feat, int ldf, const float* mask
     PEMP_REQUIRE(((uintptr_t)feat & 15) == 0, "protos: feat must be 16-byte aligned");
     const int nck = nchunks_of(n);
     const PoolWs L = pool_ws_layout(ws, BS, n, c, J);
+    static const bool force_valu = getenv("PEMP_HEAD_VALU") != nullptr;       // A/B switch for measurements
     float *A = L.A, *part = L.part, *asum = L.asum, *msum = L.msum;
     // few, long-lived blocks: every block first loads its lanes' slice of ctr (48 values per lane)
     const int ablk = min(cdiv(n, 4), max(1, 512 / BS));
     if (mode == 0) {
         PEMP_REQUIRE(ctr, "protos: ctr is null");
-        hipLaunchKernelGGL(assign_kernel<0>, dim3(ablk, BS), dim3(256), 0, st, feat, ldf, mask, ctr, A, n, h, w, H, W, c, p);
+        if (mfma_rows_ok(c) && !force_valu) {
+            const dim3 grid(cdiv(cdiv(n, 16), 4), BS);
+#define PEMP_ASG(NQ)                                                                                                  \
+    hipLaunchKernelGGL(assign_mfma_kernel<NQ>, grid, dim3(256), proj_lds_bytes(J, c), st, feat, ldf, mask, ctr, A, n, h, w, H, \
+                       W, c, p)
+            if (c == 512) PEMP_ASG(8);
+            else if (c == 256) PEMP_ASG(4);
+            else if (c == 128) PEMP_ASG(2);
+            else PEMP_ASG(1);
+#undef PEMP_ASG
+        }
+        else
+            hipLaunchKernelGGL(assign_kernel<0>, dim3(ablk, BS), dim3(256), 0, st, feat, ldf, mask, ctr, A, n, h, w, H, W, c, p);
     } else if (mode == 1) {
-        hipLaunchKernelGGL(assign_kernel<1>, dim3(ablk, BS), dim3(256), 0, st, feat, ldf, mask, ctr, A, n, h, w, H, W, c, 1);
+        hipLaunchKernelGGL(mask_assign_kernel, dim3(cdiv(n, 256), BS), dim3(256), 0, st, mask, A, n, h, w, H, W);
     } else {
         hipLaunchKernelGGL(adjoint_mask_kernel, dim3(cdiv(2 * n, 256), BS), dim3(256), 0, st, mask, A, n, h, w, H, W);
         hipLaunchKernelGGL(mask_sum_kernel, dim3(BS * 2), dim3(256), 0, st, mask, msum, H * W);
     }
     int e = launch_status("protos/assign");
     if (e) return e;
-    hipLaunchKernelGGL(pool_partial_kernel, dim3(nck, BS), dim3(256), 0, st, feat, ldf, A, part, asum, n, c, J, nck);
-    hipLaunchKernelGGL(pool_final_kernel, dim3(J, B, cdiv(c, 64)), dim3(64), 0, st, part, asum, mode == 2 ? msum : (const float*)nullptr,
+    if (c % 64 == 0 && !force_valu)
+        hipLaunchKernelGGL(pool_mfma_kernel, dim3(nck, BS), dim3(256), 0, st, feat, ldf, A, part, asum, n, c, J, nck);
+    else
+        hipLaunchKernelGGL(pool_partial_kernel, dim3(nck, BS), dim3(256), 0, st, feat, ldf, A, part, asum, n, c, J, nck);
+    hipLaunchKernelGGL(pool_final_kernel, dim3(J, B, cdiv(c, 64)), dim3(256), 0, st, part, asum, mode == 2 ? msum : (const float*)nullptr,
                        protos, S, c, J, nck, mode == 0 ? 1e-6f : 1e-5f);
     return launch_status("protos/pool");
 }
@@ -554,12 +788,19 @@ extern "C" int pemp_cosine_proto_max_f32(const float* qry, int ldf, const float*
     PEMP_REQUIRE(B > 0 && n > 0 && p >= 1 && 2 * p <= MAXJ, "cosine: bad dims");
     PEMP_REQUIRE(c > 0 && c % 4 == 0 && c <= 64 * MAXCL && ldf >= c && ldf % 4 == 0, "cosine: c=%d must be a multiple of 4 and <= %d", c, 64 * MAXCL);
     PEMP_REQUIRE(((uintptr_t)qry & 15) == 0, "cosine: qry must be 16-byte aligned");
-    static const bool force_valu = getenv("PEMP_COSINE_VALU") != nullptr;     // A/B switch for measurements
-    if (c % 8 == 0 && !force_valu) {
-        // MFMA outer product: 32 query pixels x (2p prototypes padded to 32 columns) per wave
-        const size_t lds = (size_t)(2 * p + 1) * c * sizeof(float);
-        hipLaunchKernelGGL(cosine_mfma_kernel, dim3(cdiv(cdiv(n, 32), 4), B), dim3(256), lds, (hipStream_t)stream, qry, ldf,
-                           protos, pred, resp, n, c, p, dist_scalar);
+    static const bool force_valu = getenv("PEMP_HEAD_VALU") != nullptr;     // A/B switch for measurements
+    if (mfma_rows_ok(c) && !force_valu) {
+        // MFMA outer product: 16 query pixels x (2p prototypes padded to 16 columns) per wave
+        const size_t lds = proj_lds_bytes(2 * p, c);
+        const dim3 grid(cdiv(cdiv(n, 16), 4), B);
+#define PEMP_COS(NQ)                                                                                                  \
+    hipLaunchKernelGGL(cosine_mfma_kernel<NQ>, grid, dim3(256), lds, (hipStream_t)stream, qry, ldf, protos, pred, resp, n, c, \
+                       p, dist_scalar)
+        if (c == 512) PEMP_COS(8);
+        else if (c == 256) PEMP_COS(4);
+        else if (c == 128) PEMP_COS(2);
+        else PEMP_COS(1);
+#undef PEMP_COS
         return launch_status("cosine_mfma");
     }
     hipLaunchKernelGGL(cosine_kernel, dim3(min(cdiv(n, 4), max(1, 4096 / B)), B), dim3(256), 0, (hipStream_t)stream, qry, ldf, protos,

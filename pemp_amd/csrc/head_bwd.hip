@@ -13,20 +13,18 @@ namespace pemp {
 
 // -----------------------------------------------------------------------------------------------
 // per-shot prototypes from the forward workspace:  Pps[bs][j][c] = N/D,  Dps[bs][j] = D
-__global__ __launch_bounds__(64) void pool_shot_kernel(const float* __restrict__ part, const float* __restrict__ asum,
-                                                       const float* __restrict__ den_override,
-                                                       float* __restrict__ Pps, float* __restrict__ Dps, int c, int J,
-                                                       int nchunks, float eps) {
+__global__ __launch_bounds__(256) void pool_shot_kernel(const float* __restrict__ part, const float* __restrict__ asum,
+                                                        const float* __restrict__ den_override,
+                                                        float* __restrict__ Pps, float* __restrict__ Dps, int c, int J,
+                                                        int nchunks, float eps) {
+    __shared__ float red[4][64];
     const int bs = blockIdx.y, j = blockIdx.x;
-    float den = 0.f;
-    for (int k = 0; k < nchunks; ++k) den += asum[((size_t)bs * nchunks + k) * J + j];
+    const int ch = blockIdx.z * 64 + (threadIdx.x & 63), chl = min(ch, c - 1);
+    const float num = chunk_sum(part + ((size_t)bs * nchunks * J + j) * c + chl, (size_t)J * c, nchunks, red);
+    float den = chunk_sum(asum + (size_t)bs * nchunks * J + j, (size_t)J, nchunks, red);
     if (den_override) den = den_override[bs * J + j];      // Baseline: exact full-resolution mask sums
     den += eps;
-    for (int ch = blockIdx.z * 64 + threadIdx.x; ch < c; ch += gridDim.z * 64) {
-        float num = 0.f;
-        for (int k = 0; k < nchunks; ++k) num += part[(((size_t)bs * nchunks + k) * J + j) * c + ch];
-        Pps[((size_t)bs * J + j) * c + ch] = num / den;
-    }
+    if (threadIdx.x < 64 && ch < c) Pps[((size_t)bs * J + j) * c + ch] = num / den;
     if (blockIdx.z == 0 && threadIdx.x == 0) Dps[bs * J + j] = den;
 }
 
@@ -520,7 +518,7 @@ static int head_bwd_impl(const float* sup_feat, const float* qry_feat, int ldf, 
     float* cpart = dP + (size_t)B * J * c;
     float* mpart = cpart + (size_t)B * HB_BLOCKS * J * c;
     const int nck = nchunks_of(n);
-    hipLaunchKernelGGL(pool_shot_kernel, dim3(J, BS, cdiv(c, 64)), dim3(64), 0, st, (const float*)L.part,
+    hipLaunchKernelGGL(pool_shot_kernel, dim3(J, BS, cdiv(c, 64)), dim3(256), 0, st, (const float*)L.part,
                        (const float*)L.asum, map_full_res ? (const float*)L.msum : (const float*)nullptr, Pps, Dps, c, J,
                        nck, p > 0 ? 1e-6f : 1e-5f);
     if (dlogits)

@@ -7,7 +7,7 @@ namespace pemp {
 
 constexpr int MAXJ = 8;     // 2p <= 8
 constexpr int MAXCL = 8;    // channels per lane: c <= 64*MAXCL = 512
-constexpr int PCHUNK = 32;  // pixels per pooling block
+constexpr int PCHUNK = 64;  // pixels per pooling block
 
 static inline int nchunks_of(int n) { return cdiv(n, PCHUNK); }
 
@@ -31,6 +31,21 @@ static inline PoolWs pool_ws_layout(void* ws, int BS, int n, int c, int J) {
     l.asum = l.part + (size_t)BS * nck * J * c;
     l.msum = l.asum + (size_t)BS * nck * J;
     return l;
+}
+
+// Sum over the pooling chunks of one (image, row j) by a 256-thread block: wave v adds chunks v, v+4, ... in
+// order, the four partial sums combine as (s0 + s1) + (s2 + s3) -- one order for the forward (pool_final) and the
+// backward (pool_shot).  `p` already carries the lane's channel offset; every thread of the block must call.
+__device__ __forceinline__ float chunk_sum(const float* __restrict__ p, size_t stride, int nchunks, float (*red)[64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = wave; k < nchunks; k += 4) s += p[k * stride];
+    red[wave][lane] = s;
+    __syncthreads();
+    s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    __syncthreads();
+    return s;
 }
 
 // F.interpolate(mode="nearest") source index (legacy rule: floor(dst * in/out), scale in fp32)
