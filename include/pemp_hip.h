@@ -74,6 +74,15 @@ int pemp_pack_input_nhwc4_f32(const float* img, const float* prior, float* out,
 int pemp_maxpool2d_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int ldx,
                             int Ho, int Wo, int ldy, int k, int s, int p, void* stream);
 
+/* Training form of the same layer (contiguous x, y): also writes, per output element, the offset
+ * dh*k+dw of the winning element inside its unclipped window (first maximum in scan order, as ATen's
+ * max_pool2d_with_indices), one byte each; pemp_maxpool2d_idx_bwd_nhwc_f32 routes dy through those
+ * indices (backward of backbones.py:92) without reading x again.                              */
+int pemp_maxpool2d_idx_nhwc_f32(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C,
+                                int Ho, int Wo, int k, int s, int p, void* stream);
+int pemp_maxpool2d_idx_bwd_nhwc_f32(const uint8_t* idx, const float* dy, float* dx, int N, int H, int W,
+                                    int C, int Ho, int Wo, int k, int s, int p, void* stream);
+
 /* F.adaptive_avg_pool2d(x,(1,1)) on NHWC: y[n][c] = mean_i x[n][i][c]
  * (networks/backbones.py:311,360).                                                          */
 int pemp_global_avgpool_nhwc_f32(const float* x, float* y, int N, int HW, int C, int ldx,

@@ -84,6 +84,8 @@ SYMBOLS = {
     "pemp_relu_bias_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int,
                                        c_int, c_fp, c_size, c_fp]),
     "pemp_maxpool2d_bwd_nhwc_f32": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp]),
+    "pemp_maxpool2d_idx_nhwc_f32": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp]),
+    "pemp_maxpool2d_idx_bwd_nhwc_f32": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp]),
     "pemp_scatter_strided_nhwc_f32": (c_int, [c_fp, c_fp] + [c_int] * 7 + [c_fp]),
     "pemp_gap_bwd_add_nhwc_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "pemp_head_bwd_workspace_bytes": (c_size, [c_int] * 5),

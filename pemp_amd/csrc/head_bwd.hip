@@ -29,88 +29,72 @@ __global__ __launch_bounds__(256) void pool_shot_kernel(const float* __restrict_
 }
 
 // -----------------------------------------------------------------------------------------------
-// dpred[b][ch][i] = sum_P W[P][i] * dlogits[b][ch][P],  dlogits = (softmax - onehot) / n_valid_total.
-// One thread per low-resolution pixel; it visits the full-resolution pixels whose bilinear stencil
-// touches it and re-evaluates their logits from `pred`.
-__global__ void ce_upsample_bwd_kernel(const float* __restrict__ pred, const int64_t* __restrict__ target,
-                                       const float* __restrict__ weight, const double* __restrict__ stats, int B, float* __restrict__ dpred, int h, int w,
-                                       int Ho, int Wo) {
+// dpred[b][ch][i] = sum_P W[P][i] * dlogits[b][ch][P]: adjoint of F.interpolate(pred, (Ho,Wo), "bilinear",
+// align_corners=True).  One wave per low-resolution pixel: its 64 lanes share the full-resolution window whose
+// bilinear stencils can touch the pixel (lane-strided, then a fixed butterfly -> deterministic).
+//   DERIVE: dlogits = (softmax - onehot) * weight / n_valid_total, re-evaluated from `pred` (CE path)
+//   else  : dlogits read from memory (autograd bridge)
+template <bool DERIVE>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ pred,
+                                                           const int64_t* __restrict__ target,
+                                                           const float* __restrict__ weight,
+                                                           const double* __restrict__ stats, int B,
+                                                           const float* __restrict__ dlogits, float* __restrict__ dpred,
+                                                           int h, int w, int Ho, int Wo) {
     const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = h * w;
     if (i >= n) return;
-    double nv = 0.0;
-    for (int k = 0; k < B; ++k) nv += stats[k * 8 + 1];
-    const float inv = nv > 0.0 ? (float)(1.0 / nv) : 0.f;
+    float inv = 0.f;
+    if (DERIVE) {
+        double nv = 0.0;
+        for (int k = 0; k < B; ++k) nv += stats[k * 8 + 1];
+        inv = nv > 0.0 ? (float)(1.0 / nv) : 0.f;
+    }
     const int y = i / w, x = i - y * w;
     const float* p0 = pred + (size_t)b * 2 * n;
     const float* p1 = p0 + n;
+    const float* d0 = dlogits + (size_t)b * 2 * Ho * Wo;
+    const float* d1 = d0 + (size_t)Ho * Wo;
     const float sh = (Ho > 1 && h > 1) ? (float)(h - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1 && w > 1) ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
     const int Y0 = sh > 0.f ? max(0, (int)floorf((float)(y - 1) / sh) - 1) : 0;
     const int Y1 = sh > 0.f ? min(Ho - 1, (int)ceilf((float)(y + 1) / sh) + 1) : Ho - 1;
     const int X0 = sw > 0.f ? max(0, (int)floorf((float)(x - 1) / sw) - 1) : 0;
     const int X1 = sw > 0.f ? min(Wo - 1, (int)ceilf((float)(x + 1) / sw) + 1) : Wo - 1;
+    const int nx = X1 - X0 + 1, npts = (Y1 - Y0 + 1) * nx;
     float g0 = 0.f, g1 = 0.f;
-    for (int Y = Y0; Y <= Y1; ++Y) {
+    for (int t = lane; t < npts; t += 64) {
+        const int Y = Y0 + t / nx, X = X0 + t % nx;
         const Bilin by = bilin(Y, h, Ho);
         const float wy = (by.i0 == y ? 1.f - by.l : 0.f) + (by.i1 == y && by.i1 != by.i0 ? by.l : 0.f) +
                          (by.i1 == by.i0 && by.i0 == y ? by.l : 0.f);
-        if (wy == 0.f) continue;
-        for (int X = X0; X <= X1; ++X) {
-            const Bilin bx = bilin(X, w, Wo);
-            const float wx = (bx.i0 == x ? 1.f - bx.l : 0.f) + (bx.i1 == x && bx.i1 != bx.i0 ? bx.l : 0.f) +
-                             (bx.i1 == bx.i0 && bx.i0 == x ? bx.l : 0.f);
-            if (wx == 0.f) continue;
-            const int t = (int)target[((size_t)b * Ho + Y) * Wo + X];
-            if (t == 255) continue;
+        const Bilin bx = bilin(X, w, Wo);
+        const float wx = (bx.i0 == x ? 1.f - bx.l : 0.f) + (bx.i1 == x && bx.i1 != bx.i0 ? bx.l : 0.f) +
+                         (bx.i1 == bx.i0 && bx.i0 == x ? bx.l : 0.f);
+        if (wy == 0.f || wx == 0.f) continue;
+        if (DERIVE) {
+            const int tg = (int)target[((size_t)b * Ho + Y) * Wo + X];
+            if (tg == 255) continue;
             const float l0 = bilerp(p0, w, by, bx), l1 = bilerp(p1, w, by, bx);
             const float m = fmaxf(l0, l1);
             const float e0 = expf(l0 - m), e1 = expf(l1 - m);
             const float s = e0 + e1;
             const float wgt = wy * wx * inv * (weight ? weight[((size_t)b * Ho + Y) * Wo + X] : 1.f);
-            g0 += wgt * (e0 / s - (t == 0 ? 1.f : 0.f));
-            g1 += wgt * (e1 / s - (t == 1 ? 1.f : 0.f));
-        }
-    }
-    dpred[((size_t)b * 2 + 0) * n + i] = g0;
-    dpred[((size_t)b * 2 + 1) * n + i] = g1;
-}
-
-// Adjoint of F.interpolate(pred, (Ho,Wo), "bilinear", align_corners=True) for an arbitrary upstream gradient:
-// dpred[b][ch][i] = sum_P W[P][i] * dlogits[b][ch][P]   (same gather as above, dlogits read instead of derived).
-__global__ void upsample_bwd_kernel(const float* __restrict__ dlogits, float* __restrict__ dpred, int h, int w, int Ho,
-                                    int Wo) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = h * w;
-    if (i >= n) return;
-    const int y = i / w, x = i - y * w;
-    const float sh = (Ho > 1 && h > 1) ? (float)(h - 1) / (float)(Ho - 1) : 0.f;
-    const float sw = (Wo > 1 && w > 1) ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
-    const int Y0 = sh > 0.f ? max(0, (int)floorf((float)(y - 1) / sh) - 1) : 0;
-    const int Y1 = sh > 0.f ? min(Ho - 1, (int)ceilf((float)(y + 1) / sh) + 1) : Ho - 1;
-    const int X0 = sw > 0.f ? max(0, (int)floorf((float)(x - 1) / sw) - 1) : 0;
-    const int X1 = sw > 0.f ? min(Wo - 1, (int)ceilf((float)(x + 1) / sw) + 1) : Wo - 1;
-    const float* d0 = dlogits + (size_t)b * 2 * Ho * Wo;
-    const float* d1 = d0 + (size_t)Ho * Wo;
-    float g0 = 0.f, g1 = 0.f;
-    for (int Y = Y0; Y <= Y1; ++Y) {
-        const Bilin by = bilin(Y, h, Ho);
-        const float wy = (by.i0 == y ? 1.f - by.l : 0.f) + (by.i1 == y && by.i1 != by.i0 ? by.l : 0.f) +
-                         (by.i1 == by.i0 && by.i0 == y ? by.l : 0.f);
-        if (wy == 0.f) continue;
-        for (int X = X0; X <= X1; ++X) {
-            const Bilin bx = bilin(X, w, Wo);
-            const float wx = (bx.i0 == x ? 1.f - bx.l : 0.f) + (bx.i1 == x && bx.i1 != bx.i0 ? bx.l : 0.f) +
-                             (bx.i1 == bx.i0 && bx.i0 == x ? bx.l : 0.f);
-            if (wx == 0.f) continue;
+            g0 += wgt * (e0 / s - (tg == 0 ? 1.f : 0.f));
+            g1 += wgt * (e1 / s - (tg == 1 ? 1.f : 0.f));
+        } else {
             g0 += wy * wx * d0[(size_t)Y * Wo + X];
             g1 += wy * wx * d1[(size_t)Y * Wo + X];
         }
     }
-    dpred[((size_t)b * 2 + 0) * n + i] = g0;
-    dpred[((size_t)b * 2 + 1) * n + i] = g1;
+    g0 = wave_sum(g0);
+    g1 = wave_sum(g1);
+    if (lane == 0) {
+        dpred[((size_t)b * 2 + 0) * n + i] = g0;
+        dpred[((size_t)b * 2 + 1) * n + i] = g1;
+    }
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -150,19 +134,29 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < MAXCL; ++e) accP[j][e] = 0.f;
 
+    // the next pixel's row is requested before the current one is worked on (the loop is latency-bound)
+    float4 nxt[MAXCL / 4];
+    auto fetch = [&](int i) {
+        const float* xp = qry + ((size_t)b * n + min(i, n - 1)) * ldf;
+#pragma unroll
+        for (int t = 0; t < MAXCL / 4; ++t) {
+            int ch = t * 256 + lane * 4;
+            nxt[t] = (t < ncl && ch < c) ? *(const float4*)(xp + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(blockIdx.x * 4 + wave);
     for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
-        const float* xp = qry + ((size_t)b * n + i) * ldf;
         float u[MAXCL];
         float ss = 0.f;
 #pragma unroll
         for (int t = 0; t < MAXCL / 4; ++t) {
-            int ch = t * 256 + lane * 4;
-            float4 v = (t < ncl && ch < c) ? *(const float4*)(xp + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = nxt[t];
             u[t * 4 + 0] = v.x; u[t * 4 + 1] = v.y; u[t * 4 + 2] = v.z; u[t * 4 + 3] = v.w;
             ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
+        fetch(i + gridDim.x * 4);
         ss = wave_sum(ss);
-        const float nx = fmaxf(sqrtf(ss), 1e-8f);
+        const float nx = fmaxf(sqrtf(ss), 1e-8f), rnx = 1.f / nx;
         float dot[MAXJ];
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) dot[j] = 0.f;
@@ -171,7 +165,7 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
             int ch = t * 256 + lane * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                u[t * 4 + e] = u[t * 4 + e] / nx;
+                u[t * 4 + e] = u[t * 4 + e] * rnx;
                 if (t < ncl && ch < c) {
 #pragma unroll
                     for (int j = 0; j < MAXJ; ++j)
@@ -215,7 +209,7 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float v = pn[j][ch + e], uu = u[t * 4 + e];
-                                dy[t * 4 + e] += kk * (v - cj * uu) / nx;
+                                dy[t * 4 + e] += kk * (v - cj * uu) * rnx;
                                 accP[j][t * 4 + e] += kk * (uu - cj * v) * inp;
                             }
                         }
@@ -257,15 +251,15 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
     for (int t = threadIdx.x; t < J * c; t += 256) out[t] = red[t];
 }
 
-// out[k] = scale * sum_{q<nparts} part[q][k]   (fixed order); optional transposed store [len/J][J] <- [J][len/J]
-__global__ void sum_parts_kernel(const float* __restrict__ part, int nparts, int len, float* __restrict__ out,
-                                 int transpose_J) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// out[k] = sum_{q<nparts} part[q][k]   (fixed order: wave v adds parts v, v+4, ..., then (s0+s1)+(s2+s3));
+// optional transposed store [len/J][J] <- [J][len/J].  Block = 64 values x 4 part lanes.
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, int nparts, int len,
+                                                        float* __restrict__ out, int transpose_J) {
+    __shared__ float red[4][64];
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63), kl = min(k, len - 1);
     const int grp = blockIdx.y;
-    if (k >= len) return;
-    const float* p = part + (size_t)grp * nparts * len;
-    float s = 0.f;
-    for (int q = 0; q < nparts; ++q) s += p[(size_t)q * len + k];
+    const float s = chunk_sum(part + (size_t)grp * nparts * len + kl, (size_t)len, nparts, red);
+    if (threadIdx.x >= 64 || k >= len) return;
     if (transpose_J > 0) {
         const int cdim = len / transpose_J;
         const int j = k / cdim, ch = k - j * cdim;
@@ -331,18 +325,27 @@ __global__ __launch_bounds__(256) void mpm_bwd_kernel(const float* __restrict__ 
             }
     }
     const float* mk = mask + (size_t)bs * 2 * H * W;
+    float4 nxt[MAXCL / 4];               // next pixel's row, requested one iteration ahead
+    auto fetch = [&](int i) {
+        const float* xp = feat + ((size_t)bs * n + min(i, n - 1)) * ldf;
+#pragma unroll
+        for (int t = 0; t < MAXCL / 4; ++t) {
+            int ch = t * 256 + lane * 4;
+            nxt[t] = (t < ncl && ch < c) ? *(const float4*)(xp + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(blockIdx.x * 4 + wave);
     for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
         const int y = i / w, x = i - y * w;
         const int sy = nearest_src(y, H, h), sx = nearest_src(x, W, w);
         const float mg[2] = {mk[(size_t)sy * W + sx], mk[(size_t)H * W + (size_t)sy * W + sx]};
-        const float* xp = feat + ((size_t)bs * n + i) * ldf;
         float xv[MAXCL];
 #pragma unroll
         for (int t = 0; t < MAXCL / 4; ++t) {
-            int ch = t * 256 + lane * 4;
-            float4 v = (t < ncl && ch < c) ? *(const float4*)(xp + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = nxt[t];
             xv[t * 4 + 0] = v.x; xv[t * 4 + 1] = v.y; xv[t * 4 + 2] = v.z; xv[t * 4 + 3] = v.w;
         }
+        fetch(i + gridDim.x * 4);
         float a[MAXJ], dd[MAXJ];
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256) void mpm_bwd_kernel(const float* __restrict__ 
     for (int t = threadIdx.x; t < J * c; t += 256) out[t] = red[t];
 }
 
-constexpr int HB_BLOCKS = 32;    // pixel-group blocks per image in the two wave-per-pixel kernels
+constexpr int HB_BLOCKS = 128;   // pixel-group blocks per image in the two wave-per-pixel kernels
 
 }  // namespace pemp
 
@@ -522,13 +525,15 @@ static int head_bwd_impl(const float* sup_feat, const float* qry_feat, int ldf, 
                        (const float*)L.asum, map_full_res ? (const float*)L.msum : (const float*)nullptr, Pps, Dps, c, J,
                        nck, p > 0 ? 1e-6f : 1e-5f);
     if (dlogits)
-        hipLaunchKernelGGL(upsample_bwd_kernel, dim3(cdiv(n, 128), B), dim3(128), 0, st, dlogits, dpred, h, w, Ho, Wo);
+        hipLaunchKernelGGL(upsample_bwd_kernel<false>, dim3(cdiv(n, 4), B), dim3(256), 0, st, (const float*)nullptr,
+                           (const int64_t*)nullptr, (const float*)nullptr, (const double*)nullptr, B, dlogits, dpred, h, w, Ho,
+                           Wo);
     else
-        hipLaunchKernelGGL(ce_upsample_bwd_kernel, dim3(cdiv(n, 128), B), dim3(128), 0, st, pred, target, weight, stats, B,
-                           dpred, h, w, Ho, Wo);
+        hipLaunchKernelGGL(upsample_bwd_kernel<true>, dim3(cdiv(n, 4), B), dim3(256), 0, st, pred, target, weight, stats, B,
+                           (const float*)nullptr, dpred, h, w, Ho, Wo);
     hipLaunchKernelGGL(cosine_bwd_kernel, dim3(HB_BLOCKS, B), dim3(256), 0, st, qry_feat, ldf, protos, (const float*)dpred,
                        dqry, ldd, cpart, n, c, p > 0 ? p : 1, dist_scalar);
-    hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(J * c, 256), B), dim3(256), 0, st, (const float*)cpart, HB_BLOCKS, J * c,
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(J * c, 64), B), dim3(256), 0, st, (const float*)cpart, HB_BLOCKS, J * c,
                        dP, 0);
     int e = launch_status("head_bwd/cosine");
     if (e) return e;
@@ -536,7 +541,7 @@ static int head_bwd_impl(const float* sup_feat, const float* qry_feat, int ldf, 
         hipLaunchKernelGGL(mpm_bwd_kernel<true>, dim3(HB_BLOCKS, BS), dim3(256), 0, st, sup_feat, ldf, mask,
                            (const float*)nullptr, ctr,
                            (const float*)dP, (const float*)Pps, (const float*)Dps, dsup, ldd, mpart, S, n, h, w, H, W, c, p);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(J * c, 256), 1), dim3(256), 0, st, (const float*)mpart,
+        hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(J * c, 64), 1), dim3(256), 0, st, (const float*)mpart,
                            BS * HB_BLOCKS, J * c, dctr, J);
     } else {
         hipLaunchKernelGGL(mpm_bwd_kernel<false>, dim3(HB_BLOCKS, BS), dim3(256), 0, st, sup_feat, ldf, mask,

@@ -64,6 +64,72 @@ __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ 
     }
 }
 
+// Training variant: also records WHICH window element won (first maximum in scan order, as ATen), as its
+// offset (dh * k + dw) inside the unclipped k x k window -- one byte per output element -- so that the
+// backward pass never has to re-scan the input.
+__global__ void maxpool_idx_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
+                                   int N, int H, int W, int C4, int Ho, int Wo, int k, int s, int p) {
+    long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        long long t = i / C4;
+        int wo = (int)(t % Wo);
+        t /= Wo;
+        int ho = (int)(t % Ho);
+        int n = (int)(t / Ho);
+        const int hb = ho * s - p, wb = wo * s - p;
+        const int h0 = max(hb, 0), w0 = max(wb, 0), h1 = min(hb + k, H), w1 = min(wb + k, W);
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int pos[4] = {-1, -1, -1, -1};
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) {
+                const float4 v4 = *(const float4*)(x + (((long long)n * H + h) * W + w) * C4 * 4 + c4 * 4);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > m[e] || pos[e] < 0) {
+                        m[e] = v[e];
+                        pos[e] = (h - hb) * k + (w - wb);
+                    }
+            }
+        *(float4*)(y + i * 4) = make_float4(m[0], m[1], m[2], m[3]);
+        *(uchar4*)(idx + i * 4) = make_uchar4((uint8_t)pos[0], (uint8_t)pos[1], (uint8_t)pos[2], (uint8_t)pos[3]);
+    }
+}
+// dx[pixel] = sum of dy over the (at most ceil(k/s)^2) windows whose recorded winner is this pixel
+__global__ void maxpool_idx_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ dy,
+                                       float* __restrict__ dx, int N, int H, int W, int C4, int Ho, int Wo, int k, int s,
+                                       int p) {
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int ho_lo = max(0, (h + p - k + s) / s), ho_hi = min(Ho - 1, (h + p) / s);
+        const int wo_lo = max(0, (w + p - k + s) / s), wo_hi = min(Wo - 1, (w + p) / s);
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const long long o = ((((long long)n * Ho + ho) * Wo + wo) * C4 + c4) * 4;
+                const uchar4 q = *(const uchar4*)(idx + o);
+                const int me = (h - (ho * s - p)) * k + (w - (wo * s - p));
+                if (q.x == me || q.y == me || q.z == me || q.w == me) {
+                    const float4 g = *(const float4*)(dy + o);
+                    acc[0] += q.x == me ? g.x : 0.f;
+                    acc[1] += q.y == me ? g.y : 0.f;
+                    acc[2] += q.z == me ? g.z : 0.f;
+                    acc[3] += q.w == me ? g.w : 0.f;
+                }
+            }
+        *(float4*)(dx + i * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // global average pool: block = (image, 64 channels); 1024 threads = 64 pixel lanes x 16 float4 channel
 // lanes, so every load is 16 B and a wave reads 4 pixels x 256 contiguous bytes.  Fixed summation
@@ -263,6 +329,27 @@ extern "C" int pemp_maxpool2d_nhwc_f32(const float* x, float* y, int N, int H, i
     hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W,
                        C / 4, ldx, Ho, Wo, ldy, k, s, p);
     return launch_status("maxpool");
+}
+
+extern "C" int pemp_maxpool2d_idx_nhwc_f32(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, int Ho,
+                                           int Wo, int k, int s, int p, void* stream) {
+    PEMP_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_idx: bad arguments");
+    PEMP_REQUIRE(k > 0 && k <= 15 && s > 0 && p >= 0 && 2 * p <= k, "maxpool_idx: bad window");
+    PEMP_REQUIRE(Ho > 0 && Wo > 0 && (Ho - 1) * s - p < H && (Wo - 1) * s - p < W, "maxpool_idx: bad output size");
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_idx_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W,
+                       C / 4, Ho, Wo, k, s, p);
+    return launch_status("maxpool_idx");
+}
+
+extern "C" int pemp_maxpool2d_idx_bwd_nhwc_f32(const uint8_t* idx, const float* dy, float* dx, int N, int H, int W, int C,
+                                               int Ho, int Wo, int k, int s, int p, void* stream) {
+    PEMP_REQUIRE(idx && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_idx_bwd: bad arguments");
+    PEMP_REQUIRE(k > 0 && k <= 15 && s > 0 && p >= 0 && 2 * p <= k && Ho > 0 && Wo > 0, "maxpool_idx_bwd: bad window");
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_idx_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, idx, dy, dx, N,
+                       H, W, C / 4, Ho, Wo, k, s, p);
+    return launch_status("maxpool_idx_bwd");
 }
 
 extern "C" int pemp_global_avgpool_nhwc_f32(const float* x, float* y, int N, int HW, int C, int ldx, void* stream) {

@@ -332,12 +332,12 @@ __global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restr
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// one wave: lane-strided partial sums, then a fixed butterfly (deterministic)
 __global__ void sqsum_final_kernel(const double* __restrict__ part, int nb, float* __restrict__ norm_out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nb; ++i) s += part[i];
-        norm_out[0] = (float)sqrt(s);
-    }
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) norm_out[0] = (float)sqrt(s);
 }
 // torch.nn.utils.clip_grad_norm_ + torch.optim.SGD (momentum, weight decay, no nesterov) in one pass
 __global__ void sgd_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,

@@ -52,8 +52,8 @@ class _VGGEngine(Stage1TrainEngine):
                 y = ops.conv2d(x, obj.fwd_params(relu=relu))
                 recs.append((kind, obj, relu, x, y))
             else:
-                y = ops.maxpool2d(x, 3, obj, 1)
-                recs.append((kind, obj, None, x, y))
+                y, idx = T.maxpool_idx(x.contiguous(), 3, obj, 1)
+                recs.append((kind, obj, None, x.shape[1:3], idx))
             x = y
         tape["vgg"] = recs
         return x
@@ -67,7 +67,7 @@ class _VGGEngine(Stage1TrainEngine):
     def _trunk_backward(self, dx):
         for kind, obj, relu, x, y in reversed(self.tape["vgg"]):
             if kind == "pool":
-                dx = T.maxpool_bwd(x, dx.contiguous(), 3, obj, 1)
+                dx = T.maxpool_idx_bwd(y, dx.contiguous(), x, 3, obj, 1)
                 continue
             g = torch.empty_like(y)
             obj.conv.bias.grad.copy_(T.relu_bias_bwd(dx, y, g, relu=relu, ws_cache=self.ws))

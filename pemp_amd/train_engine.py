@@ -106,7 +106,14 @@ class FlatParams:
         self.dg_data = torch.empty_like(self.data)
 
     def refresh_dgrad_mirror(self):
-        torch.index_select(self.data, 0, self.dg_perm, out=self.dg_data)
+        """Runs on the side stream: only the backward pass reads the mirror (``backward`` joins first), so the gather
+        hides under the forward pass."""
+        if self.side_stream is None:
+            torch.index_select(self.data, 0, self.dg_perm, out=self.dg_data)
+            return
+        self.side_stream.wait_stream(torch.cuda.current_stream())     # after the optimizer step / the last dgrad reader
+        with torch.cuda.stream(self.side_stream):
+            torch.index_select(self.data, 0, self.dg_perm, out=self.dg_data)
 
     def dgrad_krsc(self, p):
         o, rows, cols = self.dg_view[id(p)]
@@ -309,6 +316,7 @@ class Stage1TrainEngine:
 
     def backward(self, dfeat):
         if self.flat.side_stream is not None:      # the side stream must not start before this step's gradients were zeroed
+            torch.cuda.current_stream().wait_stream(self.flat.side_stream)     # the dgrad weight mirror is in place
             self.flat.side_stream.wait_stream(torch.cuda.current_stream())
         self._trunk_backward(self._tail_backward(dfeat))
         self.flat.join_side_stream()               # every weight gradient has landed before the optimizer / all-reduce
@@ -326,7 +334,7 @@ class Stage1TrainEngine:
 
     def _trunk_forward(self, images_list, tape):
         y, tape["stem"] = self._cbn_fwd(self._pack(images_list), *self.stem, relu=True)
-        x = ops.maxpool2d(y, 3, 2, 1, ceil_mode=True)
+        x, tape["pool_idx"] = T.maxpool_idx(y, 3, 2, 1, ceil_mode=True)
         tape["pool_in"], tape["blocks"] = y, []
         for b in self.blocks:
             x, rec = self._block_fwd(x, b)
@@ -441,7 +449,7 @@ class Stage1TrainEngine:
         for b, rec in zip(reversed(self.blocks), reversed(tp["blocks"])):       # residual blocks, last to first
             dx = self._block_bwd(dx, b, rec)
         # stem: max pool, BN+ReLU, 7x7 conv (weight gradient only)
-        dy = T.maxpool_bwd(tp["pool_in"], dx, 3, 2, 1)
+        dy = T.maxpool_idx_bwd(tp["pool_idx"], dx, tp["pool_in"].shape[1:3], 3, 2, 1)
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
 
 

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .ops import ConvDesc, CONV_STEM4, _p, _stream, _chk_dev, _ws, conv_out_size
+from .ops import ConvDesc, CONV_STEM4, _p, _stream, _chk_dev, _ws, conv_out_size, _pool_out
 
 
 def _rows(t, name):
@@ -123,6 +123,32 @@ def dgrad_weight(w_krsc, kh, kw):
     cin = w_krsc.shape[1] // (kh * kw)
     w = w_krsc.view(cout, kh, kw, cin)
     return w.flip(1, 2).permute(3, 1, 2, 0).contiguous().view(cin, kh * kw * cout)
+
+
+def maxpool_idx(x, k, s, p, ceil_mode=False):
+    """nn.MaxPool2d forward that also records the winners -> (y, idx uint8 [n,ho,wo,c])."""
+    lib = _lib.load()
+    _chk_dev(x)
+    if not x.is_contiguous():
+        raise ValueError("maxpool_idx: contiguous NHWC tensor required")
+    n, h, w, c = x.shape
+    ho, wo = _pool_out(h, k, s, p, ceil_mode), _pool_out(w, k, s, p, ceil_mode)
+    y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.pemp_maxpool2d_idx_nhwc_f32(_p(x), _p(y), _p(idx), n, h, w, c, ho, wo, k, s, p, _stream()), "maxpool_idx")
+    return y, idx
+
+
+def maxpool_idx_bwd(idx, dy, in_hw, k, s, p):
+    lib = _lib.load()
+    _chk_dev(idx, dy)
+    n, ho, wo, c = dy.shape
+    h, w = in_hw
+    if not (idx.is_contiguous() and dy.is_contiguous()) or idx.shape != dy.shape or idx.dtype != torch.uint8:
+        raise ValueError("maxpool_idx_bwd: contiguous NHWC dy and matching uint8 idx required")
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.pemp_maxpool2d_idx_bwd_nhwc_f32(_p(idx), _p(dy), _p(dx), n, h, w, c, ho, wo, k, s, p, _stream()), "maxpool_idx_bwd")
+    return dx
 
 
 def maxpool_bwd(x, dy, k, s, p):

@@ -95,7 +95,7 @@ class Stage2TrainEngine(Stage1TrainEngine):
         prior = torch.cat([p.reshape(-1, *p.shape[-2:]) for p in priors]).contiguous()
         mask = ops.cm_reduce(None, prior, 2)[0]                               # backbones.py:227
         y, tape["stem"] = self._cbn_fwd(self._pack(images_list, priors), *self.stem, relu=True)
-        x = ops.maxpool2d(y, 3, 2, 1, ceil_mode=True)
+        x, tape["pool_idx"] = T.maxpool_idx(y, 3, 2, 1, ceil_mode=True)
         tape["pool_in"], tape["blocks"], tape["cm"] = y, [], []
         tape["group"] = group
         for bi, b in enumerate(self.blocks):
@@ -131,7 +131,7 @@ class Stage2TrainEngine(Stage1TrainEngine):
             b["ds"][0].ext_backward(ops.global_avgpool(dzd) * hw_out, cm["feat"], group, dfi, accumulate=True)
             dstat = T.cm_linear_bwd(dfi, group, cm["agg"], lin.weight.data, lin.weight.grad, lin.bias.grad)
             T.cm_bwd_add(cm["x"], cm["mask"], dstat.view(n, 2, c), dx)         # [N,2,C]: d(mean), d(max) per image
-        dy = T.maxpool_bwd(tp["pool_in"], dx, 3, 2, 1)
+        dy = T.maxpool_idx_bwd(tp["pool_idx"], dx, tp["pool_in"].shape[1:3], 3, 2, 1)
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
 
     # -- purifier: conv+ReLU+Dropout2d twice, ASPP (no BN), layer6 ------------------------------

@@ -136,6 +136,19 @@ def test_relu_bias_bwd_and_pools(hip_lib, dev):
     yp.backward(gp)
     dx = T.maxpool_bwd(_nhwc(x.detach()).to(dev), _nhwc(gp).to(dev), 3, 2, 1)
     assert torch.allclose(_nchw(dx.cpu()), x.grad, rtol=1e-6, atol=1e-6)
+    # index-recording form used by the training engines: same output, same gradient (bit-exact), for the
+    # ResNet stem pool (3/2/1 ceil) and the VGG stride-1 pool (3/1/1)
+    for s, ceil in ((2, True), (1, False)):
+        xs = (_rand(2, 8, 49, 49, seed=9 + s) * 4).round().requires_grad_()
+        ys = F.max_pool2d(xs, 3, s, 1, ceil_mode=ceil)
+        gs = _rand(*ys.shape, seed=12 + s)
+        ys.backward(gs)
+        xd = _nhwc(xs.detach()).to(dev)
+        yi, idx = T.maxpool_idx(xd, 3, s, 1, ceil_mode=ceil)
+        assert torch.equal(_nchw(yi.cpu()), ys.detach()) and idx.dtype == torch.uint8 and int(idx.max()) <= 8
+        dxi = T.maxpool_idx_bwd(idx, _nhwc(gs).to(dev), xd.shape[1:3], 3, s, 1)
+        assert torch.equal(dxi, T.maxpool_bwd(xd, _nhwc(gs).to(dev), 3, s, 1))
+        assert torch.allclose(_nchw(dxi.cpu()), xs.grad, rtol=1e-6, atol=1e-6)
     # global average pool backward
     xg = _rand(3, 64, 5, 7, seed=7).requires_grad_()
     v = _rand(3, 64, seed=8)
