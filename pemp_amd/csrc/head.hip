@@ -245,7 +245,7 @@ __global__ void mask_assign_kernel(const float* __restrict__ mask, float* __rest
 typedef __attribute__((ext_vector_type(4))) float hv4f;
 constexpr int SQ = 64;                 // channels per stage pass
 constexpr int SLD = SQ + 4;            // stage row stride in floats: 16-B reads of 16 rows hit 64 different banks
-constexpr int NB = 4;                  // passes in flight (4 KB per wave each)
+constexpr int NB = 2;                  // passes in flight (4 KB per wave each)
 constexpr int TV = MAXJ * 64 * MAXCL / 256;   // table elements per thread
 
 // 16 pixel rows x c channels through a wave-private LDS stage, SQ channels at a time.  HBM side: lane l reads
@@ -330,7 +330,7 @@ __device__ __forceinline__ float table_sqnorm(const float* tab, int ldt, int J, 
 
 // cosine map x dist_scalar, group maxima, response index: the MFMA outer product with fused L2 normalisation.
 template <int NQ>
-__global__ __launch_bounds__(256) void cosine_mfma_kernel(const float* __restrict__ qry, int ldf,
+__global__ __launch_bounds__(256, 5) void cosine_mfma_kernel(const float* __restrict__ qry, int ldf,
                                                           const float* __restrict__ protos, float* __restrict__ pred,
                                                           uint8_t* __restrict__ resp, int n, int c, int p,
                                                           float scalar) {
@@ -369,17 +369,19 @@ __global__ __launch_bounds__(256) void cosine_mfma_kernel(const float* __restric
     for (int j = 0; j < MAXJ; ++j) v[j] = v[j] / fmaxf(sqrtf(__shfl(pn2, j, 64)), 1e-8f) * f;
     const int i = i0 + r;
     if (q == 0 && i < n) {
-        float best[2];
-        int bi[2];
-        for (int g = 0; g < 2; ++g) {          // g = 0: fg rows [0,p), g = 1: bg rows [p,2p)
-            best[g] = v[g * p];
-            bi[g] = 0;
-            for (int j = 1; j < p; ++j)
-                if (v[g * p + j] > best[g]) {
-                    best[g] = v[g * p + j];
-                    bi[g] = j;
+        float best[2] = {0.f, 0.f};              // [0]: fg rows [0,p), [1]: bg rows [p,2p); first maximum wins
+        int bi[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)            // static register indices: no scratch for v[]
+            if (j < J) {
+                const bool fg = j < p;
+                const int first = fg ? 0 : p;
+                if (fg) {
+                    if (j == first || v[j] > best[0]) { best[0] = v[j]; bi[0] = j; }
+                } else {
+                    if (j == first || v[j] > best[1]) { best[1] = v[j]; bi[1] = j - p; }
                 }
-        }
+            }
         pred[((size_t)b * 2 + 0) * n + i] = best[1];
         pred[((size_t)b * 2 + 1) * n + i] = best[0];
         if (resp) resp[(size_t)b * n + i] = (uint8_t)(best[0] > best[1] ? bi[0] + 3 : bi[1]);
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void cosine_mfma_kernel(const float* __restric
 // the fg and the bg group equals softmax_j(2 x.c_j - |c_j|^2) -- |x|^2 is common to a group and drops
 // out -- so the MFMA accumulates x.c_j and the epilogue finishes 16 pixels on 16 lanes.
 template <int NQ>
-__global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restrict__ feat, int ldf,
+__global__ __launch_bounds__(256, 5) void assign_mfma_kernel(const float* __restrict__ feat, int ldf,
                                                           const float* __restrict__ mask,
                                                           const float* __restrict__ ctr, float* __restrict__ A,
                                                           int n, int h, int w, int H, int W, int c, int p) {
@@ -413,13 +415,13 @@ __global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restric
     }
     for (int ch = threadIdx.x; ch < c; ch += 256) tab[J * ldt + ch] = 0.f;
     __syncthreads();
-    const float cn2 = table_sqnorm(tab, ldt, J, c, lane);
-    float cn[MAXJ];
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) cn[j] = __shfl(cn2, j, 64);
     hv4f acc = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
     rt.template run<false>(stage, tab + (size_t)min(r, J) * ldt + 4 * q, lane, acc, ss);
+    const float cn2 = table_sqnorm(tab, ldt, J, c, lane);            // |c_j|^2, needed by the epilogue only
+    float cn[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) cn[j] = __shfl(cn2, j, 64);
     float v[MAXJ];
     rows_to_lanes(acc, lane, v);
     const int i = i0 + r;
@@ -429,19 +431,24 @@ __global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restric
         const float* mk = mask + (size_t)bs * 2 * H * W;
         const float mg[2] = {mk[(size_t)sy * W + sx], mk[(size_t)H * W + (size_t)sy * W + sx]};
         float* out = A + ((size_t)bs * J) * n + i;
-        for (int g = 0; g < 2; ++g) {
-            float l[MAXJ / 2], mx = -INFINITY;
-            for (int j = 0; j < p; ++j) {
-                l[j] = 2.f * v[g * p + j] - cn[g * p + j];
-                mx = fmaxf(mx, l[j]);
+        float l[MAXJ], mx[2] = {-INFINITY, -INFINITY}, sm[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)            // static register indices throughout; group 0 = rows [0,p)
+            if (j < J) {
+                l[j] = 2.f * v[j] - cn[j];
+                if (j < p) mx[0] = fmaxf(mx[0], l[j]);
+                else mx[1] = fmaxf(mx[1], l[j]);
             }
-            float s = 0.f;
-            for (int j = 0; j < p; ++j) {
-                l[j] = expf(l[j] - mx);
-                s += l[j];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)
+            if (j < J) {
+                l[j] = expf(l[j] - (j < p ? mx[0] : mx[1]));
+                if (j < p) sm[0] += l[j];
+                else sm[1] += l[j];
             }
-            for (int j = 0; j < p; ++j) out[(size_t)(g * p + j) * n] = (l[j] / s) * mg[g];
-        }
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)
+            if (j < J) out[(size_t)j * n] = (l[j] / (j < p ? sm[0] : sm[1])) * (j < p ? mg[0] : mg[1]);
     }
 }
 
@@ -451,11 +458,11 @@ __global__ __launch_bounds__(256) void assign_mfma_kernel(const float* __restric
 // wave-wide load is 4 pixels x 256 contiguous bytes -- and feeds four MFMAs with four accumulators (channels
 // 4m + e); wave v owns slabs v and v + 4, so a block covers c <= 512 channels and every row is read once.
 // Four pixel-quads (8 KB per wave) are fetched per group, two groups in flight.
-__global__ __launch_bounds__(256) void pool_mfma_kernel(const float* __restrict__ feat, int ldf,
+__global__ __launch_bounds__(256, 5) void pool_mfma_kernel(const float* __restrict__ feat, int ldf,
                                                         const float* __restrict__ A, float* __restrict__ part,
                                                         float* __restrict__ asum, int n, int c, int J, int nchunks) {
     __shared__ float As[MAXJ + 1][PCHUNK];
-    constexpr int QG = 4;                                            // pixel quads per prefetch group
+    constexpr int QG = 2;                                            // pixel quads per prefetch group
     constexpr int NG = PCHUNK / (4 * QG);
     const int bs = blockIdx.y, ck = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
