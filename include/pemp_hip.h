@@ -64,6 +64,15 @@ int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w
                          const float* scale, const float* shift, const float* residual,
                          void* stream);
 
+/* Same convolution with a per-input-channel PADDING VALUE: out-of-image taps read pad_value[ci] instead
+ * of 0 (pad_value NULL = the call above).  This is what lets a BatchNorm that sits IN FRONT of a padded
+ * conv (ASPPV2 branches, networks/backbones.py:330-357: BN -> ReLU-less conv on the BN output, zero-padded
+ * in BN space) fold into the conv exactly:  conv_W(s*x + t, pad 0) = conv_{W*s}(x, pad -t/s) + sum_taps W t.
+ * Multi-tap, non-stem convs only.                                                                   */
+int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y,
+                              const float* scale, const float* shift, const float* residual,
+                              const float* pad_value, void* stream);
+
 /* [N,3,H,W] image (+ optional [N,1,H,W] prior; NULL -> 0) -> NHWC4 [N,H,W,4].
  * Replaces torch.cat/view at networks/pemp_stage1.py:139, pemp_stage2.py:130-138.          */
 int pemp_pack_input_nhwc4_f32(const float* img, const float* prior, float* out,

@@ -14,6 +14,7 @@ struct ConvArgs {
     const float* scale;
     const float* shift;
     const float* res;
+    const float* padv;      // per-input-channel value of out-of-image taps (NULL: zero padding)
     int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, KH, KW, stride, pad, dil, ldr, Kpad;
     unsigned flags;
     int M, HoWo, cin_steps, nk, ntaps;

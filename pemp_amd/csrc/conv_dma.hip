@@ -87,10 +87,11 @@ __global__ __launch_bounds__(NW * 64) void conv_dma_kernel(ConvArgs a) {
         const int kh = tap__ / a.KW, kw = tap__ - kh * a.KW;                                         \
         const int dh = kh * a.dil, dw = kw * a.dil;                                                  \
         const bool tok = tap__ < a.ntaps;                                                            \
+        const float* const oob__ = (a.padv && tok) ? a.padv + coff__ : zero;   /* padding value of this channel quad */ \
         _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                             \
             const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                        \
             const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;     \
-            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + coff__ : zero;        \
+            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + coff__ : oob__;       \
         }                                                                                            \
     } while (0)
 

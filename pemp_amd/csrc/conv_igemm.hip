@@ -99,12 +99,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int kh = tap__ / a.KW, kw = tap__ - kh * a.KW;                                         \
         const int dh = kh * a.dil, dw = kw * a.dil;                                                  \
         const bool tok = tap__ < a.ntaps;                                                            \
+        const bool pv__ = a.padv && tok;              /* out-of-image taps read the padding vector */ \
+        const float* const oob__ = pv__ ? a.padv + coff__ : a.x;                                     \
         okmask = 0;                                                                                  \
         _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                             \
             const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;                                        \
             const bool ok = tok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;     \
-            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + coff__ : a.x;         \
-            okmask |= (ok ? 1u : 0u) << i;                                                           \
+            pa[i] = ok ? a.x + (ptrdiff_t)(a_pix[i] + dh * a.W + dw) * a.ldx + coff__ : oob__;       \
+            okmask |= ((ok || pv__) ? 1u : 0u) << i;                                                 \
         }                                                                                            \
     } while (0)
 
@@ -254,7 +256,15 @@ using namespace pemp;
 extern "C" int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y,
                                     const float* scale, const float* shift, const float* residual,
                                     void* stream) {
+    return pemp_conv2d_padv_nhwc_f32(d, x, w, y, scale, shift, residual, nullptr, stream);
+}
+
+extern "C" int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y,
+                                         const float* scale, const float* shift, const float* residual,
+                                         const float* pad_value, void* stream) {
     PEMP_REQUIRE(d && x && w && y, "conv2d: null pointer");
+    PEMP_REQUIRE(!pad_value || (!(d->flags & PEMP_CONV_STEM4) && d->KH * d->KW > 1 && ((uintptr_t)pad_value & 15) == 0),
+                 "conv2d: pad_value needs a multi-tap non-stem conv and a 16-byte aligned [Cin] vector");
     PEMP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv2d: bad dims");
     PEMP_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
     const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
@@ -280,7 +290,7 @@ extern "C" int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, con
     PEMP_REQUIRE(in_elems < (1ll << 31) && out_elems < (1ll << 31), "conv2d: tensor too large for 32-bit indexing");
 
     ConvArgs a;
-    a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual;
+    a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual; a.padv = pad_value;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cout = d->Cout; a.ldy = d->ldy; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.dil = d->dil; a.ldr = d->ldr; a.Kpad = d->Kpad; a.flags = d->flags;

@@ -6,6 +6,8 @@ Eval-mode arithmetic only in this round (BatchNorm folded with running statistic
 ATen's eval kernel: alpha = weight * rsqrt(var + eps), beta = bias - mean * alpha; DropBlock and
 Dropout2d are identities).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -174,19 +176,33 @@ class ASPPV2Engine:
         self.l6_main = conv_params(l6, None, relu=False, in_slice=(midc, 5 * midc))
         self.l6_main.shift = None
         self.midc = midc
+        # The BatchNorm in front of every branch folds into its conv: W*s, bias + sum_taps W t, and -- because the
+        # reference zero-pads the BN OUTPUT -- out-of-image taps of the dilated convs read -t/s (ops.fold_input_affine).
+        # That removes the pass that wrote four normalised copies of x (20 % of the non-conv time of an eval step).
+        # PEMP_ASPP_COPIES=1 (or a zero BN scale) keeps the copy path.
+        folded = [ops.fold_input_affine(self.br[i], *self.bn[i]) for i in range(5)]
+        self.folded = None if (os.environ.get("PEMP_ASPP_COPIES") or any(f is None for f in folded)) else folded
 
     def forward(self, x):
         a = self.arena
         n, h, w, c = x.shape
         midc = self.midc
         g = ops.global_avgpool(x, out=a.get("gap", (n, c)))
+        cat = a.get("aspp_cat", (n, h, w, 4 * midc))
+        if self.folded is not None:
+            g2 = ops.conv2d(g.view(n, 1, 1, c), self.folded[0][0], out=a.get("gap_c", (n, 1, 1, midc)))
+            bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
+            for i in range(4):
+                q, padv = self.folded[i + 1]
+                ops.conv2d(x, q, out=cat[..., i * midc:(i + 1) * midc], pad_value=padv if q.kh * q.kw > 1 else None)
+            return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),
+                              shift_override=bias6.view(n, -1), per_image_shift=True)
         gb = a.get("gap_bn", (n, c))
         ops.channel_affine_multi(g, [self.bn[0][0]], [self.bn[0][1]], [gb])
         g2 = ops.conv2d(gb.view(n, 1, 1, c), self.br[0], out=a.get("gap_c", (n, 1, 1, midc)))
         bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
         xb = [a.get(("aspp_in", i), (n, h, w, c)) for i in range(4)]
         ops.channel_affine_multi(x, [s for s, _ in self.bn[1:]], [t for _, t in self.bn[1:]], xb)
-        cat = a.get("aspp_cat", (n, h, w, 4 * midc))
         for i in range(4):
             ops.conv2d(xb[i], self.br[i + 1], out=cat[..., i * midc:(i + 1) * midc])
         return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),

@@ -116,8 +116,10 @@ def pack_conv_weight(w_oihw, stem4=False):
     return w.reshape(co, kh * kw * ci), kh * kw * ci
 
 
-def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=False, relu=None, tile=0):
-    """y = act(scale * conv(x, w) + shift (+ residual)).  x: NHWC view, returns NHWC tensor/view ``out``."""
+def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=False, relu=None, tile=0,
+           pad_value=None):
+    """y = act(scale * conv(x, w) + shift (+ residual)).  x: NHWC view, returns NHWC tensor/view ``out``.
+    ``pad_value`` [Cin]: what out-of-image taps read instead of zero (multi-tap convs; see fold_input_affine)."""
     lib = _lib.load()
     _chk_dev(x, p.w, out, residual)
     ldx = _nhwc(x, "x")
@@ -137,6 +139,10 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
         if tuple(residual.shape) != tuple(out.shape):
             raise ValueError("conv2d: residual shape mismatch")
     shift = p.shift if shift_override is None else shift_override
+    if pad_value is not None:
+        _chk_dev(pad_value)
+        if pad_value.numel() != cin or pad_value.dtype != torch.float32 or not pad_value.is_contiguous():
+            raise ValueError(f"conv2d: pad_value must be a contiguous fp32 [{cin}] vector")
     flags = 0
     if (p.relu if relu is None else relu):
         flags |= CONV_RELU
@@ -146,8 +152,12 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
         flags |= CONV_STEM4
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, flags, t)
-        _lib.check(lib.pemp_conv2d_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift),
-                                            _p(residual), _stream()), "pemp_conv2d_nhwc_f32")
+        if pad_value is None:
+            _lib.check(lib.pemp_conv2d_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift),
+                                                _p(residual), _stream()), "pemp_conv2d_nhwc_f32")
+        else:
+            _lib.check(lib.pemp_conv2d_padv_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift),
+                                                     _p(residual), _p(pad_value), _stream()), "pemp_conv2d_padv_nhwc_f32")
 
     if tile == 0:
         key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, p.stem, n, h, w)
@@ -159,6 +169,23 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
                 tile = DEFAULT_TILE
     launch(tile)
     return out
+
+
+def fold_input_affine(p, s, t):
+    """Fold a per-input-channel affine x -> s*x + t that sits IN FRONT of the (zero-padded) conv ``p`` into the conv
+    itself (ASPPV2: BatchNorm before the dilated convs, networks/backbones.py:330-357).  Returns (ConvParams, pad_value):
+    conv_W(s*x + t, pad 0) = conv_{W*s}(x, pad -t/s) + sum_taps W t, so out-of-image taps must read -t/s -- the value
+    that is 0 in the affine's output space.  Needs s != 0 (returns None otherwise) and no output scale on ``p``."""
+    if p.stem or p.scale is not None or bool((s == 0).any()) or not bool(torch.isfinite(t / s).all()):
+        return None
+    taps = p.kh * p.kw
+    w = p.w[:, :taps * p.cin].view(p.cout, taps, p.cin)
+    shift = (w.double() * t.double().view(1, 1, -1)).sum(dim=(1, 2)).float()
+    if p.shift is not None:
+        shift = shift + p.shift
+    wf = (w * s.view(1, 1, -1)).reshape(p.cout, taps * p.cin).contiguous()
+    q = ConvParams(wf, None, shift.contiguous(), p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, p.kpad, False, p.relu)
+    return q, (-t / s).contiguous()
 
 
 def pack_input(img_nchw, prior=None, out=None):

@@ -88,6 +88,39 @@ def test_conv2d_channel_slices_and_per_image_shift(hip_lib, dev):
     assert torch.allclose(got[..., 64:192].permute(0, 3, 1, 2), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("Cin,Cout,k,dil,HW", [(64, 64, 3, 2, 13), (64, 128, 3, 6, 19), (256, 256, 3, 18, 51), (64, 64, 1, 1, 9)])
+def test_conv2d_pad_value_folds_a_leading_batchnorm(hip_lib, dev, Cin, Cout, k, dil, HW):
+    """ASPPV2 (networks/backbones.py:330-357): BN -> conv with the BN OUTPUT zero-padded.  The folded conv reads
+    -t/s at out-of-image taps; every kernel variant agrees bit for bit."""
+    from pemp_amd import ops, _lib
+    N = 2
+    x = _rand(N, Cin, HW, HW, seed=1)
+    w = _rand(Cout, Cin, k, k, seed=2) * (1.0 / (Cin * k * k) ** 0.5)
+    b = _rand(Cout, seed=3)
+    s = _rand(Cin, seed=4, lo=0.5, hi=1.5) * torch.where(_rand(Cin, seed=5) > 0, 1.0, -1.0)
+    t = _rand(Cin, seed=6)
+    pad = dil if k == 3 else 0
+    ref = F.relu(F.conv2d(x * s[None, :, None, None] + t[None, :, None, None], w, b, 1, pad, dil))
+    packed, kpad = ops.pack_conv_weight(w.to(dev))
+    prm = ops.ConvParams(packed, None, b.to(dev), Cin, Cout, k, k, 1, pad, dil, kpad, False, True)
+    q, padv = ops.fold_input_affine(prm, s.to(dev), t.to(dev))
+    xd = _nhwc(x).to(dev)
+    tol = 3e-5 * (Cin * k * k / 64) ** 0.5
+    outs = []
+    for tile in (3, 2, 13, 12, 15) + ((11, 14, 16) if Cout % 128 == 0 else ()) + ((17,) if Cout % 256 == 0 else ()):
+        y = ops.conv2d(xd, q, tile=tile, pad_value=padv if k > 1 else None)
+        outs.append(y)
+        assert ((_nchw(y.cpu()) - ref).abs() / (1 + ref.abs())).max().item() < tol, tile
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    if k > 1:       # zero padding is NOT the same thing (the border differs), and 1x1 convs reject a pad value
+        y0 = ops.conv2d(xd, q, tile=3)
+        assert not torch.allclose(_nchw(y0.cpu()), ref, rtol=1e-3, atol=1e-3)
+    else:
+        with pytest.raises(_lib.PempHipError, match="multi-tap"):
+            ops.conv2d(xd, q, tile=3, pad_value=padv)
+    assert ops.fold_input_affine(prm, torch.zeros(Cin, device=dev), t.to(dev)) is None        # s == 0: no fold
+
+
 @pytest.mark.parametrize("cin,k,s,p,H", [(3, 7, 2, 3, 97), (3, 3, 1, 1, 33), (4, 7, 2, 3, 50)])
 @pytest.mark.parametrize("tile", [0, 2, 3, 12, 13, 15])
 def test_conv2d_stem4(hip_lib, dev, cin, k, s, p, H, tile):
