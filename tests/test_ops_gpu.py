@@ -282,3 +282,35 @@ def test_cm_reduce(hip_lib, dev):
         assert torch.equal(stat.cpu()[:, 1], masked.max(-1)[0])
     only = ops.cm_reduce(None, mask[:, 0].to(dev), 2)[0]
     assert torch.equal(only.cpu(), F.max_pool2d(mask, 3, 2, 1)[:, 0])
+
+
+@pytest.mark.parametrize("N,C,h,w", [(3, 64, 25, 25), (2, 256, 13, 17), (5, 512, 7, 9), (2, 6, 11, 5)])   # C = 6: scalar kernels
+def test_cm_statistics_and_their_adjoint(hip_lib, dev, N, C, h, w):
+    """ResNetCM.comm statistics (backbones.py:208-216) and the gradient loss.backward() sends through them: masked mean
+    and max per (image, channel); the max gradient goes to the FIRST maximal pixel (quantised inputs make ties)."""
+    from pemp_amd import ops, train_ops as T
+    mask = (_rand(N, 1, h, w, seed=1) > 0.3).float()
+    x = ((_rand(N, C, h, w, seed=2) * 3).round() / 3).requires_grad_()
+    mo = F.max_pool2d(mask, 3, 1, 1)
+    masked = (x * mo).view(N, C, -1)
+    mean, mx = masked.mean(-1), masked.max(-1)[0]
+    xd = _nhwc(x.detach()).to(dev)
+    got_m, stat = ops.cm_reduce(xd, mask[:, 0].to(dev), 1)
+    assert torch.equal(got_m.cpu(), mo[:, 0])
+    assert torch.allclose(stat.cpu()[:, 0], mean, rtol=1e-5, atol=1e-6) and torch.equal(stat.cpu()[:, 1], mx.detach())
+    dstat = _rand(N, 2, C, seed=3)
+    (mean * dstat[:, 0]).sum().backward(retain_graph=True)
+    gmean = x.grad.clone()
+    x.grad = None
+    base = _rand(N, h, w, C, seed=4)
+    dx = base.clone().to(dev)
+    T.cm_bwd_add(xd, got_m, dstat.to(dev), dx)
+    got = dx.cpu() - base
+    # mean part everywhere + dmax at the first maximal pixel of x*mask (torch's CPU max picks that one too)
+    first = masked.detach().argmax(-1)                                  # [N,C]
+    want = _nhwc(gmean).clone()
+    flat = want.view(N, h * w, C)
+    mflat = mo.view(N, h * w)
+    for n in range(N):
+        flat[n, first[n], torch.arange(C)] += mflat[n, first[n]] * dstat[n, 1]
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (got - want).abs().max()
