@@ -190,6 +190,13 @@ int pemp_cm_linear_bwd_f32(const float* dfeat_img, const int32_t* group, const f
  * max gradient (torch.max semantics on the host).  Accumulates into dx [N][HW][ldd].              */
 int pemp_cm_bwd_add_f32(const float* x, int ldx, const float* mask, const float* dstat, float* dx, int ldd,
                         int N, int HW, int C, void* stream);
+/* Training forms: pemp_cm_reduce_arg_f32 also records argmax [N][C] (int32: the first maximal pixel of x*mask per
+ * image and channel; NULL = pemp_cm_reduce_f32), and pemp_cm_bwd_add_arg_f32 applies the same gradient from that
+ * record as one element-wise pass (no second reduction over x).  C % 4 == 0.                                    */
+int pemp_cm_reduce_arg_f32(const float* x, int ldx, const float* mask_in, float* mask_out, float* stat,
+                           int32_t* argmax, int N, int Hm, int Wm, int Hx, int Wx, int C, int stride, void* stream);
+int pemp_cm_bwd_add_arg_f32(const float* mask, const float* dstat, const int32_t* argmax, float* dx, int ldd,
+                            int N, int HW, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training path (Trainer.train_step, entry/pemp_stage1.py:57-65; model.train() at

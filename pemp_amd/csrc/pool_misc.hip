@@ -290,28 +290,44 @@ __global__ __launch_bounds__(256) void cm_bwd_kernel(const float* __restrict__ x
 // (image, 64 channels), 1024 threads = 64 pixel lanes x 16 float4 channel lanes, so a wave reads 4 pixels x 256
 // contiguous bytes per load instead of 64 scalars (the scalar kernels above ran at 0.4 TB/s: 0.76 ms per call at 48
 // images).  Fixed order: lane-strided partials, then a tree over the 64 pixel lanes -> deterministic.
+// ARG: also record the index of the FIRST maximal pixel per (image, channel) (training: the backward pass then is a
+// plain element-wise kernel, cm_bwd_arg_kernel).
+template <bool ARG>
 __global__ __launch_bounds__(1024) void cm_stat4_kernel(const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ mask, float* __restrict__ stat,
-                                                        int HW, int C) {
+                                                        int* __restrict__ argmax, int HW, int C) {
     __shared__ float4 rs[64][16], rm[64][16];
+    __shared__ int4 ri[ARG ? 64 : 1][16];
     const int n = blockIdx.y;
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + cl * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     if (c < C) {
         const float* b = x + (long long)n * HW * ldx + c;
         const float* mk = mask + (long long)n * HW;
         for (int i = pl; i < HW; i += 64) {
             const float4 v4 = *(const float4*)(b + (long long)i * ldx);
             const float k = mk[i];
-            const float4 v = make_float4(v4.x * k, v4.y * k, v4.z * k, v4.w * k);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            const float v[4] = {v4.x * k, v4.y * k, v4.z * k, v4.w * k};
+            s.x += v[0]; s.y += v[1]; s.z += v[2]; s.w += v[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ARG) {
+                    if (v[e] > mx[e]) {
+                        mx[e] = v[e];
+                        arg[e] = i;
+                    }
+                } else {
+                    mx[e] = fmaxf(mx[e], v[e]);
+                }
+            }
         }
     }
     rs[pl][cl] = s;
-    rm[pl][cl] = m;
+    rm[pl][cl] = make_float4(mx[0], mx[1], mx[2], mx[3]);
+    if (ARG) ri[pl][cl] = make_int4(arg[0], arg[1], arg[2], arg[3]);
     __syncthreads();
     for (int o = 32; o > 0; o >>= 1) {
         if (pl < o) {
@@ -319,7 +335,16 @@ __global__ __launch_bounds__(1024) void cm_stat4_kernel(const float* __restrict_
             a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
             rs[pl][cl] = a;
             float4 u = rm[pl][cl], w2 = rm[pl + o][cl];
-            u.x = fmaxf(u.x, w2.x); u.y = fmaxf(u.y, w2.y); u.z = fmaxf(u.z, w2.z); u.w = fmaxf(u.w, w2.w);
+            if (ARG) {                         // first (smallest-index) maximum wins, as torch.max on the CPU
+                int4 iu = ri[pl][cl], iw = ri[pl + o][cl];
+                if (w2.x > u.x || (w2.x == u.x && iw.x < iu.x)) { u.x = w2.x; iu.x = iw.x; }
+                if (w2.y > u.y || (w2.y == u.y && iw.y < iu.y)) { u.y = w2.y; iu.y = iw.y; }
+                if (w2.z > u.z || (w2.z == u.z && iw.z < iu.z)) { u.z = w2.z; iu.z = iw.z; }
+                if (w2.w > u.w || (w2.w == u.w && iw.w < iu.w)) { u.w = w2.w; iu.w = iw.w; }
+                ri[pl][cl] = iu;
+            } else {
+                u.x = fmaxf(u.x, w2.x); u.y = fmaxf(u.y, w2.y); u.z = fmaxf(u.z, w2.z); u.w = fmaxf(u.w, w2.w);
+            }
             rm[pl][cl] = u;
         }
         __syncthreads();
@@ -329,6 +354,31 @@ __global__ __launch_bounds__(1024) void cm_stat4_kernel(const float* __restrict_
         const float hw = (float)HW;
         *(float4*)(stat + ((long long)n * 2 + 0) * C + c) = make_float4(t.x / hw, t.y / hw, t.z / hw, t.w / hw);
         *(float4*)(stat + ((long long)n * 2 + 1) * C + c) = rm[0][cl];
+        if (ARG) *(int4*)(argmax + (long long)n * C + c) = ri[0][cl];
+    }
+}
+
+// dx[n][i][c] += mask[n][i] * (dmean[n][c] / HW + [i == argmax[n][c]] * dmax[n][c]), one thread per (pixel, 4 channels)
+__global__ void cm_bwd_arg_kernel(const float* __restrict__ mask, const float* __restrict__ dstat,
+                                  const int* __restrict__ argmax, float* __restrict__ dx, int ldd, int N, int HW, int C4) {
+    const long long total = (long long)N * HW * C4;
+    const float hw = (float)HW;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C4) * 4;
+        const long long pix = t / C4;
+        const int i = (int)(pix % HW), n = (int)(pix / HW);
+        const int C = C4 * 4;
+        const float k = mask[pix];
+        const float4 g0 = *(const float4*)(dstat + ((long long)n * 2 + 0) * C + c);
+        const float4 gx = *(const float4*)(dstat + ((long long)n * 2 + 1) * C + c);
+        const int4 am = *(const int4*)(argmax + (long long)n * C + c);
+        float* d = dx + pix * ldd + c;
+        float4 v = *(float4*)d;
+        v.x += k * (g0.x / hw + (i == am.x ? gx.x : 0.f));
+        v.y += k * (g0.y / hw + (i == am.y ? gx.y : 0.f));
+        v.z += k * (g0.z / hw + (i == am.z ? gx.z : 0.f));
+        v.w += k * (g0.w / hw + (i == am.w ? gx.w : 0.f));
+        *(float4*)d = v;
     }
 }
 
@@ -488,7 +538,15 @@ extern "C" int pemp_channel_affine_multi_f32(const float* x, int ldx, int M, int
 
 extern "C" int pemp_cm_reduce_f32(const float* x, int ldx, const float* mask_in, float* mask_out, float* stat, int N,
                                   int Hm, int Wm, int Hx, int Wx, int C, int stride, void* stream) {
+    return pemp_cm_reduce_arg_f32(x, ldx, mask_in, mask_out, stat, nullptr, N, Hm, Wm, Hx, Wx, C, stride, stream);
+}
+
+extern "C" int pemp_cm_reduce_arg_f32(const float* x, int ldx, const float* mask_in, float* mask_out, float* stat,
+                                      int32_t* argmax, int N, int Hm, int Wm, int Hx, int Wx, int C, int stride,
+                                      void* stream) {
     PEMP_REQUIRE(mask_in && mask_out && (stat || !x), "cm_reduce: null pointer");
+    PEMP_REQUIRE(!argmax || (x && C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)stat | (uintptr_t)argmax) & 15) == 0),
+                 "cm_reduce: argmax needs x, C and ldx multiples of 4 and 16-byte aligned x / stat / argmax");
     PEMP_REQUIRE(N > 0 && (!x || (C > 0 && ldx >= C)) && (stride == 1 || stride == 2), "cm_reduce: bad dims");
     PEMP_REQUIRE(Hx == (Hm + 2 - 3) / stride + 1 && Wx == (Wm + 2 - 3) / stride + 1,
                  "cm_reduce: pooled mask (%d,%d)->(%d,%d) does not match feature size", Hm, Wm, Hx, Wx);
@@ -497,13 +555,27 @@ extern "C" int pemp_cm_reduce_f32(const float* x, int ldx, const float* mask_in,
                        mask_out, N, Hm, Wm, Hx, Wx, stride);
     int e = launch_status("cm_reduce/mask_pool");
     if (e || !x) return e;
-    if (C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)stat & 15) == 0)
-        hipLaunchKernelGGL(cm_stat4_kernel, dim3(cdiv(C, 64), N), dim3(1024), 0, (hipStream_t)stream, x, ldx, mask_out,
-                           stat, Hx * Wx, C);
+    if (argmax)
+        hipLaunchKernelGGL(cm_stat4_kernel<true>, dim3(cdiv(C, 64), N), dim3(1024), 0, (hipStream_t)stream, x, ldx, mask_out,
+                           stat, argmax, Hx * Wx, C);
+    else if (C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)stat & 15) == 0)
+        hipLaunchKernelGGL(cm_stat4_kernel<false>, dim3(cdiv(C, 64), N), dim3(1024), 0, (hipStream_t)stream, x, ldx, mask_out,
+                           stat, (int*)nullptr, Hx * Wx, C);
     else
         hipLaunchKernelGGL(cm_stat_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, (hipStream_t)stream, x, ldx, mask_out, stat,
                            Hx * Wx, C);
     return launch_status("cm_reduce/stat");
+}
+
+extern "C" int pemp_cm_bwd_add_arg_f32(const float* mask, const float* dstat, const int32_t* argmax, float* dx, int ldd,
+                                       int N, int HW, int C, void* stream) {
+    PEMP_REQUIRE(mask && dstat && argmax && dx, "cm_bwd_add_arg: null pointer");
+    PEMP_REQUIRE(N > 0 && HW > 0 && C > 0 && C % 4 == 0 && ldd >= C && ldd % 4 == 0, "cm_bwd_add_arg: bad dims");
+    PEMP_REQUIRE((((uintptr_t)dstat | (uintptr_t)argmax | (uintptr_t)dx) & 15) == 0, "cm_bwd_add_arg: 16-byte alignment");
+    const long long total = (long long)N * HW * (C / 4);
+    hipLaunchKernelGGL(cm_bwd_arg_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, mask, dstat, argmax,
+                       dx, ldd, N, HW, C / 4);
+    return launch_status("cm_bwd_add_arg");
 }
 
 extern "C" int pemp_cm_bwd_add_f32(const float* x, int ldx, const float* mask, const float* dstat, float* dx, int ldd,

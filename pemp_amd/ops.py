@@ -381,9 +381,10 @@ def eval_tail(pred, target, want_logits=False, ws_cache=None, out_hw=None, weigh
     return am, stats, logits
 
 
-def cm_reduce(x, mask_in, stride):
+def cm_reduce(x, mask_in, stride, want_argmax=False):
     """ResNetCM.comm statistics: x NHWC [N,h,w,C] (or None: pool the mask only); mask_in [N,Hm,Wm]
-    -> (mask_out [N,h,w], stat [N,2,C] | None)."""
+    -> (mask_out [N,h,w], stat [N,2,C] | None) (+ argmax int32 [N,C] with ``want_argmax``: the first maximal pixel,
+    which train_ops.cm_bwd_add can use instead of searching for it again)."""
     lib = _lib.load()
     _chk_dev(x, mask_in)
     hm, wm = mask_in.shape[-2:]
@@ -395,6 +396,11 @@ def cm_reduce(x, mask_in, stride):
         n, h, w, c = x.shape
         stat = torch.empty((n, 2, c), dtype=torch.float32, device=x.device)
     mask_out = torch.empty((n, h, w), dtype=torch.float32, device=mask_in.device)
+    if want_argmax:
+        arg = torch.empty((n, c), dtype=torch.int32, device=x.device)
+        _lib.check(lib.pemp_cm_reduce_arg_f32(_p(x), ldx, _p(mask_in.contiguous()), _p(mask_out), _p(stat), _p(arg), n, hm, wm,
+                                              h, w, c, stride, _stream()), "cm_reduce_arg")
+        return mask_out, stat, arg
     _lib.check(lib.pemp_cm_reduce_f32(_p(x), ldx, _p(mask_in.contiguous()), _p(mask_out), _p(stat), n, hm, wm, h, w, c,
                                       stride, _stream()), "cm_reduce")
     return mask_out, stat

@@ -277,15 +277,22 @@ def cm_linear_bwd(dfeat_img, group, agg, lin_w, dlin_w, dlin_b):
     return dstat
 
 
-def cm_bwd_add(x, mask, dstat, dx):
+def cm_bwd_add(x, mask, dstat, dx, argmax=None):
     """Backward of ``ops.cm_reduce``'s statistics: dx += mask * (dmean/HW + onehot(argmax) * dmax).
-    x, dx: NHWC [N,h,w,C]; mask: the pooled mask cm_reduce returned [N,h,w]; dstat [N,2,C]."""
+    x, dx: NHWC [N,h,w,C]; mask: the pooled mask cm_reduce returned [N,h,w]; dstat [N,2,C]; ``argmax`` int32 [N,C]
+    from ``cm_reduce(want_argmax=True)`` skips the search for the maximal pixel."""
     lib = _lib.load()
-    _chk_dev(x, mask, dstat, dx)
+    _chk_dev(x, mask, dstat, dx, argmax)
     from .ops import _nhwc
     n, h, w, c = x.shape
     if tuple(dx.shape) != (n, h, w, c) or tuple(dstat.shape) != (n, 2, c) or mask.numel() != n * h * w:
         raise ValueError("cm_bwd_add: shape mismatch")
+    if argmax is not None:
+        if argmax.dtype != torch.int32 or tuple(argmax.shape) != (n, c) or not argmax.is_contiguous():
+            raise ValueError("cm_bwd_add: argmax must be contiguous int32 [N,C]")
+        _lib.check(lib.pemp_cm_bwd_add_arg_f32(_p(mask.contiguous()), _p(dstat.contiguous()), _p(argmax), _p(dx),
+                                               _nhwc(dx, "dx"), n, h * w, c, _stream()), "cm_bwd_add_arg")
+        return dx
     _lib.check(lib.pemp_cm_bwd_add_f32(_p(x), _nhwc(x, "x"), _p(mask.contiguous()), _p(dstat.contiguous()), _p(dx),
                                        _nhwc(dx, "dx"), n, h * w, c, _stream()), "cm_bwd_add")
     return dx

@@ -102,10 +102,10 @@ class Stage2TrainEngine(Stage1TrainEngine):
             if bi in self.stage_first:
                 si = self.stage_first.index(bi)
                 lin = self.lin[si]
-                mask, stat = ops.cm_reduce(x, mask, _CM_STRIDES[si])
+                mask, stat, arg = ops.cm_reduce(x, mask, _CM_STRIDES[si], want_argmax=True)
                 agg, feat = ops.cm_linear(stat, group, lin.weight.data, lin.bias.data, n_groups)   # episode mean, Linear(2C->2)
                 c1, ds = b["c1"].split(), b["ds"][0].split()
-                tape["cm"].append(dict(x=x, mask=mask, agg=agg, feat=feat))
+                tape["cm"].append(dict(x=x, mask=mask, agg=agg, feat=feat, arg=arg))
                 x, rec = self._block_fwd(x, b, bias_c1=ops.cm_bias(feat, group, c1.wext),
                                          bias_ds=ops.cm_bias(feat, group, ds.wext))
             else:
@@ -130,7 +130,7 @@ class Stage2TrainEngine(Stage1TrainEngine):
             b["c1"].ext_backward(ops.global_avgpool(dz1) * hw_out, cm["feat"], group, dfi, accumulate=False)
             b["ds"][0].ext_backward(ops.global_avgpool(dzd) * hw_out, cm["feat"], group, dfi, accumulate=True)
             dstat = T.cm_linear_bwd(dfi, group, cm["agg"], lin.weight.data, lin.weight.grad, lin.bias.grad)
-            T.cm_bwd_add(cm["x"], cm["mask"], dstat.view(n, 2, c), dx)         # [N,2,C]: d(mean), d(max) per image
+            T.cm_bwd_add(cm["x"], cm["mask"], dstat.view(n, 2, c), dx, argmax=cm["arg"])   # [N,2,C]: d(mean), d(max) per image
         dy = T.maxpool_idx_bwd(tp["pool_idx"], dx, tp["pool_in"].shape[1:3], 3, 2, 1)
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
 

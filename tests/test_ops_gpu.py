@@ -314,3 +314,9 @@ def test_cm_statistics_and_their_adjoint(hip_lib, dev, N, C, h, w):
     for n in range(N):
         flat[n, first[n], torch.arange(C)] += mflat[n, first[n]] * dstat[n, 1]
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (got - want).abs().max()
+    if C % 4 == 0:      # training form: the forward records the winners, the backward is element-wise -- same bits
+        m2, stat2, arg = ops.cm_reduce(xd, mask[:, 0].to(dev), 1, want_argmax=True)
+        assert torch.equal(m2, got_m) and torch.equal(stat2, stat) and torch.equal(arg.cpu().long(), first)
+        dx2 = base.clone().to(dev)
+        T.cm_bwd_add(xd, got_m, dstat.to(dev), dx2, argmax=arg)
+        assert torch.equal(dx2, dx)
