@@ -133,17 +133,28 @@ __global__ void adjoint_mask_kernel(const float* __restrict__ mask, float* __res
     A[((size_t)bs * 2 + g) * n + i] = acc;
 }
 
-// exact full-resolution mask sums (integers in fp32), one block per (bs, g)
-__global__ __launch_bounds__(256) void mask_sum_kernel(const float* __restrict__ mask, float* __restrict__ out,
-                                                       int HW) {
-    __shared__ float red[4];
+// exact full-resolution mask sums (integers in fp32, so the order is immaterial), one 1024-thread block per (bs, g)
+__global__ __launch_bounds__(1024) void mask_sum_kernel(const float* __restrict__ mask, float* __restrict__ out,
+                                                        int HW) {
+    __shared__ float red[16];
     const float* m = mask + (size_t)blockIdx.x * HW;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) s += m[i];
-    s = wave_sum(s);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 3072 < HW; i += 4096) {          // four independent loads in flight per thread
+        s0 += m[i];
+        s1 += m[i + 1024];
+        s2 += m[i + 2048];
+        s3 += m[i + 3072];
+    }
+    for (; i < HW; i += 1024) s0 += m[i];
+    float s = wave_sum((s0 + s1) + (s2 + s3));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        out[blockIdx.x] = t;
+    }
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -762,7 +773,7 @@ static int pooled_protos(int mode, const float* feat, int ldf, const float* mask
         hipLaunchKernelGGL(mask_assign_kernel, dim3(cdiv(n, 256), BS), dim3(256), 0, st, mask, A, n, h, w, H, W);
     } else {
         hipLaunchKernelGGL(adjoint_mask_kernel, dim3(cdiv(2 * n, 256), BS), dim3(256), 0, st, mask, A, n, h, w, H, W);
-        hipLaunchKernelGGL(mask_sum_kernel, dim3(BS * 2), dim3(256), 0, st, mask, msum, H * W);
+        hipLaunchKernelGGL(mask_sum_kernel, dim3(BS * 2), dim3(1024), 0, st, mask, msum, H * W);
     }
     int e = launch_status("protos/assign");
     if (e) return e;
