@@ -82,6 +82,61 @@ def _grad_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pemp_amd.train_engine import GradBuckets
+        n = 10000
+        g = torch.zeros(n)
+        bk = GradBuckets(g, cuts=[100, 3000, 6000, 6100, 9000], min_bytes=4000)      # 1000-float minimum
+        out = [list(bk.buckets)]
+        for step in range(2):                              # two steps: the launch state resets in finish()
+            g.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1) + step)
+            bk.enabled = True
+            bk.ready_from(9500)                            # nothing lies wholly above 9500
+            launched = [bk.next]
+            bk.ready_from(9000)                            # the backward pass reports progress from the end ...
+            bk.ready_from(6000)
+            launched.append(bk.next)
+            scale = bk.finish()                            # ... and finish() sends the rest and waits
+            out.append((launched, scale, g.numpy().copy()))
+        bk.enabled = False
+        g.fill_(1.0)
+        bk.ready_from(0)                                   # hooks of a trainer that never calls finish(): no-ops
+        out.append((bk.next, float(g.sum())))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_gradient_buckets():
+    """GradBuckets: buckets formed from the end of the flat buffer, each all-reduced exactly once, in the same order
+    on every rank, some during "backward" (ready_from) and the rest in finish()."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = np.arange(10000, dtype=np.float32)
+    for r in (0, 1):
+        buckets, s0, s1, off = got[r]
+        assert buckets == [(9000, 10000), (6100, 9000), (3000, 6100), (0, 3000)]      # 6000 / 100 would make tiny buckets
+        for step, (launched, scale, g) in enumerate((s0, s1)):
+            assert launched == [0, 2] and scale == 0.5
+            assert np.array_equal(g, base * 3 + 2 * step)                              # every element summed exactly once
+        assert off == (0, 10000.0)
+
+
 def test_two_rank_gradient_bucket_allreduce_and_broadcast():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -278,3 +278,42 @@ def test_five_shot_training_steps_stage1_and_stage2(hip_lib, dev):
     tr2 = Stage2Trainer(net1.eval(), net2, device=dev, lr=2e-3, drop_rate2=0.0)
     l2 = [tr2.train_step(sup, msk, qry, gt).item() for _ in range(6)]
     assert all(np.isfinite(l2)) and min(l2[3:]) < l2[0], l2
+
+
+def test_overlapped_gradient_buckets_on_one_rank_match_the_plain_step(hip_lib, dev, monkeypatch):
+    """The bucketed all-reduce issued DURING backward (RCCL under the side stream, see GradBuckets) leaves the same
+    weights as the plain step.  One rank: the collectives are identities, but the event / stream choreography, the
+    bucket bookkeeping and finish() are the ones an 8-GPU job runs."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    except Exception as e:                                   # no RCCL in this environment: nothing to exercise
+        pytest.skip(f"RCCL process group unavailable: {e}")
+    try:
+        sup, msk, qry, gt = _batch(dev)
+        weights, launched = [], []
+        for force in (False, True):
+            if force:
+                monkeypatch.setenv("PEMP_FORCE_BUCKETS", "1")
+            tr, net = _trainer(dev, lr=2e-3)
+            bk = tr.eng.buckets
+            assert len(bk.buckets) >= 3 and bk.buckets[0][1] == tr.eng.flat.n and bk.buckets[-1][0] == 0
+            seen = []
+            orig = bk._launch
+            bk._launch = lambda lo, hi, orig=orig, seen=seen: (seen.append((lo, hi)), orig(lo, hi))[1]
+            losses = [tr.train_step(sup, msk, qry, gt) for _ in range(3)]
+            torch.cuda.synchronize()
+            assert all(torch.isfinite(l) for l in losses)
+            launched.append(seen)
+            weights.append(tr.eng.flat.data.clone())
+        assert launched[0] == [] and launched[1] == list(tr.eng.buckets.buckets) * 3     # every bucket once per step
+        assert torch.equal(weights[0], weights[1])
+    finally:
+        dist.destroy_process_group()
