@@ -136,6 +136,11 @@ int pemp_cosine_proto_max_f32(const float* qry, int ldf, const float* protos, fl
                               uint8_t* resp, int B, int n, int c, int p, float dist_scalar,
                               void* stream);
 
+/* PANet's alignment branch (networks/panet.py:168-171): masks [B][2][n] from a low-resolution prediction
+ * pred [B][2][n]:  masks[b][0] = [argmax == 1] (foreground), masks[b][1] = [argmax == 0]; channel 0 wins ties
+ * (torch.argmax).  They feed pemp_masked_avg_pool_f32(full_res = 0) with the QUERY features as "support".    */
+int pemp_argmax_masks_f32(const float* pred, float* masks, int B, int n, void* stream);
+
 /* F.interpolate(pred, (Ho,Wo), "bilinear", align_corners=True) -> logits [B][2][Ho][Wo]
  * (networks/pemp_stage1.py:157,162; baseline.py:117).                                        */
 int pemp_upsample_bilinear_ac_f32(const float* pred, float* out, int B, int C, int h, int w,

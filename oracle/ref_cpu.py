@@ -268,6 +268,39 @@ def baseline_forward(sd, sup_img, sup_mask, qry_img, out_shape=None, backbone="v
                          mode="bilinear", align_corners=True)
 
 
+def panet_align_loss(qry_fts, pred, sup_fts, sup_mask_fg, Q, dist_scalar=20):
+    """PANet.alignLoss (networks/panet.py:149-190): prototypes from the QUERY features under the predicted masks,
+    matched against the SUPPORT features, cross-entropy against the support foreground mask."""
+    B = qry_fts.size(0) // Q
+    c = qry_fts.size(1)
+    pm = pred.argmax(dim=1, keepdim=True)
+    mfg, mbg = (pm == 1).float(), (pm == 0).float()
+    fgp = torch.sum(qry_fts * mfg, dim=(2, 3)) / (mfg.sum((2, 3)) + 1e-5)
+    bgp = torch.sum(qry_fts * mbg, dim=(2, 3)) / (mbg.sum((2, 3)) + 1e-5)
+    fgp = fgp.view(B, Q, c).mean(dim=1)
+    bgp = bgp.view(B, Q, c).mean(dim=1)
+    S = sup_fts.shape[0] // B
+    if S != 1:                                              # compute_similarity's expansion (panet.py:135-139)
+        fgp = fgp.view(B, 1, c).expand(-1, S, -1).reshape(B * S, c)
+        bgp = bgp.view(B, 1, c).expand(-1, S, -1).reshape(B * S, c)
+    ps = compute_similarity(fgp, bgp, sup_fts, dist_scalar)
+    out = F.interpolate(ps, sup_mask_fg.shape[-2:], mode="bilinear", align_corners=True)
+    return F.cross_entropy(out, sup_mask_fg.squeeze(dim=1).long())
+
+
+def panet_forward(sd, sup_img, sup_mask, qry_img, out_shape=None, backbone="vgg16", dist_scalar=20):
+    """PANet.forward (networks/panet.py:68-118): the Baseline's forward plus the alignment loss -> (logits, align_loss)."""
+    B, S, C, H, W = sup_img.shape
+    Q = qry_img.shape[1]
+    pred, f = baseline_forward(sd, sup_img, sup_mask, qry_img, out_shape, backbone, dist_scalar, ret_lowres=True)
+    _, _, c, h, w = f.shape
+    sup_fts = f[:, :S].reshape(B * S, c, h, w)
+    qry_fts = f[:, S:].reshape(B * Q, c, h, w)
+    mfg = sup_mask.view(B * S, 2, H, W)[:, :1]
+    out = F.interpolate(pred, out_shape if out_shape is not None else (H, W), mode="bilinear", align_corners=True)
+    return out, panet_align_loss(qry_fts, pred, sup_fts, mfg, Q, dist_scalar)
+
+
 def stage2_forward(sd, sup_img, sup_mask, qry_img, qry_prior, out_shape=None, ret_ind=False,
                    protos2=3, dist_scalar=20, ret_lowres=False):
     """PEMPStage2.forward, ResNet-50+CM (networks/pemp_stage2.py:104-162)."""

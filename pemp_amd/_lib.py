@@ -58,6 +58,7 @@ SYMBOLS = {
     "pemp_eval_tail_workspace_bytes": (c_size, [c_int] * 3),
     "pemp_eval_tail_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size] + [c_int] * 5 + [c_fp]),
     "pemp_cm_reduce_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp]),
+    "pemp_argmax_masks_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
     "pemp_cm_reduce_arg_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp]),
     "pemp_cm_bwd_add_arg_f32": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "pemp_cm_linear_f32": (c_int, [c_fp] * 6 + [c_int] * 3 + [c_fp]),

@@ -27,6 +27,9 @@ class TrainBridge:
         elif kind == "baseline":
             from .train_baseline import BaselineTrainer
             self.trainer = BaselineTrainer(model, device=device)
+        elif kind == "panet":
+            from .train_baseline import PANetTrainer
+            self.trainer = PANetTrainer(model, device=device)
         elif kind == "stage2":
             from .train_stage2 import Stage2Trainer
             self.trainer = Stage2Trainer(None, model, device=device)
@@ -40,6 +43,7 @@ class TrainBridge:
                 raise RuntimeError("pemp_amd: inputs must live on the GPU; there is no CPU fallback")
         if out_shape is None:
             out_shape = tuple(sup_img.shape[-2:])
+        # kind "panet": the node has two differentiable outputs, (logits, align_loss) (networks/panet.py:118)
         return _TrainStep.apply(self, self.anchor, sup_img, sup_mask, qry_img, qry_prior, tuple(int(v) for v in out_shape))
 
 
@@ -63,11 +67,15 @@ class _TrainStep(torch.autograd.Function):
             key = ("map", B, S, sup.shape[1], sup.shape[2], sup.shape[3])
             pro = ops.masked_avg_pool(sup, msk, B, S, full_res=tr.map_full_res, ws_cache=ws)
         pred = ops.cosine_proto_max(qry, pro, tr.dist_scalar)
-        ctx.bridge, ctx.state = bridge, (feat, msk, pro, key, B, S)
+        ctx.bridge, ctx.state, ctx.align = bridge, (feat, msk, pro, key, B, S), None
+        if bridge.kind == "panet":
+            from .networks.panet import align_forward
+            ctx.align = align_forward(feat, pred, sup_mask.float(), B, S, Q, tr.dist_scalar, tr.align_ws)
+            return ops.upsample_bilinear_ac(pred, out_shape), ctx.align["loss"].clone()
         return ops.upsample_bilinear_ac(pred, out_shape)
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, dalign=None):
         tr = ctx.bridge.trainer
         eng, ws, flat = tr.eng, tr.eng.ws, tr.eng.flat
         feat, msk, pro, key, B, S = ctx.state
@@ -83,6 +91,9 @@ class _TrainStep(torch.autograd.Function):
         dctr = T.head_bwd_dlogits(sup, qry, msk, ctr.data if ctr is not None else None, ws[key], pro,
                                   dlogits.float().contiguous(), dfeat, B, S, tr.protos, tr.dist_scalar, ws_cache=ws,
                                   map_full_res=tr.map_full_res)
+        if ctx.align is not None and dalign is not None:      # + dL/d(align_loss) * d(align_loss)/d(features)
+            tr.align_backward(feat, ctx.align, B, S, dalign.float(), dfeat)
+        ctx.align = None
         flat.attach_grads()
         if ctr is not None:
             ctr.grad.copy_(dctr)

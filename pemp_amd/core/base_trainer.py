@@ -69,6 +69,8 @@ class TrainingLoop:
         d = self.cfg["data"]
         mloss, miou, biou = self.evaluator.start_eval_loop(dataset, num_classes, split, self.cfg["te"]["epochs"], None,
                                                            batch=d["test_bs"], dataset_name=d["dataset"])
+        if isinstance(mloss, tuple):                 # PANet's evaluator: (loss, aux_loss) (entry/panet.py:100)
+            mloss = mloss[0]
         miou_m, biou_m = float(np.mean(miou)), float(np.mean(biou))
         best = miou_m > self.best_iou
         if best:
@@ -87,7 +89,8 @@ class TrainingLoop:
             total, calls, t0 = 0.0, 0, time.time()
             losses = []
             for inputs, qry_msk in batches_for_epoch(epoch):
-                losses.append(self.trainer.train_step(*inputs, qry_msk=qry_msk))
+                out = self.trainer.train_step(*inputs, qry_msk=qry_msk)
+                losses.append(out[0] if isinstance(out, tuple) else out)      # PANet: (loss, align_loss)
                 calls += 1
                 self.step_lr()
             total = float(torch.stack([l.reshape(()) for l in losses]).sum().item()) if losses else 0.0

@@ -627,6 +627,17 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float* __restrict__ q
     }
 }
 
+// masks[b][0][i] = [argmax_ch pred[b][.][i] == 1], masks[b][1][i] = [argmax == 0]  (channel 0 wins ties, as torch.argmax):
+// the query masks of PANet's alignment branch (networks/panet.py:169-171)
+__global__ void argmax_masks_kernel(const float* __restrict__ pred, float* __restrict__ masks, int B, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n) return;
+    const int b = t / n, i = t - b * n;
+    const float fg = pred[((size_t)b * 2 + 1) * n + i] > pred[((size_t)b * 2 + 0) * n + i] ? 1.f : 0.f;
+    masks[((size_t)b * 2 + 0) * n + i] = fg;
+    masks[((size_t)b * 2 + 1) * n + i] = 1.f - fg;
+}
+
 // -----------------------------------------------------------------------------------------------
 __global__ void upsample_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int BC, int h, int w,
                                          int Ho, int Wo) {
@@ -824,6 +835,12 @@ extern "C" int pemp_cosine_proto_max_f32(const float* qry, int ldf, const float*
     hipLaunchKernelGGL(cosine_kernel, dim3(min(cdiv(n, 4), max(1, 4096 / B)), B), dim3(256), 0, (hipStream_t)stream, qry, ldf, protos,
                        pred, resp, n, c, p, dist_scalar);
     return launch_status("cosine");
+}
+
+extern "C" int pemp_argmax_masks_f32(const float* pred, float* masks, int B, int n, void* stream) {
+    PEMP_REQUIRE(pred && masks && B > 0 && n > 0, "argmax_masks: bad arguments");
+    hipLaunchKernelGGL(argmax_masks_kernel, dim3(cdiv(B * n, 256)), dim3(256), 0, (hipStream_t)stream, pred, masks, B, n);
+    return launch_status("argmax_masks");
 }
 
 extern "C" int pemp_upsample_bilinear_ac_f32(const float* pred, float* out, int B, int C, int h, int w, int Ho, int Wo,

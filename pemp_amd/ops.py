@@ -355,6 +355,18 @@ def cedt_weight(target, sigma=5.0, ws_cache=None):
     return out
 
 
+def argmax_masks(pred):
+    """pred [B,2,h,w] -> masks [B,2,h,w] fp32: channel 0 = (argmax == 1), channel 1 = (argmax == 0) (panet.py:169-171)."""
+    lib = _lib.load()
+    _chk_dev(pred)
+    b, c, h, w = pred.shape
+    if c != 2 or not pred.is_contiguous() or pred.dtype != torch.float32:
+        raise ValueError("argmax_masks: pred must be contiguous fp32 [B,2,h,w]")
+    masks = torch.empty_like(pred)
+    _lib.check(lib.pemp_argmax_masks_f32(_p(pred), _p(masks), b, h * w, _stream()), "argmax_masks")
+    return masks
+
+
 def eval_tail(pred, target, want_logits=False, ws_cache=None, out_hw=None, weight=None):
     """pred [B,2,h,w]; target int64 [B,Ho,Wo] (or None with ``out_hw``: argmax only, statistics are zero)
     -> (argmax uint8 [B,Ho,Wo], stats f64 [B,8], logits|None)."""

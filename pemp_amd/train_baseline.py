@@ -95,7 +95,13 @@ class BaselineTrainer(Stage1Trainer):
         self.loss_obj = losses.get({"loss": loss, "sigma": sigma})
 
     def _head_hip(self, feat, sup_mask, qry_msk, B, S, Q):
-        """Full-resolution masked average pooling (adjoint form) -> cosine -> upsample + CE, and its backward."""
+        loss, pred, dfeat = self._main_head(feat, sup_mask, qry_msk, B, S, Q)
+        self.eng.backward(dfeat)
+        return loss, pred
+
+    def _main_head(self, feat, sup_mask, qry_msk, B, S, Q):
+        """Full-resolution masked average pooling (adjoint form) -> cosine -> upsample + CE, and its backward
+        -> (loss, pred, d loss / d features)."""
         if Q != 1:
             raise ValueError("query must be 1")
         eng, ws = self.eng, self.eng.ws
@@ -111,8 +117,7 @@ class BaselineTrainer(Stage1Trainer):
         dfeat = torch.empty_like(feat)
         T.head_bwd(sup, qry, msk, None, ws[("map", B, S, sup.shape[1], sup.shape[2], sup.shape[3])], pro, pred, tgt, stats,
                    dfeat, B, S, 0, self.dist_scalar, ws_cache=ws, weight=wmap, map_full_res=True)
-        eng.backward(dfeat)
-        return loss.float(), pred
+        return loss.float(), pred, dfeat
 
     def forward_backward(self, sup_img, sup_mask, qry_img, qry_msk):
         eng = self.eng
@@ -122,3 +127,51 @@ class BaselineTrainer(Stage1Trainer):
         eng.flat.grad.zero_()
         feat = self.encode(sup_img, sup_mask, qry_img)
         return self._head_hip(feat, sup_mask, qry_msk, B, S, Q)
+
+
+class PANetTrainer(BaselineTrainer):
+    """``train_step`` of entry/panet.py:103-110: ``(loss + loss_coef * align_loss).backward(); optimizer.step()`` (no
+    gradient clipping) on the explicit HIP engines -> (loss, align_loss).  The alignment branch (networks/panet.py:149-190)
+    is the PEMP head with the roles swapped -- the query features are the "support" (pooled under the predicted masks),
+    the support features the "query" -- so its backward is ``pemp_head_bwd_f32`` once more, on swapped operands."""
+
+    def __init__(self, model, loss_coef=1.0, **kw):
+        super().__init__(model, **kw)
+        from .networks.panet import net_ingredient
+        self.dist_scalar = net_ingredient.cfg["dist_scalar"]
+        self.loss_coef = loss_coef
+        self.align_ws = {}
+        self.last_align_loss = None
+
+    def align_backward(self, feat, al, B, S, coef, dfeat):
+        """dfeat += coef * d align_loss / d features (``coef``: python float or 0-dim device tensor)."""
+        sup, qry = feat[:B * S], feat[B * S:]
+        qs, msk = qry, al["qmask"]
+        if S != 1:       # one pseudo-episode per support image: its "support" is a copy of the episode's query features
+            qs, msk = qry.repeat_interleave(S, dim=0), al["qmask"].repeat_interleave(S, dim=0)
+        n, h, w, c = qs.shape
+        pro = ops.masked_avg_pool(qs, msk.contiguous(), n, 1, full_res=False, ws_cache=self.align_ws)   # == al["pro_s"]
+        tmp = torch.empty((2 * n, h, w, c), dtype=torch.float32, device=feat.device)
+        T.head_bwd(qs, sup, msk.contiguous(), None, self.align_ws[("map", n, 1, h, w, c)], pro, al["pred_s"], al["target"],
+                   al["stats"], tmp, n, 1, 0, self.dist_scalar, ws_cache=self.align_ws, map_full_res=False)
+        dq = tmp[:n] if S == 1 else tmp[:n].view(B, S, h, w, c).sum(dim=1)
+        if isinstance(coef, torch.Tensor) or coef != 1.0:
+            dfeat[:B * S].add_(tmp[n:] * coef)
+            dfeat[B * S:].add_(dq * coef)
+        else:
+            dfeat[:B * S].add_(tmp[n:])
+            dfeat[B * S:].add_(dq)
+
+    def _head_hip(self, feat, sup_mask, qry_msk, B, S, Q):
+        from .networks.panet import align_forward
+        loss, pred, dfeat = self._main_head(feat, sup_mask, qry_msk, B, S, Q)
+        al = align_forward(feat, pred, sup_mask, B, S, Q, self.dist_scalar, self.align_ws)
+        if self.loss_coef != 0.0:
+            self.align_backward(feat, al, B, S, float(self.loss_coef), dfeat)
+        self.eng.backward(dfeat)
+        self.last_align_loss = al["loss"]
+        return loss, pred
+
+    def train_step(self, sup_img, sup_mask, qry_img, qry_msk=None):
+        loss = super().train_step(sup_img, sup_mask, qry_img, qry_msk)
+        return loss, self.last_align_loss

@@ -147,6 +147,9 @@ def _episode_case(model, kind, seeds, shot, H, out_hws, extra=None):
                 logits, resp = model(sup, msk, qry, out_shape, ret_ind=True)
             elif kind == "baseline":
                 logits, resp = model(sup, msk, qry, out_shape), None
+            elif kind == "panet":
+                (logits, aux), resp = model(sup, msk, qry, out_shape), None
+                res[f"e{n}_align_loss"] = np.array(float(aux), np.float64)
             elif kind == "stage2":
                 prior = extra["prior"][n]
                 logits, resp = model(sup, msk, qry, prior, out_shape, ret_ind=True)
@@ -266,6 +269,44 @@ def gen_train_step(tmp):
         res["buf__" + k] = sd[k].numpy()
     np.savez_compressed(OUT / "stage1_rn50_trainstep.npz", **res)
     print("wrote train step; loss", float(loss))
+
+
+def gen_panet(tmp, backbone, tag, cases):
+    """G14: PANet (networks/panet.py:68-193) = the Baseline forward + the prototype-alignment loss."""
+    from networks import panet as m
+    cfg = dict(dist_scalar=20, init_channels=3, backbone=backbone, out_channels=512)
+    model = _build(m, "PANet", cfg, (), tmp)
+    _load_wgen(model)
+    _keys_fixture(model, tag)
+    for cname, (seeds, shot, H, hws) in cases.items():
+        np.savez_compressed(OUT / f"{tag}_{cname}.npz", **_episode_case(model, "panet", seeds, shot, H, hws))
+        print("wrote", tag, cname)
+
+
+def gen_train_step_panet(tmp):
+    """G15: losses and gradients of one PANet training step (entry/panet.py:103-110: loss + loss_coef * align_loss)."""
+    from networks import panet as m
+    for backbone, tag in (("vgg16", "panet_vgg16"), ("resnet50", "panet_rn50")):
+        cfg = dict(dist_scalar=20, init_channels=3, backbone=backbone, out_channels=512)
+        model = _build(m, "PANet", cfg, (), tmp)
+        _load_wgen(model)
+        model.train()
+        b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+        logits, aux = model(_t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"]), (97, 97))
+        loss = torch.nn.functional.cross_entropy(logits, _t(b["qry_mask"][:, 0]), ignore_index=255)
+        (loss + aux * 1.0).backward()
+        res = {"loss": np.array(float(loss.detach()), np.float64), "align_loss": np.array(float(aux.detach()), np.float64)}
+        names, norms = [], []
+        for k, p in model.named_parameters():
+            names.append(k)
+            norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+        res["grad_names"], res["grad_norms"] = np.array(names), np.array(norms, np.float64)
+        plist = dict(model.named_parameters())
+        for k in [k for k in plist if plist[k].grad is not None][:2] + list(plist)[-2:]:
+            g = plist[k].grad
+            res["grad__" + k] = g.numpy() if g.numel() <= 40000 else g.reshape(-1)[::37].numpy()
+        np.savez_compressed(OUT / f"{tag}_trainstep.npz", **res)
+        print("wrote", tag, "train step; loss", float(loss), "align", float(aux))
 
 
 def gen_train_step_baseline(tmp):
@@ -416,6 +457,12 @@ def main():
             gen_train_step_stage1_vgg(tmp)
         if only in ("", "train2"):
             gen_train_step_stage2(tmp)
+        if only in ("", "panet"):
+            gen_panet(tmp, "vgg16", "panet_vgg16",
+                      {"small": small["small"], "small5": small["small5"],
+                       "full": ([5678], 1, 401, [synth.QUERY_SIZES[5678 % 5]])})
+            gen_panet(tmp, "resnet50", "panet_rn50", {"small": small["small"]})
+            gen_train_step_panet(tmp)
         if only in ("", "facts"):
             gen_index_facts()
 

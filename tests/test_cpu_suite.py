@@ -100,6 +100,37 @@ def test_oracle_baseline(fixture, keys, bb):
     _check_case(fixture, keys, lambda R, sd, t, hw, g, e: R.baseline_forward(sd, t["sup_img"], t["sup_mask"], t["qry_img"], hw, backbone=bb))
 
 
+@pytest.mark.parametrize("fixture,keys,bb", [("panet_vgg16_small", "panet_vgg16", "vgg16"),
+                                             ("panet_vgg16_small5", "panet_vgg16", "vgg16"),
+                                             ("panet_rn50_small", "panet_rn50", "resnet50")])
+def test_oracle_panet(fixture, keys, bb):
+    """PANet restatement (forward + alignment branch) vs the outputs of the reference's networks/panet.py: exact."""
+    def f(R, sd, t, hw, g, e):
+        out, aux = R.panet_forward(sd, t["sup_img"], t["sup_mask"], t["qry_img"], hw, backbone=bb)
+        assert abs(float(aux) - float(g[f"e{e}_align_loss"])) <= 1e-6
+        return out
+    _check_case(fixture, keys, f)
+
+
+def test_panet_module_and_entry_surface():
+    """networks/panet.py:11-25 (net ingredient), entry/panet.py:30-47 (experiment keys), state_dict layout of both backbones."""
+    from pemp_amd.entry import panet as e
+    from pemp_amd.networks import panet as m
+    cfg = e.ex.full_config()
+    for k, v in dict(tag="panet", shot=1, query=1, split=-1, seed=1234, ckpt="bestckpt.pth", exp_id=-1, loss="ce", sigma=5.0,
+                     loss_coef=1.0).items():
+        assert cfg[k] == v
+    assert cfg["net"] == dict(dist_scalar=20, init_channels=3, backbone="vgg16", out_channels=512)
+    assert cfg["p"] == {"cls": -1, "sup": "", "qry": ""} and cfg["data"]["test_n"] == 1000 and cfg["te"] == {"epochs": 5}
+    spec = lambda net: [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+    assert spec(m.PANet(None, backbone="vgg16")) == util.key_spec("panet_vgg16")
+    assert spec(m.PANet(None, backbone="resnet50")) == util.key_spec("panet_rn50")
+    assert type(m.PANet(None, backbone="vgg16")).__name__ == "PANet/VGG16" and m.ModelClass is m.PANet
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net = m.PANet(None).eval()
+        net(torch.zeros(1, 1, 3, 33, 33), torch.zeros(1, 1, 2, 33, 33), torch.zeros(1, 1, 3, 33, 33))
+
+
 @pytest.mark.parametrize("fixture", ["stage2_rn50cm_small", "stage2_rn50cm_small5"])
 def test_oracle_stage2(fixture):
     def f(R, sd, t, hw, g, e):
