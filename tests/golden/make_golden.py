@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference; the GPU box never has it).  The
 reference's hot-path modules (networks/backbones.py, pemp_stage1.py, pemp_stage2.py,
-baseline.py) are imported unmodified from /root/reference and executed on CPU.  Two third-party
+baseline.py, panet.py) are imported unmodified from /root/reference and executed on CPU.  Two third-party
 packages they import are not installed in the image (no network): ``sacred`` (config injection)
 and ``dropblock`` (train-only regulariser).  This script puts two minimal in-process stand-ins
 for those packages on sys.path -- an ``Ingredient`` whose ``capture`` fills missing arguments
