@@ -161,6 +161,14 @@ def conv_roofline(net, pool, reps=3):
             rec = json.load(f)
         if rec.get("episodes_per_step") == len(pool[0]["seeds"]):
             traffic = rec.get("hbm_bytes_per_launch")
+    # MFMA pipe utilisation from the PMC counters (rocprofv3 --pmc MfmaUtil on this command), likewise committed
+    mfma_util = None
+    mf = os.path.join(ROOT, "profiles", "r01_mfma_util.json")
+    if os.path.exists(mf):
+        with open(mf) as f:
+            rec = json.load(f)
+        if rec.get("episodes_per_step") == len(pool[0]["seeds"]):
+            mfma_util = rec.get("conv_mfma_util_pct_time_weighted")
     # where the time goes: the six GEMM shapes (rows M, Cout N, K, with shortcut) with the largest share of conv time
     by = {}
     for r in records:
@@ -172,7 +180,7 @@ def conv_roofline(net, pool, reps=3):
                  "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)} for k, v in top]
     return {"bound": "mfma", "kernel": "conv_dma_kernel + conv_igemm_kernel (all conv launches of a step)",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "mfma_util_pmc_pct": mfma_util,
             "algorithmic_bytes_per_launch": int(abytes / n),
             "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
             "gflop_per_step": round(flops / reps / 1e9, 2), "conv_ms_per_step": round(ms / reps, 4),
