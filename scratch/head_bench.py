@@ -4,9 +4,12 @@
 
 Prints per-call time and algorithmic GB/s (feature-map bytes / time) for each op.
 """
+import os
 import sys
 
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from pemp_amd import ops
 
