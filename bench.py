@@ -341,12 +341,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # PEMP_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
+    # devices round-robin; the numbers mean nothing then).  The driver's runs use the default: one GPU per rank, RCCL.
+    backend = os.environ.get("PEMP_BENCH_BACKEND", "nccl")
+    first_local = local == 0
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from pemp_amd import build, ops
-    if local == 0:
+    if first_local:
         build.build()                 # normally a no-op: the prebuilt .so travels with the snapshot
     if world > 1:
         dist.barrier()
