@@ -266,8 +266,11 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 using namespace pemp;
 
 static int pick_split(int tiles, int steps) {
-    // aim for ~1536 blocks with at least 8 reduction steps each
-    int s = cdiv(1536, tiles);
+    // aim for ~768 blocks (3 per CU) with at least 8 reduction steps each.  The kernel shares the chip with the
+    // input-gradient chain on the other stream, so it need not fill it alone, and every split costs a [Cout][K] partial
+    // that the reduce pass has to read again: 1536 / 1024 / 768 / 512 / 384 blocks -> 20.88 / 20.78 / 20.53 / 20.59 /
+    // 20.76 ms per training step.
+    int s = cdiv(768, tiles);
     if (s > steps / 8) s = steps / 8;
     if (s < 1) s = 1;
     if (s > 512) s = 512;
