@@ -39,9 +39,9 @@ def parse():
                     help="episodes per step (the reference evaluates 1 per step); 25 -> 50 x 2601 feature rows, "
                          "which fill the 256-row conv tiles and the 256 CUs almost exactly")
     ap.add_argument("--shot", type=int, default=1)
-    ap.add_argument("--model", choices=("stage1", "stage2", "baseline"), default="stage1",
+    ap.add_argument("--model", choices=("stage1", "stage2", "baseline", "panet"), default="stage1",
                     help="stage1 = headline; stage2 = stage-1 prior + stage-2 (use with --shot 5 for configs[3]); "
-                         "baseline = Baseline VGG-16 (configs[0])")
+                         "baseline = Baseline VGG-16 (configs[0]); panet = PANet VGG-16 (the Baseline step + the alignment branch)")
     ap.add_argument("--mode", choices=("eval", "train"), default="eval",
                     help="eval (headline metric, BASELINE.json configs[1]) or train (configs[2])")
     ap.add_argument("--no-graph", action="store_true")
@@ -361,11 +361,11 @@ def main():
         dist.barrier()
     if args.mode == "train":
         return main_train(args, world, rank, dev)
-    if args.model == "baseline":        # BASELINE.json configs[0]: Baseline, VGG-16, 1-shot
-        from pemp_amd.networks import baseline as mb
+    if args.model in ("baseline", "panet"):        # BASELINE.json configs[0]: Baseline, VGG-16, 1-shot (PANet: same encoder)
+        from pemp_amd.networks import baseline as mb, panet as mp
         from tests import util
         sd = util.wgen_state_dict("baseline_vgg16")
-        net = mb.Baseline(None, backbone="vgg16")
+        net = mb.Baseline(None, backbone="vgg16") if args.model == "baseline" else mp.PANet(None, backbone="vgg16")
         net.load_state_dict(sd)
         net = net.to(dev).eval()
     else:
@@ -374,6 +374,7 @@ def main():
     ws = {}
     stats_log = torch.zeros((args.steps, args.batch, 8), dtype=torch.float64, device=dev)
 
+    aux_log, ws_align = [], {}
     stage2 = None
     if args.model == "stage2":          # BASELINE.json configs[3]: stage-1 prior + stage-2 (ResNet-50 + CM)
         from pemp_amd.networks import pemp_stage2 as m2
@@ -391,6 +392,9 @@ def main():
                 prior, _, _ = ops.eval_tail(pred, None, out_hw=ins[0].shape[-2:], ws_cache=ws)
                 prior = prior.unsqueeze(1).float()
                 pred, _ = stage2.lowres(*ins, prior) if args.no_graph else stage2.lowres_graphed(*ins, prior)
+            if args.model == "panet":       # auxiliary prototype-alignment loss of every episode (entry/panet.py:51-57)
+                from pemp_amd.networks.panet import align_forward
+                aux_log.append(align_forward(net._last_feats, pred, ins[1], ins[0].shape[0], args.shot, 1, 20, ws_align)["loss"])
             am, stats, _ = ops.eval_tail(pred, ep["qry_mask"], ws_cache=ws)
         if log:
             stats_log[i].copy_(stats)
@@ -425,15 +429,15 @@ def main():
         eps_total = args.steps * args.batch * world
         out = {
             "metric": "episodes/sec (%s eval step, PASCAL-5i-shaped %d-shot, %s)" % (
-                "Baseline" if args.model == "baseline" else "PEMP stage-1" if stage2 is None else "PEMP stage-1 prior + stage-2",
-                args.shot, "VGG-16" if args.model == "baseline" else "ResNet-50"),
+                "Baseline" if args.model == "baseline" else "PANet" if args.model == "panet" else "PEMP stage-1" if stage2 is None else "PEMP stage-1 prior + stage-2",
+                args.shot, "VGG-16" if args.model in ("baseline", "panet") else "ResNet-50"),
             "value": round(eps_total / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s eval test_step, %s, %d-shot, 401x401, %d episode(s)/step, "
                                    "synthetic E(seed) episodes + Wgen(1234) weights" % (
-                                       "baseline" if args.model == "baseline" else "pemp_" + args.model,
-                                       "VGG-16" if args.model == "baseline" else "ResNet-50", args.shot, args.batch),
+                                       args.model if args.model in ("baseline", "panet") else "pemp_" + args.model,
+                                       "VGG-16" if args.model in ("baseline", "panet") else "ResNet-50", args.shot, args.batch),
                        "episodes_per_step": args.batch, "shot": args.shot, "hipgraph": not args.no_graph,
                        "mean_ce_loss": round(mean_loss, 6)},
         }
@@ -450,7 +454,7 @@ def main():
                 out["roofline"]["traffic"] = None        # the committed PMC run is the stage-1 workload
         if world == 1 and args.model == "stage1" and not args.no_graph and not args.no_e2e:
             guarded("end_to_end", lambda: end_to_end(net, args, dev))
-        if world == 1 and args.cpu_episodes > 0 and args.model != "baseline":
+        if world == 1 and args.cpu_episodes > 0 and args.model not in ("baseline", "panet"):
             guarded("cpu_baseline", lambda: cpu_baseline({k: v.cpu() for k, v in sd.items()}, args.shot, args.cpu_episodes))
     if world > 1:
         dist.barrier()
