@@ -440,6 +440,8 @@ def main():
             s1 = gen_stage1(tmp, "resnet50", "stage1_rn50", {**small, **full} if only != "stage2" else {})
         if only in ("", "map"):
             gen_stage1_map(tmp)
+        if only in ("", "stage1rn101"):       # ResNet-101 trunk (layers 3/4/23, networks/pemp_stage1.py:86-96)
+            gen_stage1(tmp, "resnet101", "stage1_rn101", {"small": ([3], 1, 97, [(80, 120)])})
         if only in ("", "stage1vgg"):
             gen_stage1(tmp, "vgg16", "stage1_vgg16", {"small": small["small"]})
         if only in ("", "baseline"):

@@ -79,6 +79,15 @@ def test_oracle_stage1_rn50_full_size():
     _check_case("stage1_rn50_full", "stage1_rn50", _s1("resnet50"), max_eps=1)
 
 
+def test_oracle_stage1_rn101():
+    """ResNet-101 trunk (layers 3/4/23): oracle vs the reference's output, and the state_dict layout."""
+    _check_case("stage1_rn101_small", "stage1_rn101", _s1("resnet101"))
+    from pemp_amd.networks import pemp_stage1 as m
+    net = m.PEMPStage1(None, backbone="resnet101")
+    spec = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+    assert spec == util.key_spec("stage1_rn101")
+
+
 def test_oracle_stage1_vgg16():
     _check_case("stage1_vgg16_small", "stage1_vgg16", _s1("vgg16"))
 

@@ -63,6 +63,22 @@ def test_stage1_vgg16_matches_reference_golden(hip_lib, dev):
         _compare(g, e, out, t["qry_mask"], net._last_feats)
 
 
+def test_stage1_resnet101_matches_reference_golden(hip_lib, dev):
+    """The deeper trunk (23 blocks in layer3) through the same engines."""
+    from pemp_amd.networks import pemp_stage1 as m
+    net = m.PEMPStage1(None, backbone="resnet101")
+    net.load_state_dict(util.wgen_state_dict("stage1_rn101"))
+    net = net.to(dev).eval()
+    g = util.gold("stage1_rn101_small")
+    for e, seed in enumerate(g["seeds"]):
+        hw = tuple(int(v) for v in g[f"e{e}_out_hw"])
+        t = util.episode_tensors(seed, 1, 97, hw, dev)
+        with torch.no_grad():
+            out, resp = net(t["sup_img"], t["sup_mask"], t["qry_img"], hw, ret_ind=True)
+        _compare(g, e, out, t["qry_mask"], net._last_feats)
+        assert (resp[0, ::7, ::7].cpu().numpy() == g[f"e{e}_resp_s7"]).mean() > 0.99
+
+
 def test_stage1_plain_map_branch_matches_reference_golden(hip_lib, dev):
     from pemp_amd.networks import pemp_stage1 as m
     net = m.PEMPStage1(None, protos=0)
