@@ -271,6 +271,43 @@ def gen_train_step(tmp):
     print("wrote train step; loss", float(loss))
 
 
+def gen_train_step_5shot(tmp):
+    """G16: 5-shot training steps (mean over shots in the MPM / the PANet alignment branch's expansion over S):
+    stage-1 ResNet-50 and PANet VGG-16, B = 2 episodes x (5 + 1) images, 97x97."""
+    from networks import pemp_stage1 as m1, panet as mp
+    for tag in ("stage1_rn50", "panet_vgg16"):
+        # the reference's PANet supports S > 1 only for one episode per batch (its compute_similarity views an expanded
+        # tensor, panet.py:135-139; scripts/panet.sh trains with data.bs=1): B = 1 there, B = 2 for stage 1
+        b = synth.make_batch([41, 42] if tag == "stage1_rn50" else [41], shot=5, height=97, width=97, out_hw=(97, 97))
+        sup, msk, qry, gt = _t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"]), _t(b["qry_mask"][:, 0])
+        if tag == "stage1_rn50":
+            cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3, drop_rate=0.0, block_size=4)
+            model = _build(m1, "PEMPStage1", cfg, (), tmp)
+        else:
+            cfg = dict(dist_scalar=20, init_channels=3, backbone="vgg16", out_channels=512)
+            model = _build(mp, "PANet", cfg, (), tmp)
+        _load_wgen(model)
+        model.train()
+        out = model(sup, msk, qry, (97, 97))
+        logits, aux = out if isinstance(out, tuple) else (out, None)
+        loss = torch.nn.functional.cross_entropy(logits, gt, ignore_index=255)
+        (loss if aux is None else loss + aux).backward()
+        res = {"loss": np.array(float(loss.detach()), np.float64)}
+        if aux is not None:
+            res["align_loss"] = np.array(float(aux.detach()), np.float64)
+        names, norms = [], []
+        for k, p in model.named_parameters():
+            names.append(k)
+            norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+        res["grad_names"], res["grad_norms"] = np.array(names), np.array(norms, np.float64)
+        plist = dict(model.named_parameters())
+        for k in [k for k in plist if plist[k].grad is not None][:2] + list(plist)[-2:]:
+            g = plist[k].grad
+            res["grad__" + k] = g.numpy() if g.numel() <= 40000 else g.reshape(-1)[::37].numpy()
+        np.savez_compressed(OUT / f"{tag}_trainstep5.npz", **res)
+        print("wrote", tag, "5-shot train step; loss", float(loss), "" if aux is None else float(aux))
+
+
 def gen_panet(tmp, backbone, tag, cases):
     """G14: PANet (networks/panet.py:68-193) = the Baseline forward + the prototype-alignment loss."""
     from networks import panet as m
@@ -465,6 +502,8 @@ def main():
                        "full": ([5678], 1, 401, [synth.QUERY_SIZES[5678 % 5]])})
             gen_panet(tmp, "resnet50", "panet_rn50", {"small": small["small"]})
             gen_train_step_panet(tmp)
+        if only in ("", "train5"):
+            gen_train_step_5shot(tmp)
         if only in ("", "facts"):
             gen_index_facts()
 

@@ -117,3 +117,47 @@ def test_panet_reference_trainer_body_runs_through_the_autograd_bridge(hip_lib, 
     assert abs(loss.item() - l2.item()) < 1e-6 and abs(aux_loss.item() - tr.last_align_loss.item()) < 1e-6
     for k, p in ref_net.named_parameters():      # torch's CE backward vs the fused one: a few ulps apart
         assert (grads[k] - p.grad).abs().max().item() <= 1e-4 * p.grad.abs().max().item() + 1e-9, k
+
+
+def _check_grad_fixture(net, g, rtol_norm=1e-2, rtol_t=1.5e-2):
+    params = dict(net.named_parameters())
+    bad = []
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        if ref < 0:
+            continue
+        got = params[str(name)].grad.norm().item()
+        if abs(got - ref) > rtol_norm * ref + 1e-5:
+            bad.append((str(name), got, float(ref)))
+    assert not bad, bad[:10]
+    for key in [k for k in g.files if k.startswith("grad__")]:
+        name = key[len("grad__"):]
+        got = params[name].grad.cpu()
+        ref = torch.from_numpy(g[key])
+        got = (got if got.numel() <= 40000 else got.reshape(-1)[::37]).reshape(ref.shape)
+        assert (got - ref).abs().max().item() <= rtol_t * ref.abs().max().item() + 1e-7, name
+
+
+def test_five_shot_train_steps_match_reference_gradients(hip_lib, dev):
+    """5-shot gradients from the reference: stage 1 (mean over shots inside the MPM, B = 2) and PANet (the alignment
+    branch expanded over the S support images; the reference supports S > 1 only with one episode per batch)."""
+    from pemp_amd import synth
+    from pemp_amd.networks import pemp_stage1 as m1
+    from pemp_amd.train_baseline import PANetTrainer
+    from pemp_amd.train_engine import Stage1Trainer
+    t = lambda a: torch.from_numpy(a).to(dev)
+    b = synth.make_batch([41, 42], shot=5, height=97, width=97, out_hw=(97, 97))
+    g = util.gold("stage1_rn50_trainstep5")
+    net = m1.ModelClass(None)
+    net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    tr = Stage1Trainer(net, device=dev, drop_rate=0.0)
+    loss, _ = tr.forward_backward(t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0]))
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    _check_grad_fixture(net, g)
+    b = synth.make_batch([41], shot=5, height=97, width=97, out_hw=(97, 97))
+    g = util.gold("panet_vgg16_trainstep5")
+    net = _net(dev, "vgg16", "panet_vgg16")
+    tr = PANetTrainer(net, device=dev, loss_coef=1.0)
+    loss, _ = tr.forward_backward(t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0]))
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    assert abs(tr.last_align_loss.item() - float(g["align_loss"])) < 2e-3 * max(1.0, float(g["align_loss"]))
+    _check_grad_fixture(net, g)
