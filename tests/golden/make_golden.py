@@ -405,16 +405,17 @@ def stage2_train_prior(qry_mask):
     return np.roll(fg, (3, 5), axis=(1, 2)).astype(np.int64)[:, None]          # [BQ,1,H,W]
 
 
-def gen_train_step_stage2(tmp):
+def gen_train_step_stage2(tmp, shot=1, seeds=(31, 32), out="stage2_rn50cm_trainstep"):
     """G11: loss and gradients of one stage-2 training step (entry/pemp_stage2.py:72-83): ResNet-50+CM in
-    train() mode (batch-stat BN, Dropout2d off = drop_rate2 0), B=2 episodes, 97x97, CE loss."""
+    train() mode (batch-stat BN, Dropout2d off = drop_rate2 0), B=2 episodes, 97x97, CE loss.
+    (shot=5: G17, the communication modules' episode means then run over S + Q = 6 images.)"""
     from networks import pemp_stage2 as m
     cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
                drop_rate=0.1, block_size=4, backbone2="resnet50", protos2=3, drop_rate2=0.0, cm=True)
-    model = _build(m, "PEMPStage2", cfg, (1, 1), tmp)
+    model = _build(m, "PEMPStage2", cfg, (shot, 1), tmp)
     _load_wgen(model, seed=4321)
     model.train()
-    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    b = synth.make_batch(list(seeds), shot=shot, height=97, width=97, out_hw=(97, 97))
     prior = torch.from_numpy(stage2_train_prior(b["qry_mask"]))
     logits = model(_t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"]), prior, (97, 97))
     loss = torch.nn.functional.cross_entropy(logits, _t(b["qry_mask"][:, 0]), ignore_index=255)
@@ -437,8 +438,8 @@ def gen_train_step_stage2(tmp):
     for k in (bb + "bn1.running_mean", bb + "layer3.5.bn3.running_var", bb + "layer2.0.downsample.1.running_mean",
               bb + "bn1.num_batches_tracked"):
         res["buf__" + k] = sd[k].numpy()
-    np.savez_compressed(OUT / "stage2_rn50cm_trainstep.npz", **res)
-    print("wrote stage-2 train step; loss", float(loss))
+    np.savez_compressed(OUT / f"{out}.npz", **res)
+    print("wrote stage-2 train step", out, "; loss", float(loss))
 
 
 def gen_index_facts():
@@ -504,6 +505,7 @@ def main():
             gen_train_step_panet(tmp)
         if only in ("", "train5"):
             gen_train_step_5shot(tmp)
+            gen_train_step_stage2(tmp, shot=5, seeds=(41, 42), out="stage2_rn50cm_trainstep5")
         if only in ("", "facts"):
             gen_index_facts()
 

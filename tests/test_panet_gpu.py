@@ -161,3 +161,29 @@ def test_five_shot_train_steps_match_reference_gradients(hip_lib, dev):
     assert abs(loss.item() - float(g["loss"])) < 2e-5
     assert abs(tr.last_align_loss.item() - float(g["align_loss"])) < 2e-3 * max(1.0, float(g["align_loss"]))
     _check_grad_fixture(net, g)
+    # stage 2, 5-shot: the communication modules' episode means run over S + Q = 6 images
+    from pemp_amd.networks import pemp_stage2 as m2
+    from pemp_amd.train_stage2 import Stage2Trainer
+    from tests.golden.make_golden import stage2_train_prior
+    b = synth.make_batch([41, 42], shot=5, height=97, width=97, out_hw=(97, 97))
+    g = util.gold("stage2_rn50cm_trainstep5")
+    net = m2.ModelClass(5, 1, None)
+    net.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+    tr = Stage2Trainer(None, net, device=dev, drop_rate2=0.0)
+    prior = torch.from_numpy(stage2_train_prior(b["qry_mask"])).to(dev)
+    loss, _ = tr.forward_backward(t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0]), prior)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    params = dict(net.named_parameters())
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        p = params[str(name)]
+        if ref < 0:
+            assert not p.requires_grad, name
+            continue
+        # linear*.bias feeds a pre-BatchNorm activation: its true gradient is zero, both sides hold rounding noise
+        assert abs(p.grad.norm().item() - ref) <= 1e-2 * ref + 2e-5, (str(name), p.grad.norm().item(), float(ref))
+    for key in [k for k in g.files if k.startswith("grad__")]:
+        name = key[len("grad__"):]
+        got = params[name].grad.cpu()
+        ref = torch.from_numpy(g[key])
+        got = (got if got.numel() <= 40000 else got.reshape(-1)[::37]).reshape(ref.shape)
+        assert (got - ref).abs().max().item() <= 1.5e-2 * max(ref.abs().max().item(), 1e-6) + 2e-7, name
