@@ -442,6 +442,47 @@ def gen_train_step_stage2(tmp, shot=1, seeds=(31, 32), out="stage2_rn50cm_trains
     print("wrote stage-2 train step", out, "; loss", float(loss))
 
 
+def cedt_cases():
+    """Targets / logits of the CELossDT fixture (shared with the tests): two 97x97 query masks (one with an ignored
+    corner), one 333x500 mask, an all-background and an all-foreground map; logits from a seeded generator."""
+    ts = [torch.from_numpy(synth.make_episode(s, out_hw=hw)["qry_mask"][0]) for s, hw in ((41, (97, 97)), (42, (97, 97)))]
+    t = torch.stack(ts)
+    t[0, :4, :9] = 255
+    cases = [t, torch.from_numpy(synth.make_episode(43, out_hw=(333, 500))["qry_mask"]),
+             torch.zeros(1, 40, 57, dtype=torch.int64), torch.ones(1, 9, 11, dtype=torch.int64)]
+    g = torch.Generator().manual_seed(77)
+    return [(c, torch.rand(c.shape[0], 2, *c.shape[-2:], generator=g) * 6 - 3) for c in cases]
+
+
+def gen_cedt():
+    """G18: CELossDT of the reference itself (core/losses.py:17-43): weight maps and loss values.  The class is written
+    for numpy < 1.24 and a CUDA box: ``np.bool`` is aliased to ``bool`` and ``Tensor.cuda`` is the identity while it
+    runs here (environment shims in this process only; the reference file is imported unmodified)."""
+    import core.losses as L
+    had_bool = hasattr(np, "bool")
+    if not had_bool:
+        np.bool = bool
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        obj = L.CELossDT(5.0)
+        res = {}
+        for n, (tgt, logits) in enumerate(cedt_cases()):
+            mask = torch.zeros_like(tgt, dtype=torch.float32)
+            mask[tgt == 1] = 1
+            mask = mask.unsqueeze(1)
+            dil = torch.clamp(torch.nn.functional.conv2d(mask, obj.kernel, padding=1), 0, 1) - mask
+            ero = mask - torch.clamp(torch.nn.functional.conv2d(mask, obj.kernel, padding=1) - 8, 0, 1)
+            res[f"c{n}_weight"] = obj.boundary2weight((dil + ero).squeeze(1)).numpy()      # the reference's own method
+            res[f"c{n}_loss"] = np.array(float(obj(logits, tgt)), np.float64)               # and its __call__
+    finally:
+        torch.Tensor.cuda = orig_cuda
+        if not had_bool:
+            del np.bool
+    np.savez_compressed(OUT / "cedt_reference.npz", **res)
+    print("wrote cedt_reference", [float(res[f"c{n}_loss"]) for n in range(4)])
+
+
 def gen_index_facts():
     """G8: index-map facts of the stock ops."""
     import torch.nn.functional as F
@@ -506,6 +547,8 @@ def main():
         if only in ("", "train5"):
             gen_train_step_5shot(tmp)
             gen_train_step_stage2(tmp, shot=5, seeds=(41, 42), out="stage2_rn50cm_trainstep5")
+        if only in ("", "cedt"):
+            gen_cedt()
         if only in ("", "facts"):
             gen_index_facts()
 

@@ -28,6 +28,22 @@ def test_cedt_weight_matches_scipy(hip_lib, dev, idx):
     assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6), (got - ref).abs().max()
 
 
+def test_cedt_weight_and_loss_match_the_reference_class(hip_lib, dev):
+    """Device weight map (boundary + exact EDT) and weighted CE vs what the reference's own CELossDT produced
+    (tests/golden/cedt_reference.npz, make_golden.py --only cedt)."""
+    from pemp_amd import ops
+    from tests import util
+    from tests.golden.make_golden import cedt_cases
+    g = util.gold("cedt_reference")
+    for n, (tgt, logits) in enumerate(cedt_cases()):
+        w = ops.cedt_weight(tgt.to(dev), 5.0)
+        assert torch.allclose(w.cpu(), torch.from_numpy(g[f"c{n}_weight"]), rtol=1e-6, atol=1e-6), n
+        # the fused tail evaluates the loss from a low-resolution prediction; feed it the logits at identity scale
+        _, stats, _ = ops.eval_tail(logits.to(dev).contiguous(), tgt.to(dev), weight=w)
+        loss = (stats[:, 0].sum() / stats[:, 1].sum()).item()
+        assert abs(loss - float(g[f"c{n}_loss"])) < 2e-6 * max(1.0, float(g[f"c{n}_loss"])), (n, loss)
+
+
 def test_cedt_loss_and_gradient(hip_lib, dev):
     from oracle import ref_cpu
     from pemp_amd import ops, train_ops as T

@@ -151,6 +151,16 @@ def test_oracle_stage2(fixture):
     _check_case(fixture, "stage2_rn50cm", f)
 
 
+def test_oracle_celoss_dt_matches_the_reference_class():
+    """CELossDT restatement vs weight maps / losses the reference's own core/losses.py produced (cedt_reference.npz)."""
+    from oracle import ref_cpu
+    from tests.golden.make_golden import cedt_cases
+    g = util.gold("cedt_reference")
+    for n, (tgt, logits) in enumerate(cedt_cases()):
+        assert np.array_equal(ref_cpu.cedt_weight(tgt, 5.0).numpy(), g[f"c{n}_weight"]), n
+        assert abs(float(ref_cpu.celoss_dt(logits, tgt, 5.0)) - float(g[f"c{n}_loss"])) <= 1e-7, n
+
+
 def test_index_facts():
     """G8: geometry facts of the stock ops that the kernels hard-code."""
     g = util.gold("index_facts")
