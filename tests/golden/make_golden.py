@@ -483,6 +483,35 @@ def gen_cedt():
     print("wrote cedt_reference", [float(res[f"c{n}_loss"]) for n in range(4)])
 
 
+def metric_cases():
+    rng = np.random.RandomState(0)
+    out = []
+    for cls in (1, 3, 3, 5, 17):
+        pred = rng.randint(0, 2, (1, 40, 50))
+        ref = rng.randint(0, 2, (1, 40, 50))
+        ref[0, :3] = 255
+        out.append((pred, ref, [cls]))
+    return out
+
+
+def gen_metric():
+    """G19: FewShotMetric / Accumulator of the reference itself (core/metrics.py:4-66) on seeded predictions."""
+    from core.metrics import Accumulator, FewShotMetric
+    m = FewShotMetric(20)
+    for pred, ref, cls in metric_cases():
+        m.update(pred, ref, cls)
+    labels = [1, 3, 5, 17]
+    c, mean = m.mIoU(labels)
+    cb, meanb = m.mIoU(labels, binary=True)
+    acc = Accumulator(loss=[], miou=[], n=0.0)
+    for i in range(3):
+        acc.update(loss=0.5 + i, miou=c * (i + 1), n=2.0)
+    np.savez_compressed(OUT / "metric_reference.npz", stat=m.stat, miou_c=c, miou=np.array(mean), biou_c=cb,
+                        biou=np.array(meanb), acc_loss=np.array(acc.mean("loss")), acc_miou=acc.mean("miou", axis=0),
+                        acc_n=np.array(acc.mean("n")))
+    print("wrote metric_reference", float(mean), float(meanb))
+
+
 def gen_index_facts():
     """G8: index-map facts of the stock ops."""
     import torch.nn.functional as F
@@ -547,6 +576,8 @@ def main():
         if only in ("", "train5"):
             gen_train_step_5shot(tmp)
             gen_train_step_stage2(tmp, shot=5, seeds=(41, 42), out="stage2_rn50cm_trainstep5")
+        if only in ("", "metric"):
+            gen_metric()
         if only in ("", "cedt"):
             gen_cedt()
         if only in ("", "facts"):

@@ -198,6 +198,30 @@ def test_oracle_metric_matches_reference_formulas():
     assert m.stat[0].tolist() == c[0].tolist() and m.stat[5].tolist() == c[1].tolist()
 
 
+def test_metric_matches_the_reference_module():
+    """FewShotMetric (oracle and product) and Accumulator vs the numbers the reference's core/metrics.py produced."""
+    from oracle import ref_cpu
+    from pemp_amd.core.metrics import Accumulator, FewShotMetric
+    from tests.golden.make_golden import metric_cases
+    g = util.gold("metric_reference")
+    a, b = ref_cpu.FewShotMetric(20), FewShotMetric(20)
+    for pred, ref, cls in metric_cases():
+        a.update(pred, ref, cls)
+        b.update(pred, ref, cls)
+    labels = [1, 3, 5, 17]
+    assert np.array_equal(a.stat, g["stat"]) and np.array_equal(b.stat, g["stat"])
+    for m in (lambda *x, **k: a.miou(*x, **k), b.mIoU):
+        c, mean = m(labels)
+        cb, meanb = m(labels, binary=True)
+        assert np.array_equal(c, g["miou_c"]) and mean == float(g["miou"])
+        assert np.array_equal(cb, g["biou_c"]) and meanb == float(g["biou"])
+    acc = Accumulator(loss=[], miou=[], n=0.0)
+    for i in range(3):
+        acc.update(loss=0.5 + i, miou=g["miou_c"] * (i + 1), n=2.0)
+    assert acc.mean("loss") == float(g["acc_loss"]) and np.array_equal(acc.mean("miou", axis=0), g["acc_miou"])
+    assert acc.mean("n") == float(g["acc_n"])
+
+
 # ---------------------------------------------------------------------------------------------
 # host mirrors
 # ---------------------------------------------------------------------------------------------
