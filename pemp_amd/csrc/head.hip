@@ -2,9 +2,13 @@
 // plain / full-resolution masked average pooling, pixel x prototype cosine map with group max,
 // and the upsample / argmax / cross-entropy / IoU-count tail of the evaluator.
 //
-// All of these are streaming kernels over [pixels][c] feature maps (c contiguous): their bound
-// is HBM/L2 bandwidth (AI ~ 3 flop/B at 2p = 6 prototypes), so the design is wave-per-pixel
-// coalesced 16-B loads + wavefront shuffles, partial sums in a fixed order (deterministic).
+// All of these are streaming kernels over [pixels][c] feature maps (c contiguous): their bound is HBM
+// bandwidth (AI ~ 3 flop/B at 2p = 6 prototypes).  The three passes over the features run on the matrix
+// cores -- per-pixel products with a c x 2p table as 16x16x4 fp32 MFMA row streams (cosine map, MPM
+// assignment), masked pooling as an MFMA over pixels -- with lane-contiguous loads, 8-16 KB per wave in
+// flight and at most 96 VGPRs / 32 KB of LDS per block so that five blocks share a CU (measured 5.4-5.7
+// TB/s).  Wave-per-pixel VALU variants remain for channel counts the MFMA kernels are not instantiated
+// for.  Partial sums are combined in a fixed order everywhere (deterministic).
 #include <stdlib.h>
 #include "head_common.h"
 
