@@ -483,7 +483,7 @@ class GradBuckets:
         n = flat_grad.numel()
         bounds, hi = [n], n
         for c in sorted({int(c) for c in cuts if 0 < int(c) < n}, reverse=True):
-            if (hi - c) * 4 >= min_bytes and c * 4 >= min_bytes:        # neither this bucket nor the remainder gets tiny
+            if (hi - c) * 4 >= min_bytes and c * 16 >= min_bytes:       # a full bucket above, no sliver (< 1/4 bucket) below
                 bounds.append(c)
                 hi = c
         bounds.append(0)
