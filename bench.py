@@ -49,14 +49,90 @@ def parse():
     ap.add_argument("--train-graph", action="store_true", help="--mode train: replay forward/backward from a hipGraph")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the staging-inclusive end_to_end figure")
+    ap.add_argument("--dataset", choices=("PASCAL", "COCO"), default="PASCAL",
+                    help="COCO: BASELINE.json configs[4] -- COCO-20i label set and picture formats (ground truth up to 640x640)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------
+# N > 1 without an external launcher: `python bench.py --gpus N` starts its own ranks
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    """Start ``n`` copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
+    as torchrun would), wait for them and return the exit code: 0 only if every rank exited 0.  Runs BEFORE this
+    process makes any GPU call (it never makes one): the children are fresh processes, nothing is re-exec'ed.  A rank
+    that dies takes the job down -- the survivors (blocked in a barrier) are terminated by PID."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PEMP_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    try:
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in alive:
+                        q.terminate()
+    finally:
+        for q in alive:
+            q.kill()
+    return rc
+
+
+def dry_run(args, world, rank):
+    """PEMP_BENCH_DRYRUN=1 (tests, CPU): the control flow of an N-rank run -- rendezvous, barriers, K timed steps,
+    MAX over ranks, ONE line on rank 0 -- with a sleep in place of the GPU step.  PEMP_BENCH_FAIL_RANK=r makes rank r
+    exit non-zero before the first barrier (the launcher must then fail the whole job)."""
+    if os.environ.get("PEMP_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    if world > 1:
+        dist.init_process_group(os.environ.get("PEMP_BENCH_BACKEND", "gloo"))
+        dist.barrier()
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "episodes/sec (dry run: no GPU work)", "value": round(args.steps * args.batch * world / dt, 2),
+                          "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry run", "mode": args.mode}}))
+
+
 def build_model(dev):
+    from pemp_amd import synth
     from pemp_amd.networks import pemp_stage1 as m
-    from tests import util
-    sd = util.wgen_state_dict("stage1_rn50")
     net = m.ModelClass(None)
+    sd = synth.wgen_state_dict_for(net)
     net.load_state_dict(sd)
     return net.to(dev).eval(), sd
 
@@ -273,9 +349,8 @@ def main_train(args, world, rank, dev):
     from pemp_amd import synth
     from pemp_amd.networks import pemp_stage1 as m
     from pemp_amd.train_engine import Stage1Trainer
-    from tests import util
     net = m.ModelClass(None)
-    net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    net.load_state_dict(synth.wgen_state_dict_for(net))
     # eager by default: the weight-gradient kernels run on a side stream concurrently with the input-gradient chain
     # (21.4 ms/step); a hipGraph replay of the same two-stream capture does not overlap its branches (23.6 ms/step)
     use_graph = args.train_graph
@@ -283,7 +358,7 @@ def main_train(args, world, rank, dev):
         from pemp_amd.networks import pemp_stage2 as m2
         from pemp_amd.train_stage2 import Stage2Trainer
         net2 = m2.ModelClass(args.shot, 1, None)
-        net2.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+        net2.load_state_dict(synth.wgen_state_dict_for(net2, seed=4321))
         tr = Stage2Trainer(net.to(dev).eval(), net2, device=dev, use_graph=use_graph)
     else:
         tr = Stage1Trainer(net, device=dev, use_graph=use_graph)
@@ -336,9 +411,15 @@ def main():
     args = parse()
     if args.mode == "train" and "--batch" not in sys.argv:           # the reference trains with data.bs = 4
         args.batch = 4
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:              # no launcher around us: be the launcher
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
+    if os.environ.get("PEMP_BENCH_DRYRUN"):
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # PEMP_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
@@ -362,10 +443,10 @@ def main():
     if args.mode == "train":
         return main_train(args, world, rank, dev)
     if args.model in ("baseline", "panet"):        # BASELINE.json configs[0]: Baseline, VGG-16, 1-shot (PANet: same encoder)
+        from pemp_amd import synth
         from pemp_amd.networks import baseline as mb, panet as mp
-        from tests import util
-        sd = util.wgen_state_dict("baseline_vgg16")
         net = mb.Baseline(None, backbone="vgg16") if args.model == "baseline" else mp.PANet(None, backbone="vgg16")
+        sd = synth.wgen_state_dict_for(net)
         net.load_state_dict(sd)
         net = net.to(dev).eval()
     else:
@@ -377,10 +458,10 @@ def main():
     aux_log, ws_align = [], {}
     stage2 = None
     if args.model == "stage2":          # BASELINE.json configs[3]: stage-1 prior + stage-2 (ResNet-50 + CM)
+        from pemp_amd import synth
         from pemp_amd.networks import pemp_stage2 as m2
-        from tests import util
         stage2 = m2.PEMPStage2(args.shot, 1, None)
-        stage2.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+        stage2.load_state_dict(synth.wgen_state_dict_for(stage2, seed=4321))
         stage2 = stage2.to(dev).eval()
 
     def step(i, log=True):

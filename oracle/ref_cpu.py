@@ -8,12 +8,13 @@ library.
 Pinning: the reference's own tests hold no golden vector for this arithmetic, so
 the restatement is pinned by outputs of the reference itself, produced in the build container by
 ``tests/golden/make_golden.py`` (imports /root/reference/networks/*.py on CPU) and committed under
-``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this file against them.
+``tests/golden/*.npz``; ``tests/test_cpu_suite.py`` (``test_oracle_*``) checks this file against them, bit for bit.
 
 Every function cites the reference lines it restates (paths relative to the reference root).
 All functions are functional: weights come in as a ``{state_dict key: tensor}`` mapping using
-the reference's key names.  Eval-mode semantics only (BatchNorm uses running
-statistics, DropBlock/Dropout are identities) -- that is what the parity configs exercise.
+the reference's key names.  ``TRAIN = False``: eval-mode semantics (BatchNorm uses running
+statistics, DropBlock/Dropout are identities); ``TRAIN = True``: ``model.train()`` BatchNorm (batch statistics) for the
+training-step fixtures and the training cpu_baseline.
 """
 import numpy as np
 import torch

@@ -27,7 +27,6 @@ class TrainingLoop:
         trainer.attach_optimizer(self.optimizer)
         self.optimizer._opt_called = True      # the update runs in the fused kernel; tells torch's schedulers not to warn
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.do_ckpt = tr["ckpt_epoch"] > 0 or True
         rid = run_id if run_id is not None else time.strftime("%y%m%d-%H%M%S", time.localtime())
         self.model_dir = Path(cfg["g"]["model_dir"]) / str(cfg["tag"]) / str(rid)
         self.best_iou, self.best_epoch = -1.0, -1

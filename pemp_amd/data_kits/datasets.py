@@ -33,13 +33,34 @@ PASCAL_CLASSES = ("background", "aeroplane", "bicycle", "bird", "boat", "bottle"
                   "diningtable", "dog", "horse", "motorbike", "person", "potted plant", "sheep", "sofa", "train", "tv/monitor")
 
 
+#: COCO-20i class names per split, label id = split * 20 + position + 1 (reference data_kits/coco.py:20-35)
+COCO_CLASSES = (
+    ("person", "airplane", "boat", "parking meter", "dog", "elephant", "backpack", "suitcase", "sports ball", "skateboard",
+     "wine glass", "spoon", "sandwich", "hot dog", "chair", "dining table", "mouse", "microwave", "refrigerator", "scissors"),
+    ("bicycle", "bus", "traffic light", "bench", "horse", "bear", "umbrella", "frisbee", "kite", "surfboard",
+     "cup", "bowl", "orange", "pizza", "couch", "toilet", "remote", "oven", "book", "teddy bear"),
+    ("car", "train", "fire hydrant", "bird", "sheep", "zebra", "handbag", "skis", "baseball bat", "tennis racket",
+     "fork", "banana", "broccoli", "donut", "potted plant", "tv", "keyboard", "toaster", "clock", "hair drier"),
+    ("motorcycle", "truck", "stop sign", "cat", "cow", "giraffe", "tie", "snowboard", "baseball glove", "bottle",
+     "knife", "apple", "carrot", "cake", "bed", "laptop", "cell phone", "sink", "vase", "toothbrush"),
+)
+
+
 def get_val_labels(split, dataset="PASCAL"):
     """Validation classes of a split (reference data_kits/datasets.py:83-104): 5 per PASCAL-5i split, 20 per COCO-20i."""
-    n = 5 if dataset == "PASCAL" else 20
-    return list(range(split * n + 1, split * n + n + 1))
+    from .. import synth
+    return synth.val_labels(split, dataset)
+
+
+def num_classes(dataset="PASCAL"):
+    """Foreground classes of the metric table (entry/pemp_stage1.py:151-152): PASCAL 20, COCO 80 -> ``[C+1, 3]``."""
+    from .. import synth
+    return synth.num_classes(dataset)
 
 
 def get_class_name(cls, dataset="PASCAL"):
     if dataset == "PASCAL" and 0 <= cls < len(PASCAL_CLASSES):
         return PASCAL_CLASSES[cls]
+    if dataset == "COCO" and 1 <= cls <= 80:          # data_kits/coco.py:20-35, class_names[split][k] <-> split*20+k+1
+        return COCO_CLASSES[(int(cls) - 1) // 20][(int(cls) - 1) % 20]
     return str(int(cls))

@@ -19,7 +19,7 @@ from .. import ops, synth
 from ..config import Experiment, device_ingredient, global_ingredient
 from ..core.metrics import Accumulator, FewShotMetric
 from ..core.solver import test_ingredient, train_ingredient
-from ..data_kits.datasets import PASCAL_CLASSES, data_ingredient, get_class_name, get_val_labels  # noqa: F401
+from ..data_kits.datasets import PASCAL_CLASSES, data_ingredient, get_class_name, get_val_labels, num_classes  # noqa: F401
 from ..networks.pemp_stage1 import ModelClass, net_ingredient
 
 NAME = "PEMP"
@@ -47,9 +47,10 @@ class SyntheticEpisodes:
     ``E(test_seed + round * test_n + i)`` (pemp_amd.synth), yielded in the reference's batch layout
     ``((sup_img, sup_mask, qry_img), qry_mask, cls)`` with a leading batch dim of 1."""
 
-    def __init__(self, test_n, test_seed, shot, split=0, height=401, width=401):
+    def __init__(self, test_n, test_seed, shot, split=0, height=401, width=401, dataset="PASCAL"):
         self.test_n, self.test_seed, self.shot, self.split = test_n, test_seed, shot, split
-        self.height, self.width = height, width
+        self.height, self.width, self.dataset = height, width, dataset
+        synth.val_labels(max(split, 0), dataset)          # unknown dataset names fail here, like datasets.py:83-104
         self.round = -1
 
     def reset_sampler(self):
@@ -63,7 +64,7 @@ class SyntheticEpisodes:
 
     def task(self, i):
         seed = self.test_seed + self.round * self.test_n + i
-        ep = synth.make_episode(seed, self.shot, self.height, self.width, index=i, split=self.split)
+        ep = synth.make_episode(seed, self.shot, self.height, self.width, index=i, split=self.split, dataset=self.dataset)
         t = lambda a: torch.from_numpy(a)[None]
         return (t(ep["sup_img"]), t(ep["sup_mask"]), t(ep["qry_img"])), t(ep["qry_mask"]), torch.tensor([ep["cls"]])
 
@@ -73,13 +74,16 @@ class SyntheticDecodedEpisodes(SyntheticEpisodes):
     HWC images and uint8 {0,255} label images at their own sizes (pemp_amd.data_kits.synth_u8).  The
     evaluator then runs resize / normalise / mask planes on the device (pemp_amd.data_kits.episode)."""
     SIZES = ((375, 500), (333, 500), (500, 375), (366, 500), (457, 500))
+    SIZES_COCO = ((480, 640), (640, 480), (427, 640), (640, 640), (375, 500), (640, 427), (512, 640))
 
     def decoded_task(self, i):
         from ..data_kits import synth_u8
         seed = self.test_seed + self.round * self.test_n + i
-        hs, ws = self.SIZES[seed % len(self.SIZES)]
+        sizes = self.SIZES if self.dataset == "PASCAL" else self.SIZES_COCO
+        hs, ws = sizes[seed % len(sizes)]
         pairs = [(synth_u8.image(seed * 8 + k, hs, ws), synth_u8.mask(seed * 8 + k, hs, ws)) for k in range(self.shot + 1)]
-        cls = get_val_labels(self.split)[seed % 5] if self.split >= 0 else 1
+        labels = get_val_labels(max(self.split, 0), self.dataset)
+        cls = labels[seed % len(labels)]
         return pairs[:self.shot], pairs[self.shot:], cls
 
 
@@ -229,9 +233,9 @@ def test(_config, split, shot, seed):
     torch.manual_seed(seed)
     model = ModelClass(logger).cuda().eval()
     dcfg = _config["data"]
-    data = SyntheticEpisodes(dcfg["test_n"], dcfg["test_seed"], shot, split, dcfg["height"], dcfg["width"])
+    data = SyntheticEpisodes(dcfg["test_n"], dcfg["test_seed"], shot, split, dcfg["height"], dcfg["width"], dcfg["dataset"])
     ev = Evaluator(model)
-    nclass = 20 if dcfg["dataset"] == "PASCAL" else 80
+    nclass = num_classes(dcfg["dataset"])
     loss, miou, biou = ev.start_eval_loop(data, nclass, split, _config["te"]["epochs"], logger, batch=dcfg["test_bs"],
                                           dataset_name=dcfg["dataset"])
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
@@ -257,12 +261,12 @@ def run_training(_config, name, make_trainer, make_evaluator, split, shot, seed,
     trainer = make_trainer(logger if rank == 0 else None, dev)
     broadcast_model(trainer.model)
     loop = TrainingLoop(_config, trainer, make_evaluator(trainer, dev), logger, run_id=exp_id if exp_id >= 0 else None)
-    val = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"])
+    val = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"], d["dataset"])
 
     def batches(epoch):
         return synthetic_batches(d["bs"], shot, loop.steps_per_epoch, d["seed"] + 7919 * epoch, rank, d["height"], d["width"])
 
-    hist = loop.start_training_loop(batches, val, 20 if d["dataset"] == "PASCAL" else 80, split)
+    hist = loop.start_training_loop(batches, val, num_classes(d["dataset"]), split)
     return f"best val mIoU {loop.best_iou * 100:.2f} at epoch {loop.best_epoch}; checkpoints in {loop.model_dir}" if hist else "no epochs"
 
 

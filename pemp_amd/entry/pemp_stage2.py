@@ -9,7 +9,7 @@ from ..core.metrics import Accumulator, FewShotMetric  # noqa: F401
 from ..networks.pemp_stage2 import ModelClass, PriorNet, net_ingredient  # noqa: F401
 from ..config import Experiment
 from .pemp_stage1 import Evaluator as _Stage1Evaluator
-from .pemp_stage1 import INGREDIENTS, SyntheticEpisodes, allreduce_round, get_val_labels, shard_indices  # noqa: F401
+from .pemp_stage1 import INGREDIENTS, SyntheticEpisodes, allreduce_round, get_val_labels, num_classes, shard_indices  # noqa: F401
 
 NAME = "PEMP_Stage2"
 ex = Experiment(name=NAME, ingredients=INGREDIENTS)
@@ -94,9 +94,9 @@ def test(_config, split, shot, seed):
     stage1 = PriorNet(logger).cuda().eval()
     model = ModelClass(shot, _config["query"], logger).cuda().eval()
     d = _config["data"]
-    data = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"])
+    data = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"], d["dataset"])
     ev = Evaluator(stage1, model)
-    loss, miou, biou = ev.start_eval_loop(data, 20 if d["dataset"] == "PASCAL" else 80, split, _config["te"]["epochs"], logger,
+    loss, miou, biou = ev.start_eval_loop(data, num_classes(d["dataset"]), split, _config["te"]["epochs"], logger,
                                           batch=d["test_bs"], dataset_name=d["dataset"])
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
 

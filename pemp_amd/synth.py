@@ -22,6 +22,31 @@ _M2 = _U(0x94D049BB133111EB)
 
 #: query ground-truth sizes cycled by episode index
 QUERY_SIZES = ((333, 500), (375, 500), (457, 500), (366, 500), (500, 333))
+#: COCO-20i: the val2014 picture formats, up to 640x640; test-time query labels keep the
+#: picture's own size (data_kits/coco.py, as pascal_voc.py:229)
+QUERY_SIZES_COCO = ((480, 640), (640, 480), (427, 640), (640, 640), (375, 500), (640, 427), (512, 640), (500, 333))
+
+
+def query_sizes(dataset="PASCAL"):
+    if dataset == "PASCAL":
+        return QUERY_SIZES
+    if dataset == "COCO":
+        return QUERY_SIZES_COCO
+    raise ValueError(f"Not supported dataset: {dataset}. [PASCAL, COCO]")
+
+
+def val_labels(split, dataset="PASCAL"):
+    """Validation classes of a split (data_kits/datasets.py:83-104): 5 per PASCAL-5i split, 20 per COCO-20i split."""
+    if dataset == "PASCAL":
+        return list(range(split * 5 + 1, split * 5 + 6))
+    if dataset == "COCO":
+        return list(range(split * 20 + 1, split * 20 + 21))
+    raise ValueError(f"Not supported dataset: {dataset}. [PASCAL, COCO]")
+
+
+def num_classes(dataset="PASCAL"):
+    """Rows of the metric table minus background (entry/pemp_stage1.py:151: 20 for PASCAL, 80 for COCO)."""
+    return {"PASCAL": 20, "COCO": 80}[dataset]
 
 
 def _mix(z):
@@ -185,17 +210,19 @@ def _image(seed, tag, mask, h, w):
     return img.astype(np.float32)
 
 
-def make_episode(seed, shot=1, height=401, width=401, index=None, out_hw=None, split=0):
+def make_episode(seed, shot=1, height=401, width=401, index=None, out_hw=None, split=0, dataset="PASCAL"):
     """One 1-way ``shot``-shot episode.
 
     Returns dict of numpy arrays WITHOUT the batch dim:
       sup_img [S,3,H,W] f32, sup_mask [S,2,H,W] f32, qry_img [1,3,H,W] f32,
       qry_mask [1,Ho,Wo] int64 in {0,1}, cls int.
-    Query GT size cycles over QUERY_SIZES by ``index`` (default: seed) unless ``out_hw`` given.
+    Query GT size cycles over the dataset's size table by ``index`` (default: seed) unless ``out_hw`` given; the
+    class cycles over the split's validation labels by ``seed`` (every label of a split receives episodes).
     """
     if index is None:
         index = seed
-    ho, wo = out_hw if out_hw is not None else QUERY_SIZES[int(index) % len(QUERY_SIZES)]
+    sizes = query_sizes(dataset)
+    ho, wo = out_hw if out_hw is not None else sizes[int(index) % len(sizes)]
     sup_img = np.empty((shot, 3, height, width), np.float32)
     sup_mask = np.empty((shot, 2, height, width), np.float32)
     for s in range(shot):
@@ -208,12 +235,24 @@ def make_episode(seed, shot=1, height=401, width=401, index=None, out_hw=None, s
     qm = _raster(qell, height, width)
     qry_img = _image(seed, "q", qm, height, width)[None]
     qry_mask = _raster(qell, ho, wo).astype(np.int64)[None]
-    cls = split * 5 + 1 + int(seed) % 5
+    labels = val_labels(max(int(split), 0), dataset)
+    cls = labels[int(seed) % len(labels)]
     return dict(sup_img=sup_img, sup_mask=sup_mask, qry_img=qry_img, qry_mask=qry_mask, cls=cls)
 
 
-def make_batch(seeds, shot=1, height=401, width=401, out_hw=None, split=0):
+def make_batch(seeds, shot=1, height=401, width=401, out_hw=None, split=0, dataset="PASCAL"):
     """Stack episodes along B.  All query masks must share one size (pass ``out_hw``)."""
-    eps = [make_episode(s, shot, height, width, out_hw=out_hw, split=split) for s in seeds]
+    eps = [make_episode(s, shot, height, width, out_hw=out_hw, split=split, dataset=dataset) for s in seeds]
     return {k: (np.stack([e[k] for e in eps]) if k != "cls" else np.array([e[k] for e in eps]))
             for k in eps[0]}
+
+
+# --------------------------------------------------------------------------------------------
+# Wgen for a module: the state_dict itself is the template (keys / shapes are the reference's, pinned by
+# tests/golden/state_keys_*.json), every tensor a function of (seed, key, shape) only
+# --------------------------------------------------------------------------------------------
+def wgen_state_dict_for(module, seed=1234):
+    """Wgen weights for ``module`` (any torch module with the reference's key layout) as {key: torch tensor}."""
+    import torch
+    sd = gen_state_dict(module.state_dict(), seed)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}

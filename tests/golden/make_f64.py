@@ -7,7 +7,7 @@ is bit-equal to the reference in fp32 on every eval fixture) under torch autogra
 ``<case>_trainstep_f64.npz`` with the same sampled tensors as the fp32 fixture (keys ``g64__<name>``)
 and all gradient norms (``grad_norms64``).
 
-    python tests/golden/make_f64.py stage1 | stage2
+    python tests/golden/make_f64.py stage1 | stage2 | stage1_full | stage2_full
 """
 import sys
 from pathlib import Path
@@ -23,7 +23,10 @@ from oracle import ref_cpu as R          # noqa: E402
 from pemp_amd import synth              # noqa: E402
 from tests import util                  # noqa: E402
 
-CASES = {"stage1": ("stage1_rn50_trainstep", "stage1_rn50", 1234), "stage2": ("stage2_rn50cm_trainstep", "stage2_rn50cm", 4321)}
+CASES = {"stage1": ("stage1_rn50_trainstep", "stage1_rn50", 1234), "stage2": ("stage2_rn50cm_trainstep", "stage2_rn50cm", 4321),
+         # the shapes BASELINE.json configs[2] / configs[3] run at (401x401; 4 one-shot episodes / one 5-shot episode)
+         "stage1_full": ("stage1_rn50_trainstep_full", "stage1_rn50", 1234),
+         "stage2_full": ("stage2_rn50cm_trainstep5_full", "stage2_rn50cm", 4321)}
 
 
 def main(case):
@@ -39,17 +42,20 @@ def main(case):
         else:
             leaf = "running" not in k and k not in frozen
             sd[k] = v.double().requires_grad_(leaf)
-    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    seeds = [int(v) for v in g["seeds"]] if "seeds" in g.files else [31, 32]
+    H = int(g["H"]) if "H" in g.files else 97
+    shot = int(g["shot"]) if "shot" in g.files else 1
+    b = synth.make_batch(seeds, shot=shot, height=H, width=H, out_hw=(H, H))
     t = lambda a: torch.from_numpy(a)
     R.TRAIN = True
     try:
         ins = (t(b["sup_img"]).double(), t(b["sup_mask"]).double(), t(b["qry_img"]).double())
-        if case == "stage1":
-            logits = R.stage1_forward(sd, *ins, (97, 97))
+        if case.startswith("stage1"):
+            logits = R.stage1_forward(sd, *ins, (H, H))
         else:
             from tests.golden.make_golden import stage2_train_prior
             prior = t(stage2_train_prior(b["qry_mask"])).double()
-            logits = R.stage2_forward(sd, *ins, prior, (97, 97))
+            logits = R.stage2_forward(sd, *ins, prior, (H, H))
         loss = F.cross_entropy(logits, t(b["qry_mask"][:, 0]), ignore_index=255)
         names = [k for k, v in sd.items() if v.requires_grad]
         grads = dict(zip(names, torch.autograd.grad(loss, [sd[k] for k in names])))

@@ -236,22 +236,27 @@ def gen_stage2(tmp, stage1_model, cases):
         print("wrote stage2", cname)
 
 
-def gen_train_step(tmp):
+TRAIN_FULL = dict(seeds=(1234, 1235, 1236, 1237), H=401, out="stage1_rn50_trainstep_full")     # BASELINE.json configs[2]
+
+
+def gen_train_step(tmp, seeds=(31, 32), H=97, out="stage1_rn50_trainstep"):
     """G9: one training step's loss and gradients of the reference in train() mode (batch-stat BN;
-    DropBlock = identity, i.e. drop_rate 0), B=2 episodes, 97x97, CE loss (entry/pemp_stage1.py:57-65)."""
+    DropBlock = identity, i.e. drop_rate 0), B=2 episodes, 97x97, CE loss (entry/pemp_stage1.py:57-65).
+    G20 (``TRAIN_FULL``): the same at the shape BASELINE.json configs[2] trains at -- data.bs = 4 episodes, 401x401."""
     from networks import pemp_stage1 as m
     cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
                drop_rate=0.0, block_size=4)
     model = _build(m, "PEMPStage1", cfg, (), tmp)
     _load_wgen(model)
     model.train()
-    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    b = synth.make_batch(list(seeds), shot=1, height=H, width=H, out_hw=(H, H))
     sup, msk, qry = _t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"])
     gt = _t(b["qry_mask"][:, 0])
-    logits = model(sup, msk, qry, (97, 97))
+    logits = model(sup, msk, qry, (H, H))
     loss = torch.nn.functional.cross_entropy(logits, gt, ignore_index=255)
     loss.backward()
-    res = {"loss": np.array(float(loss), np.float64), "logits_s7": logits.detach()[:, :, ::7, ::7].numpy()}
+    res = {"loss": np.array(float(loss), np.float64), "logits_s7": logits.detach()[:, :, ::7, ::7].numpy(),
+           "seeds": np.array(seeds), "H": np.array(H)}
     names, norms = [], []
     for k, p in model.named_parameters():
         names.append(k)
@@ -267,8 +272,8 @@ def gen_train_step(tmp):
     for k in ("encoder.backbone.bn1.running_mean", "encoder.backbone.layer3.5.bn3.running_var",
               "encoder.purifier.6.aspp_0.0.running_var", "encoder.backbone.bn1.num_batches_tracked"):
         res["buf__" + k] = sd[k].numpy()
-    np.savez_compressed(OUT / "stage1_rn50_trainstep.npz", **res)
-    print("wrote train step; loss", float(loss))
+    np.savez_compressed(OUT / f"{out}.npz", **res)
+    print("wrote train step", out, "; loss", float(loss))
 
 
 def gen_train_step_5shot(tmp):
@@ -405,22 +410,24 @@ def stage2_train_prior(qry_mask):
     return np.roll(fg, (3, 5), axis=(1, 2)).astype(np.int64)[:, None]          # [BQ,1,H,W]
 
 
-def gen_train_step_stage2(tmp, shot=1, seeds=(31, 32), out="stage2_rn50cm_trainstep"):
+def gen_train_step_stage2(tmp, shot=1, seeds=(31, 32), out="stage2_rn50cm_trainstep", H=97):
     """G11: loss and gradients of one stage-2 training step (entry/pemp_stage2.py:72-83): ResNet-50+CM in
     train() mode (batch-stat BN, Dropout2d off = drop_rate2 0), B=2 episodes, 97x97, CE loss.
-    (shot=5: G17, the communication modules' episode means then run over S + Q = 6 images.)"""
+    (shot=5: G17, the communication modules' episode means then run over S + Q = 6 images.  H=401: G22, one 5-shot
+    episode at the full input size of BASELINE.json configs[3].)"""
     from networks import pemp_stage2 as m
     cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
                drop_rate=0.1, block_size=4, backbone2="resnet50", protos2=3, drop_rate2=0.0, cm=True)
     model = _build(m, "PEMPStage2", cfg, (shot, 1), tmp)
     _load_wgen(model, seed=4321)
     model.train()
-    b = synth.make_batch(list(seeds), shot=shot, height=97, width=97, out_hw=(97, 97))
+    b = synth.make_batch(list(seeds), shot=shot, height=H, width=H, out_hw=(H, H))
     prior = torch.from_numpy(stage2_train_prior(b["qry_mask"]))
-    logits = model(_t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"]), prior, (97, 97))
+    logits = model(_t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"]), prior, (H, H))
     loss = torch.nn.functional.cross_entropy(logits, _t(b["qry_mask"][:, 0]), ignore_index=255)
     loss.backward()
-    res = {"loss": np.array(float(loss.detach()), np.float64), "logits_s7": logits.detach()[:, :, ::7, ::7].numpy()}
+    res = {"loss": np.array(float(loss.detach()), np.float64), "logits_s7": logits.detach()[:, :, ::7, ::7].numpy(),
+           "seeds": np.array(seeds), "H": np.array(H), "shot": np.array(shot)}
     names, norms = [], []
     for k, p in model.named_parameters():
         names.append(k)
@@ -510,6 +517,34 @@ def gen_metric():
     print("wrote metric_reference", float(mean), float(meanb))
 
 
+def metric_cases_coco():
+    """COCO-20i, split 1: labels 21..40 of an [81, 3] table; every label once, two of them twice, one ignored band."""
+    rng = np.random.RandomState(1)
+    out = []
+    for cls in list(range(21, 41)) + [21, 40]:
+        pred = rng.randint(0, 2, (1, 48, 64))
+        ref = rng.randint(0, 2, (1, 48, 64))
+        ref[0, -2:] = 255
+        out.append((pred, ref, [cls]))
+    return out
+
+
+def gen_metric_coco():
+    """G21: the reference's FewShotMetric with 80 classes (entry/pemp_stage1.py:152) and COCO-20i validation labels
+    (split 1: 21..40, the list data_kits/datasets.py:99-100 returns; that module needs torchvision / pycocotools and is
+    not importable here, so the list is written out)."""
+    from core.metrics import FewShotMetric
+    m = FewShotMetric(80)
+    for pred, ref, cls in metric_cases_coco():
+        m.update(pred, ref, cls)
+    labels = list(range(1 * 20 + 1, 1 * 20 + 21))
+    c, mean = m.mIoU(labels)
+    cb, meanb = m.mIoU(labels, binary=True)
+    np.savez_compressed(OUT / "metric_reference_coco.npz", stat=m.stat, labels=np.array(labels), miou_c=c, miou=np.array(mean),
+                        biou_c=cb, biou=np.array(meanb))
+    print("wrote metric_reference_coco", m.stat.shape, float(mean), float(meanb))
+
+
 def gen_index_facts():
     """G8: index-map facts of the stock ops."""
     import torch.nn.functional as F
@@ -559,6 +594,14 @@ def main():
             gen_stage2(tmp, s1, {"small": ([3], 1, 97, [(80, 120)]), "small5": ([5], 5, 97, [(64, 90)])})
         if only in ("", "train"):
             gen_train_step(tmp)
+        if only in ("", "trainfull"):
+            gen_train_step(tmp, **TRAIN_FULL)
+        if only in ("", "train2full"):
+            gen_train_step_stage2(tmp, shot=5, seeds=(1234,), out="stage2_rn50cm_trainstep5_full", H=401)
+        if only in ("", "stage2full"):         # BASELINE.json configs[3]: 5-shot stage 2 at 401x401 (12 encoder passes)
+            if s1 is None:
+                s1 = gen_stage1(tmp, "resnet50", "stage1_rn50", {})
+            gen_stage2(tmp, s1, {"full5": ([5678], 5, 401, [synth.QUERY_SIZES[5678 % 5]])})
         if only in ("", "trainbase"):
             gen_train_step_baseline(tmp)
         if only in ("", "trainvgg"):
@@ -576,6 +619,8 @@ def main():
             gen_train_step_stage2(tmp, shot=5, seeds=(41, 42), out="stage2_rn50cm_trainstep5")
         if only in ("", "metric"):
             gen_metric()
+        if only in ("", "metric"):
+            gen_metric_coco()
         if only in ("", "cedt"):
             gen_cedt()
         if only in ("", "facts"):

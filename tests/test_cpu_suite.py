@@ -222,6 +222,59 @@ def test_metric_matches_the_reference_module():
     assert acc.mean("n") == float(g["acc_n"])
 
 
+def test_coco20i_metric_matches_the_reference_module():
+    """COCO-20i (BASELINE.json configs[4]): 80 classes -> an [81, 3] table, validation labels split*20+1 .. split*20+20
+    (reference core/metrics.py:7, data_kits/datasets.py:99-100); oracle and product vs the reference's own numbers."""
+    from oracle import ref_cpu
+    from pemp_amd.core.metrics import FewShotMetric
+    from pemp_amd.data_kits.datasets import get_class_name, get_val_labels, num_classes
+    from tests.golden.make_golden import metric_cases_coco
+    g = util.gold("metric_reference_coco")
+    n = num_classes("COCO")
+    assert n == 80 and num_classes("PASCAL") == 20
+    a, b = ref_cpu.FewShotMetric(n), FewShotMetric(n)
+    for pred, ref, cls in metric_cases_coco():
+        a.update(pred, ref, cls)
+        b.update(pred, ref, cls)
+    assert b.stat.shape == (81, 3) and np.array_equal(a.stat, g["stat"]) and np.array_equal(b.stat, g["stat"])
+    labels = get_val_labels(1, "COCO")
+    assert labels == g["labels"].tolist() == list(range(21, 41))
+    for m in (lambda *x, **k: a.miou(*x, **k), b.mIoU):
+        c, mean = m(labels)
+        cb, meanb = m(labels, binary=True)
+        assert np.isfinite(c).all() and np.array_equal(c, g["miou_c"]) and mean == float(g["miou"])
+        assert np.array_equal(cb, g["biou_c"]) and meanb == float(g["biou"])
+    assert [get_val_labels(s, "COCO")[0] for s in range(4)] == [1, 21, 41, 61] and get_val_labels(3, "COCO")[-1] == 80
+    assert get_val_labels(2, "PASCAL") == [11, 12, 13, 14, 15]
+    assert get_class_name(1, "COCO") == "person" and get_class_name(80, "COCO") == "toothbrush" and get_class_name(21, "COCO") == "bicycle"
+    with pytest.raises(ValueError):
+        get_val_labels(0, "ADE20K")
+
+
+def test_coco20i_synthetic_episodes_cover_the_label_set():
+    """Every validation label of a COCO-20i split receives episodes (a round of >= 20 consecutive seeds hits all 20),
+    ground-truth sizes follow the COCO picture formats up to 640 x 640; PASCAL draws are unchanged (digest above)."""
+    from pemp_amd import synth
+    from pemp_amd.entry import pemp_stage1 as e1
+    for split in (0, 3):
+        data = e1.SyntheticEpisodes(40, 5678, shot=1, split=split, height=33, width=33, dataset="COCO")
+        data.reset_sampler()
+        data.sample_tasks()
+        seen, sizes = set(), set()
+        for i in range(40):
+            _, qry_msk, cls = data.task(i)
+            seen.add(int(cls[0]))
+            sizes.add(tuple(qry_msk.shape[-2:]))
+        assert seen == set(e1.get_val_labels(split, "COCO")) and len(seen) == 20
+        assert sizes <= set(synth.QUERY_SIZES_COCO) and (640, 640) in sizes
+    dec = e1.SyntheticDecodedEpisodes(40, 5678, 1, 2, dataset="COCO")
+    dec.sample_tasks()
+    assert {dec.decoded_task(i)[2] for i in range(40)} == set(range(41, 61))
+    assert synth.make_episode(7, height=17, width=17, split=1)["cls"] == 6 + 7 % 5          # PASCAL: split*5+1+seed%5
+    with pytest.raises(ValueError):
+        e1.SyntheticEpisodes(4, 1, 1, 0, dataset="LVIS")
+
+
 # ---------------------------------------------------------------------------------------------
 # host mirrors
 # ---------------------------------------------------------------------------------------------

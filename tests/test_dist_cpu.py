@@ -159,3 +159,53 @@ def test_two_rank_gradient_bucket_allreduce_and_broadcast():
         g, scale, w = got[r]
         assert scale == 0.5 and np.array_equal(g, base * 3) and np.array_equal(g * scale, base * 1.5)   # mean of ranks
     assert np.array_equal(got[0][2], got[1][2])                                                        # same weights
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py --gpus N starts its own ranks (no external launcher); PEMP_BENCH_DRYRUN stands in for the GPU step
+# ---------------------------------------------------------------------------------------------
+def _run_bench(extra_env, *argv):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PEMP_BENCH_DRYRUN="1", PEMP_BENCH_BACKEND="gloo", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=240)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) spawns two ranks, they rendezvous on 127.0.0.1,
+    and rank 0 prints exactly ONE JSON line with n_gpus = 2 -- for the eval and the train mode alike."""
+    import json
+    for mode in ("eval", "train"):
+        r = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["config"]["mode"] == mode
+        # MAX over ranks: rank 1 sleeps twice as long per step as rank 0 (4 ms vs 2 ms)
+        assert out["ms_per_step"] >= 3.9
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """A rank that dies makes the whole job exit non-zero (the surviving rank is blocked in the rendezvous / a barrier
+    and is terminated by the launcher); nothing is printed as a result line."""
+    r = _run_bench({"PEMP_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "rank 1 exited" in r.stderr
+
+
+def test_bench_under_an_external_launcher_uses_its_world_size():
+    """Under torchrun-style environment variables bench.py does not spawn: a single rank with WORLD_SIZE=1 reports n_gpus 1."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PEMP_BENCH_DRYRUN="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1

@@ -78,3 +78,57 @@ def test_stage2_batched_evaluation_gives_identical_metrics(hip_lib, dev):
         res.append(ev.start_eval_loop(e2.SyntheticEpisodes(10, 5678, 1, split=0, height=97, width=97), 20, 0, te_epochs=1, batch=batch))
     (l0, m0, b0), (l1, m1, b1) = res
     assert l0 == l1 and np.array_equal(m0, m1) and np.array_equal(b0, b1)
+
+
+def test_coco20i_round_matches_cpu_oracle(hip_lib, dev):
+    """BASELINE.json configs[4] (COCO-20i 1-shot): a COCO-shaped round -- 40 episodes, every one of the split's 20
+    validation labels drawn, ground truth at the COCO picture formats up to 640x640, metric table [81, 3]
+    (reference data_kits/datasets.py:99-100, core/metrics.py:7) -- through the sharded evaluator (one episode per
+    step and 8 per step) versus the CPU oracle + the reference-style host metric.  |d mIoU|, |d bIoU| <= 1e-4,
+    every per-class IoU finite."""
+    from oracle import ref_cpu
+    from pemp_amd import synth
+    from pemp_amd.entry import pemp_stage1 as e1
+    from pemp_amd.networks import pemp_stage1 as m
+    n_eps, split = 40, 1                                   # split 1: labels 21..40 -- PASCAL-style ids would all be NaN
+    sd = util.wgen_state_dict("stage1_rn50")
+    net = m.ModelClass(None)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    nclass = e1.num_classes("COCO")
+    labels = e1.get_val_labels(split, "COCO")
+    assert nclass == 80 and labels == list(range(21, 41))
+    res = []
+    for batch in (1, 8):
+        data = e1.SyntheticEpisodes(n_eps, 5678, shot=1, split=split, dataset="COCO")
+        ev = e1.Evaluator(net, dev)
+        res.append(ev.start_eval_loop(data, nclass, split, te_epochs=1, batch=batch, dataset_name="COCO"))
+    (loss, miou_c, biou_c), (loss8, miou8, biou8) = res
+    assert loss == loss8 and np.array_equal(miou_c, miou8) and np.array_equal(biou_c, biou8)
+    assert np.asarray(miou_c).shape[-1] == 20 and np.isfinite(miou_c).all() and np.isfinite(biou_c).all()
+    torch.set_num_threads(16)
+    data = e1.SyntheticEpisodes(n_eps, 5678, shot=1, split=split, dataset="COCO")
+    data.reset_sampler()
+    data.sample_tasks()
+    metric = ref_cpu.FewShotMetric(nclass)
+    assert metric.stat.shape == (81, 3)
+    losses, seen, sizes = [], set(), set()
+    fwd = lambda a, b, c, hw: ref_cpu.stage1_forward(sd, a, b, c, hw)
+    with torch.no_grad():
+        for i in range(n_eps):
+            inputs, qry_msk, cls = data.task(i)
+            pred, l, _ = ref_cpu.test_step(fwd, inputs, qry_msk[0])
+            metric.update(pred, qry_msk[0].numpy(), cls.tolist())
+            losses.append(l)
+            seen.add(int(cls[0]))
+            sizes.add(tuple(qry_msk.shape[-2:]))
+    assert seen == set(labels) and (640, 640) in sizes and sizes <= set(synth.QUERY_SIZES_COCO)
+    ref_c, ref_miou = metric.miou(labels)
+    ref_biou = metric.miou(labels, binary=True)[1]
+    got_miou, got_biou = float(np.mean(miou_c)), float(np.mean(biou_c))
+    print(f"COCO-20i mIoU hip {got_miou:.6f} ref {ref_miou:.6f}  bIoU hip {got_biou:.6f} ref {ref_biou:.6f}  "
+          f"loss hip {loss:.6f} ref {np.mean(losses):.6f}")
+    assert np.isfinite(ref_c).all()
+    assert abs(got_miou - ref_miou) <= 1e-4 and abs(got_biou - ref_biou) <= 1e-4
+    assert np.abs(np.asarray(miou_c).reshape(-1) - ref_c).max() <= 2e-4
+    assert abs(loss - float(np.mean(losses))) <= 1e-4

@@ -4,10 +4,12 @@ seeded episodes.
 
 Stated tolerances (fp32 everywhere; only the summation order differs from the reference):
   features : |d| <= 1e-3 * (1 + |ref|)      (13 residual blocks of K<=2304 contractions)
-  logits   : |d| <= 5e-3  (logits are 20*cos, range ~[14,20])
-  argmax   : >= 99.8 % pixel agreement, |d mIoU-style IoU| <= 2e-3 on a single episode
-             (the 1e-4 mIoU bar of north_star is checked on the aggregated metric in
-             test_eval_protocol_miou).
+  logits   : |d| <= 2e-4  (util.LOGIT_TOL; logits are 20*cos, range ~[14,20]; measured ~2e-5)
+  indices  : arg-max class and response index are held to EXACT agreement wherever the decision margin (lead of the
+             winner over the runner-up) exceeds 4e-4 = 2 * the logit tolerance; the pixels inside the margin are
+             excluded, their fraction is printed and bounded (util.assert_argmax_exact / assert_response_exact)
+  IoU      : |d IoU| <= 2e-3 on a single episode (the 1e-4 mIoU bar of north_star is checked on the aggregated
+             metric in test_eval_protocol_gpu.py).
 """
 import numpy as np
 import pytest
@@ -51,27 +53,27 @@ def test_stage1_matches_reference_golden(model, dev, fixture):
         # logits
         lref = torch.from_numpy(g[f"e{e}_logits_s7"])
         lerr = (logits[0, :, ::7, ::7] - lref).abs().max().item()
-        assert lerr < 5e-3, f"{fixture} e{e}: logit err {lerr}"
+        assert lerr < util.LOGIT_TOL, f"{fixture} e{e}: logit err {lerr}"
         if H <= 97:
-            assert (logits[0] - torch.from_numpy(g[f"e{e}_logits"])).abs().max().item() < 5e-3
-        # argmax / counts / loss
+            assert (logits[0] - torch.from_numpy(g[f"e{e}_logits"])).abs().max().item() < util.LOGIT_TOL
+        # argmax (exact outside the margin) / counts / loss
         am = logits.argmax(1).numpy().astype(np.uint8)
         ref_bits = np.unpackbits(g[f"e{e}_argmax_bits"])[: am.size].reshape(am.shape)
-        agree = (am == ref_bits).mean()
-        assert agree >= 0.998, f"{fixture} e{e}: argmax agreement {agree}"
+        masked = util.assert_argmax_exact(logits, ref_bits, what=f"{fixture} e{e}")
         cn = util.counts(am[0], t["qry_mask"][0].cpu().numpy())
         rc = g[f"e{e}_counts"]
         iou = lambda c: c[1, 0] / max(1, c[1].sum())
         assert abs(iou(cn) - iou(rc)) <= 2e-3
         loss = torch.nn.functional.cross_entropy(logits, t["qry_mask"].cpu(), ignore_index=255).item()
         assert abs(loss - float(g[f"e{e}_loss"])) < 1e-4
-        # response map: the fg/bg group must agree; the index inside a group may differ where two
-        # meta-prototypes coincide (exact ties in the reference, e.g. two centres that attract no
-        # pixel pool to the same vector) -- there the first-max rule amplifies 1-ulp differences.
+        # response map: exact wherever the winning prototype leads by more than the margin.  Where two meta-prototypes
+        # coincide (centres that attract no pixel pool to the same vector: exact ties in the reference) the margin is
+        # 0 and the first-max rule amplifies 1-ulp differences -- those pixels are the masked ones.
         rref = g[f"e{e}_resp_s7"]
         rgot = resp[0, ::7, ::7].cpu().numpy()
-        assert ((rgot >= 3) == (rref >= 3)).mean() > 0.995
-        assert (rgot == rref).mean() > 0.85
+        _, margin = util.response_reference(model._last_feats, t["sup_mask"], model.ctr, 1, shot, 3, 20, hw)
+        rmask = util.assert_response_exact(rgot, rref, margin[0, ::7, ::7], what=f"{fixture} e{e}")
+        print(f"{fixture} e{e}: |dlogit| {lerr:.2e}  argmax pixels inside the margin {masked:.5f}  response {rmask:.4f}")
 
 
 def test_stage1_matches_cpu_oracle_batched(model, dev):
@@ -85,8 +87,10 @@ def test_stage1_matches_cpu_oracle_batched(model, dev):
         ref, rresp = ref_cpu.stage1_forward(sd, sup, msk, qry, (71, 113), ret_ind=True)
         got, gresp = model(sup.to(dev), msk.to(dev), qry.to(dev), (71, 113), ret_ind=True)
     assert got.shape == ref.shape and gresp.shape == rresp.shape and gresp.dtype == torch.int64
-    assert (got.cpu() - ref).abs().max().item() < 5e-3
-    assert (got.cpu().argmax(1) == ref.argmax(1)).float().mean().item() > 0.998
+    assert (got.cpu() - ref).abs().max().item() < util.LOGIT_TOL
+    util.assert_argmax_exact(got, ref.argmax(1), what="batched")
+    _, margin = util.response_reference(model._last_feats, msk, model.ctr, 2, 2, 3, 20, (71, 113))
+    util.assert_response_exact(gresp, rresp, margin, what="batched")
 
 
 def test_stage1_non_square_and_odd_sizes(model, dev):
@@ -103,8 +107,8 @@ def test_stage1_non_square_and_odd_sizes(model, dev):
             ref = ref_cpu.stage1_forward(sd, sup, msk, qry, out)
             got = model(sup.to(dev), msk.to(dev), qry.to(dev), out)
         assert got.shape == ref.shape
-        assert (got.cpu() - ref).abs().max().item() < 5e-3, (H, W)
-        assert (got.cpu().argmax(1) == ref.argmax(1)).float().mean().item() > 0.998
+        assert (got.cpu() - ref).abs().max().item() < util.LOGIT_TOL, (H, W)
+        util.assert_argmax_exact(got, ref.argmax(1), max_masked=0.02, what=f"{H}x{W}")
 
 
 def test_stage1_default_out_shape_and_errors(model, dev):

@@ -2,13 +2,15 @@
 produced (tests/golden/stage1_rn50_trainstep.npz: model.train(), batch-stat BN, DropBlock off) and
 (b) torch SGD semantics for the update.
 
-Tolerances: loss 2e-5; per-parameter gradient norms 5e-3 relative (tiny-norm tensors: 1e-5 absolute);
-sampled gradient tensors within 1.5e-2 * max|g| of BOTH the reference's fp32 gradients and an fp64
-evaluation of the same step (tests/golden/stage1_rn50_trainstep_f64.npz, oracle in double precision).
-The fp32 reference itself sits 4.5e-3..5.7e-3 * max|g| away from that fp64 result on the early-layer
-weights (back-propagation through 50 batch-statistics BatchNorms on a 2-episode batch is that
-ill-conditioned), so this is the resolution the comparison has; every kernel is checked separately
-at 1e-5..1e-4 in test_train_ops_gpu.py."""
+Tolerances: loss 2e-5; gradients are held to an fp64-RELATIVE bound: with g64 the same step evaluated in double
+precision (tests/golden/*_trainstep*_f64.npz, oracle under autograd) and ref32 the reference's own fp32 gradients,
+every sampled tensor must satisfy  max|hip - g64| <= 2 * max|ref32 - g64| + 5e-4 * max|g64|  -- i.e. the HIP path may
+sit at most twice as far from the exact gradient as the reference's own fp32 arithmetic does (the reference is
+4.5e-3..5.7e-3 * max|g| away on the early-layer weights: back-propagation through 50 batch-statistics BatchNorms is
+that ill-conditioned; 1e-5..1e-4 on the head).  Per-parameter gradient NORMS the same way (all 148 tensors).
+Run at the fixture size (2 episodes, 97x97) and at the shape BASELINE.json configs[2] trains at (4 episodes,
+401x401: 128x128 wgrad tiles, split-M reduce at M = 20.8k, ...).  Every kernel is checked separately at 1e-5..1e-4
+in test_train_ops_gpu.py."""
 import numpy as np
 import pytest
 import torch
@@ -26,40 +28,33 @@ def _trainer(dev, **kw):
     return Stage1Trainer(net, device=dev, drop_rate=0.0, **kw), net
 
 
-def _batch(dev):
+def _batch(dev, seeds=(31, 32), H=97, shot=1):
     from pemp_amd import synth
-    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    b = synth.make_batch(list(seeds), shot=shot, height=H, width=H, out_hw=(H, H))
     t = lambda a: torch.from_numpy(a).to(dev)
     return t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0])
 
 
-@pytest.mark.parametrize("head", ["hip", "torch"])
-def test_train_step_gradients_match_reference(hip_lib, dev, head):
-    """head="hip": the whole step on libpemp_hip.so; head="torch": encoder on HIP, head by autograd (cross-check)."""
-    from pemp_amd import ops
-    g = util.gold("stage1_rn50_trainstep")
-    g64 = util.gold("stage1_rn50_trainstep_f64")
-    tr, net = _trainer(dev)
-    sup, msk, qry, gt = _batch(dev)
-    if head == "hip":
-        loss, pred = tr.forward_backward(sup, msk, qry, gt)
-        logits = ops.upsample_bilinear_ac(pred, (97, 97))
-    else:
-        loss, logits = util.torch_head_step(tr, sup, msk, qry, gt)
-    torch.cuda.synchronize()
-    assert abs(loss.item() - float(g["loss"])) < 2e-5
-    assert (logits.cpu()[:, :, ::7, ::7].numpy() - g["logits_s7"]).__abs__().max() < 5e-3
-    params = dict(net.named_parameters())
-    bad = []
-    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+def _fixture_batch(g, dev):
+    seeds = [int(v) for v in g["seeds"]] if "seeds" in g.files else [31, 32]
+    H = int(g["H"]) if "H" in g.files else 97
+    shot = int(g["shot"]) if "shot" in g.files else 1
+    return _batch(dev, seeds, H, shot), seeds, H, shot
+
+
+def _check_gradients(g, g64, params, what):
+    """fp64-relative bound on all gradient norms and on the sampled gradient tensors (module docstring)."""
+    bad, worst = [], 0.0
+    for name, ref, ref64 in zip(g["grad_names"], g["grad_norms"], g64["grad_norms64"]):
         p = params[str(name)]
         if ref < 0:
-            assert not p.requires_grad
+            assert not p.requires_grad, name
             continue
+        assert p.requires_grad, name
         got = p.grad.norm().item()
-        if abs(got - ref) > 5e-3 * ref + 1e-5:
-            bad.append((str(name), got, float(ref)))
-    assert not bad, bad[:10]
+        if abs(got - ref64) > 2 * abs(ref - ref64) + 1e-3 * ref64 + 1e-6:
+            bad.append((str(name), got, float(ref), float(ref64)))
+    assert not bad, (what, bad[:10])
     for key in [k for k in g.files if k.startswith("grad__")]:
         name = key[len("grad__"):]
         got = params[name].grad.cpu()
@@ -67,8 +62,35 @@ def test_train_step_gradients_match_reference(hip_lib, dev, head):
         got = (got if got.numel() <= 40000 else got.reshape(-1)[::37]).reshape(ref.shape)
         ref64 = torch.from_numpy(g64["g64__" + name])
         scale = ref64.abs().max().item()
-        assert (got - ref).abs().max().item() <= 1.5e-2 * scale + 1e-7, name
-        assert (got.double() - ref64).abs().max().item() <= 1.5e-2 * scale + 1e-7, name
+        e_ref = (ref.double() - ref64).abs().max().item()
+        e_hip = (got.double() - ref64).abs().max().item()
+        bound = 2 * e_ref + 5e-4 * scale + 1e-7
+        worst = max(worst, e_hip / bound)
+        print(f"{what} {name:50s} |hip-f64| {e_hip / max(scale, 1e-30):.2e}  |ref32-f64| {e_ref / max(scale, 1e-30):.2e}  (x max|g|)")
+        assert e_hip <= bound, (what, name, e_hip, e_ref, scale)
+    return worst
+
+
+@pytest.mark.parametrize("head,fixture", [("hip", "stage1_rn50_trainstep"), ("torch", "stage1_rn50_trainstep"),
+                                          ("hip", "stage1_rn50_trainstep_full")])
+def test_train_step_gradients_match_reference(hip_lib, dev, head, fixture):
+    """head="hip": the whole step on libpemp_hip.so; head="torch": encoder on HIP, head by autograd (cross-check).
+    ``_full``: BASELINE.json configs[2]'s per-rank step -- 4 episodes, 401x401 -- against the reference's gradients."""
+    from pemp_amd import ops
+    g = util.gold(fixture)
+    g64 = util.gold(fixture + "_f64")
+    tr, net = _trainer(dev)
+    (sup, msk, qry, gt), _, H, _ = _fixture_batch(g, dev)
+    if head == "hip":
+        loss, pred = tr.forward_backward(sup, msk, qry, gt)
+        logits = ops.upsample_bilinear_ac(pred, (H, H))
+    else:
+        loss, logits = util.torch_head_step(tr, sup, msk, qry, gt)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    assert (logits.cpu()[:, :, ::7, ::7].numpy() - g["logits_s7"]).__abs__().max() < 1e-3
+    params = dict(net.named_parameters())
+    _check_gradients(g, g64, params, fixture)
     sd = net.state_dict()
     for key in [k for k in g.files if k.startswith("buf__")]:
         name = key[len("buf__"):]
@@ -151,54 +173,38 @@ def test_baseline_train_step_matches_reference(hip_lib, dev, backbone, tag):
         assert torch.allclose(p.detach(), r.detach(), rtol=1e-6, atol=1e-7)
 
 
-def _stage2_trainer(dev, **kw):
+def _stage2_trainer(dev, shot=1, **kw):
     from pemp_amd.networks import pemp_stage2 as m
     from pemp_amd.train_stage2 import Stage2Trainer
-    net = m.ModelClass(1, 1, None)
+    net = m.ModelClass(shot, 1, None)
     net.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
     return Stage2Trainer(None, net, device=dev, **kw), net
 
 
-def test_stage2_train_step_matches_reference(hip_lib, dev):
+@pytest.mark.parametrize("fixture", ["stage2_rn50cm_trainstep", "stage2_rn50cm_trainstep5_full"])
+def test_stage2_train_step_matches_reference(hip_lib, dev, fixture):
     """Stage 2 (4-channel stem, communication modules as per-image conv bias with explicit backward through the
     Linear / episode mean / masked mean+max statistics, trainable block BNs, ASPP without BN) vs the gradients
-    the reference produced (tests/golden/stage2_rn50cm_trainstep.npz; Dropout2d off) and their fp64 evaluation."""
+    the reference produced (tests/golden/stage2_rn50cm_trainstep*.npz; Dropout2d off) and their fp64 evaluation.
+    ``_full``: one 5-shot episode at 401x401 (BASELINE.json configs[3]: 6 images, CM statistics at 101 x 101).
+    (linear*: with one episode per batch the communication module's output is constant over the batch and the
+    following batch-statistics BN removes it -- exact gradient 0, fp32 rounding noise on both sides.)"""
     from pemp_amd import ops
     from tests.golden.make_golden import stage2_train_prior
     from pemp_amd import synth
-    g = util.gold("stage2_rn50cm_trainstep")
-    g64 = util.gold("stage2_rn50cm_trainstep_f64")
-    tr, net = _stage2_trainer(dev, drop_rate2=0.0)
-    sup, msk, qry, gt = _batch(dev)
-    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    g = util.gold(fixture)
+    g64 = util.gold(fixture + "_f64")
+    (sup, msk, qry, gt), seeds, H, shot = _fixture_batch(g, dev)
+    tr, net = _stage2_trainer(dev, drop_rate2=0.0, shot=shot)
+    b = synth.make_batch(seeds, shot=shot, height=H, width=H, out_hw=(H, H))
     prior = torch.from_numpy(stage2_train_prior(b["qry_mask"])).to(dev)
     loss, pred = tr.forward_backward(sup, msk, qry, gt, prior)
-    logits = ops.upsample_bilinear_ac(pred, (97, 97))
+    logits = ops.upsample_bilinear_ac(pred, (H, H))
     torch.cuda.synchronize()
     assert abs(loss.item() - float(g["loss"])) < 2e-5
-    assert (logits.cpu()[:, :, ::7, ::7].numpy() - g["logits_s7"]).__abs__().max() < 5e-3
+    assert (logits.cpu()[:, :, ::7, ::7].numpy() - g["logits_s7"]).__abs__().max() < 1e-3
     params = dict(net.named_parameters())
-    bad = []
-    for name, ref, ref64 in zip(g["grad_names"], g["grad_norms"], g64["grad_norms64"]):
-        p = params[str(name)]
-        if ref < 0:
-            assert not p.requires_grad, name
-            continue
-        assert p.requires_grad, name
-        got = p.grad.norm().item()
-        # linear*.bias: a constant shift of a pre-BatchNorm activation has zero gradient (1e-9 of rounding in fp32)
-        if abs(got - ref) > 5e-3 * ref + 1e-5 and abs(got - ref64) > 5e-3 * ref64 + 1e-5:
-            bad.append((str(name), got, float(ref), float(ref64)))
-    assert not bad, bad[:10]
-    for key in [k for k in g.files if k.startswith("grad__")]:
-        name = key[len("grad__"):]
-        got = params[name].grad.cpu()
-        ref = torch.from_numpy(g[key])
-        got = (got if got.numel() <= 40000 else got.reshape(-1)[::37]).reshape(ref.shape)
-        ref64 = torch.from_numpy(g64["g64__" + name])
-        scale = max(ref64.abs().max().item(), 1e-6)
-        assert (got - ref).abs().max().item() <= 5e-3 * scale + 1e-7, name
-        assert (got.double() - ref64).abs().max().item() <= 5e-3 * scale + 1e-7, name
+    _check_gradients(g, g64, params, fixture)
     sd = net.state_dict()
     for key in [k for k in g.files if k.startswith("buf__")]:
         name = key[len("buf__"):]

@@ -111,3 +111,67 @@ def torch_head_step(tr, sup_img, sup_mask, qry_img, qry_msk):
         ctr.grad.copy_(grads[1])
     eng.backward(grads[0].contiguous())
     return loss.detach(), logits.detach()
+
+
+# ---------------------------------------------------------------------------------------------
+# margin-aware exactness for index outputs (arg-max class, response index): where the winner leads the runner-up
+# by more than the float noise between two fp32 summation orders the indices must agree EXACTLY; pixels inside
+# the margin are excluded and their fraction reported / bounded
+# ---------------------------------------------------------------------------------------------
+LOGIT_TOL = 2e-4          # |d logit| bound the end-to-end tests state (logits are 20 * cos, |.| <= 20; measured ~2e-5)
+MARGIN = 2 * LOGIT_TOL    # two values that each moved by <= LOGIT_TOL cannot swap order beyond this lead
+
+
+def assert_argmax_exact(logits, ref_argmax, margin=MARGIN, max_masked=0.01, what=""):
+    """logits [B,2,H,W] (ours), ref_argmax [B,H,W] (reference).  Exact agreement outside the margin."""
+    logits = logits.detach().cpu()
+    ref_argmax = torch.as_tensor(np.asarray(ref_argmax)).long()
+    lead = (logits[:, 1] - logits[:, 0]).abs()
+    keep = lead > margin
+    am = logits.argmax(1)
+    wrong = int(((am != ref_argmax) & keep).sum())
+    masked = 1.0 - keep.float().mean().item()
+    assert wrong == 0, f"{what}: {wrong} arg-max mismatches outside the {margin:g} margin"
+    assert masked <= max_masked, f"{what}: {masked:.4f} of the pixels inside the margin"
+    return masked
+
+
+def response_reference(feats_nhwc, sup_mask, ctr, B, S, protos, dist_scalar, out_hw):
+    """Response index + its decision margin by the reference's formulas (networks/pemp_stage1.py:195-222,232-261)
+    evaluated on OUR feature map (so that only the head's own rounding is in play): returns (response int64
+    [B,Ho,Wo], margin f32 [B,Ho,Wo]) at the output size (nearest upsample, pemp_stage1.py:162).  margin = the
+    smaller of: lead of the winning prototype inside the winning class, lead of the winning class."""
+    from oracle import ref_cpu
+    f = feats_nhwc.detach().cpu().permute(0, 3, 1, 2).contiguous()
+    n, c, h, w = f.shape
+    Q = n // B - S
+    sup_f, qry_f = f[:B * S].view(B, S, c, h, w), f[B * S:].view(B, Q, c, h, w)     # images are [all supports | all queries]
+    H, W = sup_mask.shape[-2:]
+    m = F.interpolate(sup_mask.detach().cpu().reshape(B * S, 2, H, W), (h, w), mode="nearest")
+    fg, bg = m.unbind(dim=1)
+    _, _, ap = ref_cpu.mpm(sup_f, qry_f, fg, bg, ctr.detach().cpu(), protos, dist_scalar, True)
+    fgp, bgp = ap.view(B, c, 2, protos).unbind(dim=2)                      # adaptive_p = [B, c, (fg|bg) x p]
+    sim = ref_cpu.compute_similarity(fgp, bgp, qry_f.reshape(-1, c, 1, h, w), dist_scalar)     # [B,2,p,h,w] (bg, fg)
+    top = sim.topk(2, dim=2)
+    vals, idx = top.values, top.indices
+    cls = (vals[:, 1, 0] > vals[:, 0, 0]).long()                            # ties -> class 0, as argmax does
+    inner = vals[:, :, 0] - vals[:, :, 1]                                   # [B,2,h,w]
+    pick = lambda t: torch.where(cls == 1, t[:, 1], t[:, 0])
+    resp = pick(idx[:, :, 0]) + 3 * cls
+    margin = torch.minimum(pick(inner), (vals[:, 1, 0] - vals[:, 0, 0]).abs())
+    up = lambda t: F.interpolate(t[:, None].float(), tuple(out_hw), mode="nearest")[:, 0]
+    return up(resp).long(), up(margin)
+
+
+def assert_response_exact(resp_got, resp_ref, margin_map, margin=MARGIN, what="", max_masked=0.35):
+    """Exact agreement of the response index wherever its decision margin exceeds ``margin``.  Returns the masked
+    fraction (coinciding meta-prototypes -- centres that attract no pixel pool to the same vector -- give exact ties
+    over whole regions; those are the masked pixels)."""
+    resp_got = torch.as_tensor(np.asarray(resp_got.cpu() if hasattr(resp_got, "cpu") else resp_got)).long()
+    resp_ref = torch.as_tensor(np.asarray(resp_ref)).long()
+    keep = margin_map > margin
+    wrong = int(((resp_got != resp_ref) & keep).sum())
+    masked = 1.0 - keep.float().mean().item()
+    assert wrong == 0, f"{what}: {wrong} response-index mismatches outside the {margin:g} margin"
+    assert masked <= max_masked, f"{what}: {masked:.4f} of the response pixels inside the margin"
+    return masked
