@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 OUT = os.path.join(HERE, "libpemp_hip.so")
-SOURCES = ("conv_igemm.hip", "conv_dma.hip", "conv_wgrad.hip", "train_ops.hip", "pool_misc.hip", "head.hip", "head_bwd.hip", "cedt.hip",
+SOURCES = ("conv_igemm.hip", "conv_dma.hip", "conv_dma2.hip", "conv_wgrad.hip", "train_ops.hip", "pool_misc.hip", "head.hip", "head_bwd.hip", "cedt.hip",
            "episode_io.hip", "dropout.hip", "cm_linear.hip")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 

@@ -84,5 +84,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
 
 // conv_dma.hip
 int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st);
+// conv_dma2.hip
+bool conv_dma2_supported(const ConvArgs& a);
+int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st);
 
 }  // namespace pemp

@@ -1,0 +1,287 @@
+// Implicit-GEMM convolution, second LDS-DMA variant: the same GEMM view, LDS image, fragment reads, MFMA order and
+// epilogue as conv_dma.hip (results are bit-identical), with the two things that kept the MFMA pipe idle there removed:
+//
+//  * Operand addressing.  conv_dma.hip rebuilds a 64-bit source pointer per row every K step (bounds tests, a 64-bit
+//    multiply-add, a select against the zero block: ~100 VALU/SALU instructions per wave per step, executed by both
+//    waves of a SIMD at the same moment right after the barrier).  Here both operands are fetched with
+//    `buffer_load_dwordx4 ... offen lds`: a per-lane BYTE OFFSET that never changes during the K loop plus a
+//    wave-uniform SGPR offset that carries the whole K-step dependence (tap displacement + channel chunk for the
+//    activations, K offset for the weights).  Which taps of a row fall outside the image is decided ONCE per tile
+//    (one bit per tap); an out-of-image tap replaces the lane's offset by 2^31, the buffer range check (num_records =
+//    2 GiB) then makes the hardware write zeros -- zero padding without a zero block, 3 VALU instructions per row
+//    and step.  (The base of the activation descriptor is moved back by pad rows + pad pixels so that every
+//    in-image offset is non-negative.)
+//
+//  * Barrier placement.  One barrier per K step as before, but it sits BEFORE the last quarter of the step's MFMAs,
+//    whose operands are already in registers: after the barrier a wave issues the first fragment reads of the next
+//    step and the LDS-DMA of the step after that in the shadow of those 4*TM*TN MFMAs, instead of starting every
+//    step with address arithmetic + a dozen LDS reads + a full wait while the matrix pipe drains.
+//
+// Not handled here (conv_dma.hip keeps them): the NHWC4 stem (a K step spans 8 taps, the tap differs per lane), a
+// per-channel padding VALUE (padv), more than 32 taps, operands of 2 GiB or more.
+#include "conv_common.h"
+
+namespace pemp {
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WGM, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the launch stub (buffer-resource builtins / "s" asm operands are device-only)
+    constexpr int WGN = NW / WGM;
+    constexpr int RPI = NW * 8;                 // rows covered by one DMA instruction round of the block
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AL = BM / RPI, BL = BN / RPI; // DMA wave-instructions per thread per K step
+    constexpr int NMF = TM * TN * 4, NDS = TM + TN, NDMA = AL + BL;      // per quarter step: MFMAs, fragment reads; DMAs per step
+    constexpr int PER = (NDS + NDMA + NMF - 1) / NMF;
+
+    extern __shared__ __attribute__((aligned(16))) v4f smem[];
+    v4f* As = smem;                      // [2][BM][8]
+    v4f* Bs = smem + 2 * BM * 8;         // [2][BN][8]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WGN) * WM;
+    const int wn0 = (wave % WGN) * WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const int ntn = a.Cout / BN;
+    const int tile_id = xcd_tile_order(blockIdx.x, gridDim.x);
+    const int bm = tile_id / ntn;
+    const int bn = tile_id % ntn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // loader role: thread (r, p) fetches, for rows r + RPI i, the quad that belongs at position p (see conv_dma.hip)
+    const int p = tid & 7;
+    const int r = tid >> 3;
+    const int sq = p ^ ((r >> 1) & 7);
+
+    const int bias_pix = a.pad * a.W + a.pad;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - (ptrdiff_t)bias_pix * a.ldx), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x80000000u, 0x00020000);
+
+    unsigned a_voff[AL], a_inv[AL], b_voff[BL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int m = m0 + r + RPI * i;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int img = mm / a.HoWo;
+        const int rem = mm - img * a.HoWo;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        const int hi0 = ho * a.stride - a.pad;
+        const int wi0 = wo * a.stride - a.pad;
+        a_voff[i] = (unsigned)(((img * a.H + hi0) * a.W + wi0 + bias_pix) * a.ldx + sq * 4) * 4u;
+        unsigned mask = 0;
+        int kh = 0, kw = 0;
+        for (int t = 0; t < a.ntaps; ++t) {
+            const int hi = hi0 + kh * a.dil, wi = wi0 + kw * a.dil;
+            if (ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) mask |= 1u << t;
+            if (++kw == a.KW) {
+                kw = 0;
+                ++kh;
+            }
+        }
+        a_inv[i] = ~mask;
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) b_voff[i] = (unsigned)((n0 + r + RPI * i) * a.Kpad + sq * 4) * 4u;
+
+    // wave-uniform K-step state.  Multi-tap convs: channel chunk OUTER, tap INNER (same order as every other conv
+    // kernel of the library: variants stay bit-identical); 1x1: chunks in sequence.
+    int tap = 0, cb = 0, kh_i = 0, kw_i = 0;
+    const int tapw = a.dil * a.ldx * 4, taph = a.dil * a.W * a.ldx * 4;     // byte displacement of one tap step
+
+#define PEMP_DMA2(buf_)                                                                                           \
+    do {                                                                                                          \
+        v4f* Ad_ = As + (buf_) * BM * 8 + wave * 64;                                                              \
+        v4f* Bd_ = Bs + (buf_) * BN * 8 + wave * 64;                                                              \
+        const int sa_ = kh_i * taph + kw_i * tapw + cb * 128;                                                     \
+        const int sb_ = (tap * a.Cin + cb * 32) * 4;                                                              \
+        const int sh_ = 31 - tap;                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                                          \
+            const unsigned vo_ = ((int)(a_inv[i] << sh_) < 0) ? 0x80000000u : a_voff[i];                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(Ad_ + i * RPI * 8), 16, vo_, sa_, 0, 0);        \
+        }                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < BL; ++i)                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(Bd_ + i * RPI * 8), 16, b_voff[i], sb_, 0, 0);  \
+    } while (0)
+
+    // branch-free and pinned to the scalar unit (inline asm: hipcc otherwise turns the selects into VALU code, the
+    // SGPR offsets of the DMA instructions into VGPRs and every DMA into a readfirstlane loop); the steady-state
+    // K step must stay one basic block
+    const int multi = __builtin_amdgcn_readfirstlane(a.ntaps > 1 ? 1 : 0);
+    const int s_kw = __builtin_amdgcn_readfirstlane(a.KW), s_ntaps = __builtin_amdgcn_readfirstlane(a.ntaps);
+#define PEMP_ADVANCE2()                                                                                           \
+    do {                                                                                                          \
+        int wt_;                                                                                                  \
+        asm volatile(                                                                                             \
+            "s_add_u32 %0, %0, %5\n\t"      /* tap += multi                      */                                \
+            "s_add_u32 %2, %2, %5\n\t"      /* kw  += multi                      */                                \
+            "s_cmp_eq_u32 %2, %6\n\t"       /* kw == KW ?                        */                                \
+            "s_cselect_b32 %2, 0, %2\n\t"   /*   kw = 0                          */                                \
+            "s_addc_u32 %1, %1, 0\n\t"      /*   kh += 1                         */                                \
+            "s_xor_b32 %4, %5, 1\n\t"       /* 1x1: wrap every step              */                                \
+            "s_cmp_eq_u32 %0, %7\n\t"       /* tap == ntaps ?                    */                                \
+            "s_cselect_b32 %4, 1, %4\n\t"                                                                          \
+            "s_cmp_lg_u32 %4, 0\n\t"                                                                               \
+            "s_cselect_b32 %0, 0, %0\n\t"   /*   tap = kh = kw = 0, next channel chunk */                          \
+            "s_cselect_b32 %1, 0, %1\n\t"                                                                          \
+            "s_cselect_b32 %2, 0, %2\n\t"                                                                          \
+            "s_addc_u32 %3, %3, 0"                                                                                \
+            : "+s"(tap), "+s"(kh_i), "+s"(kw_i), "+s"(cb), "=&s"(wt_)                                             \
+            : "s"(multi), "s"(s_kw), "s"(s_ntaps)                                                    \
+            : "scc");                                                                                             \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    PEMP_DMA2(0);
+    if (a.nk > 1) {
+        PEMP_ADVANCE2();
+        PEMP_DMA2(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AL + BL) : "memory");      // step 0 has landed, step 1 may still fly
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // fragment read positions: quad Q of row (.. + lr) sits at position Q ^ ((lr>>1)&7)
+    const int rsw = (lr >> 1) & 7;
+    const int arow = (wm0 + lr) * 8, brow = (wn0 + lr) * 8;
+    v4f af[2][TM], bf[2][TN];
+
+#define PEMP_READ(dst_, buf_, j_)                                                                                 \
+    do {                                                                                                          \
+        const v4f* Ab_ = As + (buf_) * BM * 8;                                                                    \
+        const v4f* Bb_ = Bs + (buf_) * BN * 8;                                                                    \
+        const int pos_ = (2 * (j_) + lh) ^ rsw;                                                                   \
+        _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) af[dst_][mi] = Ab_[arow + mi * 256 + pos_];             \
+        _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) bf[dst_][ni] = Bb_[brow + ni * 256 + pos_];             \
+    } while (0)
+
+#define PEMP_MMA(src_)                                                                                            \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) {     \
+            const v4f av = af[src_][mi], bv = bf[src_][ni];                                                       \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[mi][ni], 0, 0, 0);                 \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[mi][ni], 0, 0, 0);                 \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[mi][ni], 0, 0, 0);                 \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[mi][ni], 0, 0, 0);                 \
+        }                                                                                                         \
+    } while (0)
+
+    // One K step.  DMA_: issue the LDS-DMA of step kt+2 (into the buffer this step frees); NEXT_: read the first
+    // fragments of step kt+1.  The steady-state body has both and no branch, so that the scheduler can place the reads
+    // and the DMA issue between the MFMAs of the last quarter; the last two steps are peeled.
+#define PEMP_STEP(buf_, DMA_, NEXT_)                                                                              \
+    do {                                                                                                          \
+        PEMP_READ(1, buf_, 1);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_MMA(0);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_READ(0, buf_, 2);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_MMA(1);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_READ(1, buf_, 3);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_MMA(0);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        /* every LDS read of `buf` by this wave has returned; this wave's DMA pieces of step kt+1 have landed */  \
+        __builtin_amdgcn_s_waitcnt(0x0070);          /* vmcnt(0) lgkmcnt(0), visible to hipcc's own wait bookkeeping */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* (the LDS-DMA loads are not in that bookkeeping) */    \
+        __builtin_amdgcn_s_barrier();   /* ... everybody's: `buf` is free for step kt+2, `buf^1` holds step kt+1 */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if (NEXT_) PEMP_READ(0, (buf_) ^ 1, 0);                                                                   \
+        if (DMA_) {                                                                                               \
+            PEMP_ADVANCE2();                                                                                      \
+            PEMP_DMA2(buf_);                                                                                      \
+        }                                                                                                         \
+        PEMP_MMA(1);                    /* the last quarter of step kt covers the reads / DMA issue above */      \
+        if (DMA_) {                     /* ... placed BETWEEN its MFMAs: one LDS read / one DMA per MFMA slot */    \
+            _Pragma("unroll") for (int k_ = 0; k_ < NMF; ++k_) {                                                  \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+                _Pragma("unroll") for (int q_ = 0; q_ < PER; ++q_) {                                              \
+                    const int it_ = k_ * PER + q_;                                                                \
+                    if (it_ < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+                    else if (it_ < NDS + NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                 \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+
+    PEMP_READ(0, 0, 0);
+    int kt = 0;
+    for (; kt + 2 < a.nk; ++kt) {
+        const int buf = kt & 1;
+        PEMP_STEP(buf, true, true);
+    }
+    if (kt + 1 < a.nk) {
+        const int buf = kt & 1;
+        PEMP_STEP(buf, false, true);
+        ++kt;
+    }
+    {
+        const int buf = kt & 1;
+        PEMP_STEP(buf, false, false);
+    }
+#undef PEMP_STEP
+#undef PEMP_DMA2
+#undef PEMP_ADVANCE2
+#undef PEMP_READ
+#undef PEMP_MMA
+
+    // ---- epilogue: transpose through LDS.  No LDS read and no DMA is outstanding after the loop's last barrier. ----
+    conv_epilogue_lds<TM, TN>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
+#endif
+}
+
+template <int BM, int BN, int WGM, int NW>
+static int launch_dma2(const ConvArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
+    auto kern = conv_dma2_kernel<BM, BN, WGM, NW>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    const int grid = cdiv(a.M, BM) * (a.Cout / BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    return launch_status("conv_dma2");
+}
+
+// true when the geometry / operands fit this variant (the caller falls back to conv_dma.hip otherwise)
+bool conv_dma2_supported(const ConvArgs& a) {
+    if ((a.flags & PEMP_CONV_STEM4) || a.padv || a.ntaps > 32) return false;
+    const long long xbytes = ((long long)a.N * a.H * a.W + (long long)a.pad * a.W + a.pad + (long long)a.dil * (a.KH - 1) * a.W +
+                              (long long)a.dil * (a.KW - 1)) * a.ldx * 4;
+    const long long wbytes = (long long)a.Cout * a.Kpad * 4;
+    return xbytes < (1ll << 31) && wbytes < (1ll << 31);
+}
+
+int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st) {
+    if (tile == 7) return launch_dma2<256, 256, 4, 8>(a, st);
+    if (tile == 6) return launch_dma2<256, 128, 4, 8>(a, st);
+    if (tile == 4) return launch_dma2<128, 128, 4, 8>(a, st);
+    if (tile == 5) return launch_dma2<128, 64, 4, 8>(a, st);
+    if (tile == 1) return launch_dma2<128, 128, 2, 4>(a, st);
+    if (tile == 2) return launch_dma2<128, 64, 2, 4>(a, st);
+    return launch_dma2<64, 64, 2, 4>(a, st);
+}
+
+}  // namespace pemp

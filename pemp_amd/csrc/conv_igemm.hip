@@ -309,6 +309,15 @@ extern "C" int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x
         tile = 3;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (tile >= 21 && tile <= 27) {      // conv_dma2.hip: buffer-addressed LDS-DMA + barrier inside the MFMA stream (same tile shapes as 11..17)
+        if (conv_dma2_supported(a)) {
+            const int t = tile - 20;
+            PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || a.Cout % 128 == 0, "conv2d: tile N=128 needs Cout %% 128 == 0");
+            PEMP_REQUIRE(t != 7 || a.Cout % 256 == 0, "conv2d: tile 256x256 needs Cout %% 256 == 0");
+            return launch_conv_dma2(t, a, st);
+        }
+        tile -= 10;                      // stem / padding value / > 32 taps / >= 2 GiB operands: the pointer-addressed variant
+    }
     if (tile >= 11 && tile <= 17) {      // LDS-DMA staging variants (conv_dma.hip); 14..17: 8-wave blocks, 16: 256x128, 17: 256x256
         PEMP_REQUIRE((tile != 11 && tile != 14 && tile != 16) || a.Cout % 128 == 0, "conv2d: tile N=128 needs Cout %% 128 == 0");
         PEMP_REQUIRE(tile != 17 || a.Cout % 256 == 0, "conv2d: tile 256x256 needs Cout %% 256 == 0");

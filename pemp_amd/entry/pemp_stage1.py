@@ -219,6 +219,8 @@ class Evaluator:
                 logger.info(f"[round {epoch}/{te_epochs}] mIoU: {miou * 100:5.2f}  |  bIoU: {biou * 100:5.2f}")
             accum.update(loss=loss_tot / max(n_tot, 1.0), miou=miou_c, biou=biou_c)
         self.cps = calls / timed if timed > 0 else 0.0
+        #: per-class IoU of every round, [te_epochs, len(val_labels)] / [te_epochs, 2] (the return value averages them)
+        self.round_miou, self.round_biou = np.array(accum.values["miou"]), np.array(accum.values["biou"])
         return accum.mean(["loss", "miou", "biou"])
 
 

@@ -64,7 +64,9 @@ class ConvParams:
 #: kernel variants the autotuner may pick: id -> (BM, BN); ids >= 11 stage through LDS-DMA.  All variants
 #: accumulate in the same K order, so they are bit-identical and the choice only affects speed.
 TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15: (128, 64), 3: (64, 64),
-                 17: (256, 256), 16: (256, 128)}    # 16/17: 8-wave blocks, 98/131 KB LDS, half the L2->LDS bytes per flop
+                 17: (256, 256), 16: (256, 128),    # 16/17: 8-wave blocks, 98/131 KB LDS, half the L2->LDS bytes per flop
+                 # 2x: the same shapes on conv_dma2.hip (buffer-addressed LDS-DMA, barrier inside the MFMA stream)
+                 23: (64, 64), 24: (128, 128), 22: (128, 64), 21: (128, 128), 25: (128, 64), 27: (256, 256), 26: (256, 128)}
 AUTOTUNE = True
 DEFAULT_TILE = 13
 _TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared by every ConvParams object

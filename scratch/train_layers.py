@@ -3,9 +3,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pemp_amd import ops, train_ops as T, synth
 from pemp_amd.networks import pemp_stage1 as m
 from pemp_amd.train_engine import Stage1Trainer
-from tests import util
+from pemp_amd import synth as _synth
 dev = torch.device("cuda:0")
-net = m.ModelClass(None); net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+net = m.ModelClass(None); net.load_state_dict(_synth.wgen_state_dict_for(net))
 tr = Stage1Trainer(net, device=dev)
 b = synth.make_batch([1, 2, 3, 4], shot=1, out_hw=(401, 401))
 ins = tuple(torch.from_numpy(b[k]).to(dev) for k in ("sup_img", "sup_mask", "qry_img")) + (torch.from_numpy(b["qry_mask"][:, 0]).to(dev),)

@@ -98,14 +98,16 @@ def test_coco20i_round_matches_cpu_oracle(hip_lib, dev):
     nclass = e1.num_classes("COCO")
     labels = e1.get_val_labels(split, "COCO")
     assert nclass == 80 and labels == list(range(21, 41))
-    res = []
+    res, per_class = [], []
     for batch in (1, 8):
         data = e1.SyntheticEpisodes(n_eps, 5678, shot=1, split=split, dataset="COCO")
         ev = e1.Evaluator(net, dev)
         res.append(ev.start_eval_loop(data, nclass, split, te_epochs=1, batch=batch, dataset_name="COCO"))
+        per_class.append(ev.round_miou[0])
     (loss, miou_c, biou_c), (loss8, miou8, biou8) = res
     assert loss == loss8 and np.array_equal(miou_c, miou8) and np.array_equal(biou_c, biou8)
-    assert np.asarray(miou_c).shape[-1] == 20 and np.isfinite(miou_c).all() and np.isfinite(biou_c).all()
+    assert np.array_equal(per_class[0], per_class[1]) and per_class[0].shape == (20,)
+    assert np.isfinite(per_class[0]).all() and np.isfinite(miou_c) and np.isfinite(biou_c)
     torch.set_num_threads(16)
     data = e1.SyntheticEpisodes(n_eps, 5678, shot=1, split=split, dataset="COCO")
     data.reset_sampler()
@@ -130,5 +132,5 @@ def test_coco20i_round_matches_cpu_oracle(hip_lib, dev):
           f"loss hip {loss:.6f} ref {np.mean(losses):.6f}")
     assert np.isfinite(ref_c).all()
     assert abs(got_miou - ref_miou) <= 1e-4 and abs(got_biou - ref_biou) <= 1e-4
-    assert np.abs(np.asarray(miou_c).reshape(-1) - ref_c).max() <= 2e-4
+    assert np.abs(per_class[0] - ref_c).max() <= 2e-4
     assert abs(loss - float(np.mean(losses))) <= 1e-4
