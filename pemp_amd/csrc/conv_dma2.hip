@@ -17,8 +17,10 @@
 //    step and the LDS-DMA of the step after that in the shadow of those 4*TM*TN MFMAs, instead of starting every
 //    step with address arithmetic + a dozen LDS reads + a full wait while the matrix pipe drains.
 //
-// Not handled here (conv_dma.hip keeps them): the NHWC4 stem (a K step spans 8 taps, the tap differs per lane), a
-// per-channel padding VALUE (padv), more than 32 taps, operands of 2 GiB or more.
+// Not handled here (conv_dma.hip keeps them): the NHWC4 stem (a K step spans 8 taps, the tap differs per lane), more
+// than 32 taps, operands of 2 GiB or more, and a per-channel padding VALUE (padv): the in-image and the out-of-image
+// lanes of a piece would have to come from two descriptors, and an exec-masked LDS-DMA does not leave the inactive
+// lanes' 16-byte slots alone (tried: two masked DMAs per piece give wrong data), so a piece cannot be assembled from two.
 #include "conv_common.h"
 
 namespace pemp {
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int AL = BM / RPI, BL = BN / RPI; // DMA wave-instructions per thread per K step
-    constexpr int NMF = TM * TN * 4, NDS = TM + TN, NDMA = AL + BL;      // per quarter step: MFMAs, fragment reads; DMAs per step
+    constexpr int NMF = TM * TN * 4, NDS = TM + TN, NDMA = AL + BL;   // per quarter step: MFMAs, fragment reads; DMAs per step
     constexpr int PER = (NDS + NDMA + NMF - 1) / NMF;
 
     extern __shared__ __attribute__((aligned(16))) v4f smem[];
@@ -114,8 +116,13 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
     // branch-free and pinned to the scalar unit (inline asm: hipcc otherwise turns the selects into VALU code, the
     // SGPR offsets of the DMA instructions into VGPRs and every DMA into a readfirstlane loop); the steady-state
     // K step must stay one basic block
-    const int multi = __builtin_amdgcn_readfirstlane(a.ntaps > 1 ? 1 : 0);
-    const int s_kw = __builtin_amdgcn_readfirstlane(a.KW), s_ntaps = __builtin_amdgcn_readfirstlane(a.ntaps);
+    // (the three loop-invariant inputs are produced by an asm statement with an "=s" result: hipcc has been seen to keep
+    // a uniform value -- even the result of __builtin_amdgcn_readfirstlane -- in a VGPR and to print that VGPR into an
+    // "s" operand)
+    int multi, s_kw, s_ntaps;
+    asm volatile("v_readfirstlane_b32 %0, %3\n\tv_readfirstlane_b32 %1, %4\n\tv_readfirstlane_b32 %2, %5"
+                 : "=s"(multi), "=s"(s_kw), "=s"(s_ntaps)
+                 : "v"(a.ntaps > 1 ? 1 : 0), "v"(a.KW), "v"(a.ntaps));
 #define PEMP_ADVANCE2()                                                                                           \
     do {                                                                                                          \
         int wt_;                                                                                                  \
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
     if (a.nk > 1) {
         PEMP_ADVANCE2();
         PEMP_DMA2(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AL + BL) : "memory");      // step 0 has landed, step 1 may still fly
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");         // step 0 has landed, step 1 may still fly
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

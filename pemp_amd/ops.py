@@ -79,21 +79,27 @@ if _TILE_CACHE_FILE and os.path.exists(_TILE_CACHE_FILE):
 
 
 def _pick_tile(launch, p, key, cout):
-    """Time the candidate variants once for this (layer, input shape) and remember the fastest."""
-    best, best_ms = DEFAULT_TILE, None
-    for t, (bm, bn) in TILE_VARIANTS.items():
-        if cout % bn:
-            continue
+    """Time the candidate variants for this (layer, input shape) and remember the fastest: two rounds over all
+    candidates (the minimum of a variant's two timings counts: a round can be disturbed by whatever else the GPU is
+    finishing), then a run-off between the best three with more repetitions."""
+    cands = [t for t, (bm, bn) in TILE_VARIANTS.items() if cout % bn == 0]
+
+    def timed(t, reps):
         launch(t)                                   # warm
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(3):
+        for _ in range(reps):
             launch(t)
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1)
-        if best_ms is None or ms < best_ms * 0.98:  # prefer earlier (default) variants on ties
-            best, best_ms = t, ms
+        return e0.elapsed_time(e1) / reps
+
+    ms = {t: timed(t, 3) for t in cands}
+    for t in cands:
+        ms[t] = min(ms[t], timed(t, 3))
+    top = sorted(cands, key=lambda t: ms[t])[:3]
+    final = {t: min(timed(t, 8), timed(t, 8)) for t in top}
+    best = min(top, key=lambda t: final[t])
     _TILE_CACHE[key] = best
     if _TILE_CACHE_FILE:
         with open(_TILE_CACHE_FILE, "w") as f:
@@ -162,7 +168,7 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
                                                      _p(residual), _p(pad_value), _stream()), "pemp_conv2d_padv_nhwc_f32")
 
     if tile == 0:
-        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, p.stem, n, h, w)
+        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, p.stem, n, h, w, int(residual is not None), int(pad_value is not None))
         tile = _TILE_CACHE.get(key)
         if tile is None:
             if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():

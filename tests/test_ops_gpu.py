@@ -107,8 +107,7 @@ def test_conv2d_pad_value_folds_a_leading_batchnorm(hip_lib, dev, Cin, Cout, k, 
     xd = _nhwc(x).to(dev)
     tol = 3e-5 * (Cin * k * k / 64) ** 0.5
     outs = []
-    # (2x ids: conv_dma2.hip has no padding-value path and hands such launches to conv_dma.hip)
-    for tile in (3, 2, 13, 12, 15, 23, 25) + ((11, 14, 16, 24) if Cout % 128 == 0 else ()) + ((17, 27) if Cout % 256 == 0 else ()):
+    for tile in (3, 2, 13, 12, 15, 23, 22, 25) + ((11, 14, 16, 21, 24, 26) if Cout % 128 == 0 else ()) + ((17, 27) if Cout % 256 == 0 else ()):
         y = ops.conv2d(xd, q, tile=tile, pad_value=padv if k > 1 else None)
         outs.append(y)
         assert ((_nchw(y.cpu()) - ref).abs() / (1 + ref.abs())).max().item() < tol, tile
