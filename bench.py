@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""Headline benchmark: episodes/sec of the PEMP stage-1 evaluation step (BASELINE.json configs[1]:
-pemp_stage1, PASCAL-5i-shaped 1-shot episodes, ResNet-50, 401x401) on N MI355X.
+"""Headline benchmark: episodes/sec of the PEMP hot path on N MI355X.
 
-A "step" is one pass of the hot path -- Evaluator.test_step's device work (encoder, meta-prototype
-module, cosine map, upsample + argmax + CE + IoU counts; reference entry/pemp_stage1.py:48-53) --
-over ``--batch`` synthetic episodes that are already resident in HBM.  Ranks are independent
-(episodes shard; no data-path collective), scaling is weak.
+    python bench.py --gpus N --steps K --warmup W                      eval, BASELINE.json configs[1] (headline)
+    python bench.py --mode train [--model stage2]                      training step, configs[2] (stage 2: + the prior pass)
+    python bench.py --model stage2 --shot 5 --batch 8                  stage-1 prior + stage 2, 5-shot, configs[3]
+    python bench.py --dataset COCO                                     COCO-20i-shaped episodes, configs[4]
+    python bench.py --model baseline --batch 12                        Baseline VGG-16, configs[0]
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel (the fp32-MFMA implicit-GEMM conv) against the 157.3 TFLOP/s
-                dense fp32 matrix peak; durations from HIP events around every conv launch of the
-                same workload, taken in bench.py on the launch stream;
-  cpu_baseline  the CPU oracle (oracle/ref_cpu.py, verified bit-equal to the reference here) timed on
-                the host cores for a bounded sample of the same episodes.
+A "step" is one pass of the hot path over ``--batch`` synthetic episodes already resident in HBM: for eval the device
+work of Evaluator.test_step (encoder, meta-prototype module, cosine map, upsample + argmax + CE + IoU counts; reference
+entry/pemp_stage1.py:48-53), for train the whole Trainer.train_step (entry/pemp_stage1.py:57-65).  Ranks are independent
+in eval (episodes shard; no data-path collective) and data-parallel in training (gradient all-reduce over RCCL); scaling
+is weak.  ``--gpus N`` without a launcher around it (no WORLD_SIZE in the environment) starts the N ranks itself.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline        the dominant kernel class (the fp32-MFMA implicit-GEMM convs) against the 157.3 TFLOP/s dense fp32
+                  matrix peak: algorithmic flops of every conv launch of a step / their durations, taken live with HIP
+                  events on the stream each kernel is launched on (an instrumented pass over the C ABI, eager, same
+                  workload); ``by_class`` splits the step over conv / weight-gradient / BatchNorm / head / optimizer
+  single_episode  (eval, N = 1) the reference's own protocol, one episode per test_step (data_kits/datasets.py:23)
+  cpu_baseline    the CPU oracle (oracle/ref_cpu.py, bit-equal to the reference here) timed on the host cores in child
+                  processes: 1 thread and all cores of the box's share, bounded samples of the same workload
 """
 import argparse
 import json
@@ -28,6 +36,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md, "HBM3E peak BW" (spec; 6.29 TB/s measured for a float4 copy)
 
 
 def parse():
@@ -44,13 +53,15 @@ def parse():
                          "baseline = Baseline VGG-16 (configs[0]); panet = PANet VGG-16 (the Baseline step + the alignment branch)")
     ap.add_argument("--mode", choices=("eval", "train"), default="eval",
                     help="eval (headline metric, BASELINE.json configs[1]) or train (configs[2])")
+    ap.add_argument("--dataset", choices=("PASCAL", "COCO"), default="PASCAL",
+                    help="COCO: BASELINE.json configs[4] -- COCO-20i label set and picture formats (ground truth up to 640x640)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-episodes", type=int, default=12, help="bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--train-graph", action="store_true", help="--mode train: replay forward/backward from a hipGraph")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the staging-inclusive end_to_end figure")
-    ap.add_argument("--dataset", choices=("PASCAL", "COCO"), default="PASCAL",
-                    help="COCO: BASELINE.json configs[4] -- COCO-20i label set and picture formats (ground truth up to 640x640)")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-episode-per-step figure")
+    ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)        # internal: "<threads>" -> run one CPU-baseline leg
     return ap.parse_args()
 
 
@@ -128,24 +139,38 @@ def dry_run(args, world, rank):
                           "config": {"workload": "dry run", "mode": args.mode}}))
 
 
-def build_model(dev):
+# ---------------------------------------------------------------------------------------------
+# models and episodes
+# ---------------------------------------------------------------------------------------------
+def build_model(dev, kind="stage1", shot=1):
+    """Random-init model of the reference's architecture with Wgen(1234) weights (no checkpoint exists on either box)."""
     from pemp_amd import synth
-    from pemp_amd.networks import pemp_stage1 as m
-    net = m.ModelClass(None)
-    sd = synth.wgen_state_dict_for(net)
+    if kind == "stage1":
+        from pemp_amd.networks import pemp_stage1 as m
+        net = m.ModelClass(None)
+        sd = synth.wgen_state_dict_for(net)
+    elif kind == "stage2":
+        from pemp_amd.networks import pemp_stage2 as m2
+        net = m2.ModelClass(shot, 1, None)
+        sd = synth.wgen_state_dict_for(net, seed=4321)
+    else:
+        from pemp_amd.networks import baseline as mb, panet as mp
+        net = mb.Baseline(None, backbone="vgg16") if kind == "baseline" else mp.PANet(None, backbone="vgg16")
+        sd = synth.wgen_state_dict_for(net)
     net.load_state_dict(sd)
-    return net.to(dev).eval(), sd
+    return (net.to(dev).eval() if dev is not None else net), sd
 
 
-def episode_pool(dev, shot, batch, rank, n_groups=5):
+def episode_pool(dev, shot, batch, rank, n_groups=5, dataset="PASCAL"):
     """n_groups batches of `batch` episodes; all episodes of a batch share one query size so that one
     fused tail launch serves the batch.  Seeds follow the evaluation sampler (test_seed = 5678)."""
     from pemp_amd import synth
+    sizes = synth.query_sizes(dataset)
     pool = []
     for g in range(n_groups):
-        hw = synth.QUERY_SIZES[g % len(synth.QUERY_SIZES)]
+        hw = sizes[g % len(sizes)]
         seeds = [5678 + 1000 * rank + g * batch + b for b in range(batch)]
-        b = synth.make_batch(seeds, shot=shot, out_hw=hw)
+        b = synth.make_batch(seeds, shot=shot, out_hw=hw, dataset=dataset)
         pool.append(dict(
             sup_img=torch.from_numpy(b["sup_img"]).to(dev), sup_mask=torch.from_numpy(b["sup_mask"]).to(dev),
             qry_img=torch.from_numpy(b["qry_img"]).to(dev), qry_mask=torch.from_numpy(b["qry_mask"][:, 0]).to(dev),
@@ -153,152 +178,276 @@ def episode_pool(dev, shot, batch, rank, n_groups=5):
     return pool
 
 
-def conv_roofline(net, pool, reps=3):
-    """Per-launch HIP-event timing of every conv launch of one step (eager pass, same stream)."""
-    from pemp_amd import ops
-    records = []
-    orig = ops.conv2d
+# ---------------------------------------------------------------------------------------------
+# live per-kernel timing over the C ABI
+# ---------------------------------------------------------------------------------------------
+CLASS_OF = {
+    "pemp_conv2d_nhwc_f32": "conv", "pemp_conv2d_padv_nhwc_f32": "conv", "pemp_conv2d_wgrad_nhwc_f32": "wgrad",
+    "pemp_bn_stats_f32": "batchnorm", "pemp_bn_apply_f32": "batchnorm", "pemp_bn_bwd_f32": "batchnorm",
+    "pemp_relu_bias_bwd_f32": "batchnorm",
+    "pemp_mpm_protos_f32": "head", "pemp_masked_avg_pool_f32": "head", "pemp_cosine_proto_max_f32": "head",
+    "pemp_eval_tail_f32": "head", "pemp_eval_tail_weighted_f32": "head", "pemp_head_bwd_f32": "head",
+    "pemp_head_bwd_dlogits_f32": "head", "pemp_upsample_bilinear_ac_f32": "head", "pemp_argmax_masks_f32": "head",
+    "pemp_sgd_clip_step_f32": "optimizer",
+}
 
-    def timed(x, p, out=None, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = orig(x, p, out=out, **kw)
-        e1.record()
-        n, ho, wo, co = y.shape
-        cin_real = 3 if (p.stem and p.cin == 4 and not getattr(p, "real4", False)) else p.cin
-        nbytes = 4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * p.cin + n * ho * wo * co * (2 if kw.get("residual") is not None else 1)
-                        + p.w.numel())
-        records.append((e0, e1, 2.0 * n * ho * wo * co * p.kh * p.kw * cin_real, nbytes,
-                        (n * ho * wo, co, p.kh * p.kw * cin_real, kw.get("residual") is not None)))
-        return y
 
-    cos_rec, cos_last = [], []
-    orig_cos = ops.cosine_proto_max
+class TimedLib:
+    """Stand-in for the ctypes handle of libpemp_hip.so that brackets every kernel-launching entry point with a pair of
+    HIP events recorded on the stream the launch is made on (the ABI's last argument)."""
 
-    def timed_cos(qry, protos, dist_scalar, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_cos(qry, protos, dist_scalar, **kw)
-        e1.record()
-        b, h, w, c = qry.shape
-        j = protos.shape[1]
-        cos_rec.append((e0, e1, 4.0 * (b * h * w * c + protos.numel() + 2 * b * h * w), 2.0 * b * h * w * c * j))
-        cos_last[:] = [(qry, protos, dist_scalar, kw)]
-        return out
+    def __init__(self, lib):
+        self._lib, self.rec = lib, []
 
-    ops.conv2d = timed
-    ops.cosine_proto_max = timed_cos
-    import pemp_amd.engine as eng
-    eng.ops.conv2d = timed
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name.endswith("_bytes") or name in ("pemp_last_error", "pemp_abi_version", "pemp_episode_plan"):
+            return fn
+
+        def timed(*a):
+            st = a[-1]
+            st = st.value if hasattr(st, "value") else st
+            stream = torch.cuda.ExternalStream(int(st)) if st else torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = fn(*a)
+            e1.record(stream)
+            self.rec.append((name, e0, e1, a))
+            return rc
+        return timed
+
+
+def _conv_work(name, a):
+    """(flops, algorithmic bytes, (M, N, K, shortcut)) of one conv / weight-gradient launch from its descriptor."""
+    d = a[0]._obj if hasattr(a[0], "_obj") else a[0].contents
+    stem = bool(d.flags & 4)
+    cin = 3 if stem else d.Cin
+    m = d.N * d.Ho * d.Wo
+    k = d.KH * d.KW * cin
+    flops = 2.0 * m * d.Cout * k
+    res = name != "pemp_conv2d_wgrad_nhwc_f32" and bool(a[6])
+    nbytes = 4.0 * (d.N * d.H * d.W * d.Cin + m * d.Cout * (2 if res else 1) + d.Cout * d.KH * d.KW * d.Cin)
+    return flops, nbytes, (m, d.Cout, k, res)
+
+
+def instrumented(run, reps=3):
+    """Run ``run()`` reps+1 times with every C-ABI launch bracketed by HIP events; returns the records of the last
+    ``reps`` runs."""
+    from pemp_amd import _lib
+    real = _lib.load()
+    proxy = TimedLib(real)
+    _lib._lib = proxy
     try:
-        with torch.no_grad():
-            for r in range(reps + 1):
-                if r == 1:
-                    records.clear()
-                ep = pool[r % len(pool)]
-                net.lowres(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
+        for r in range(reps + 1):
+            if r == 1:
+                proxy.rec.clear()
+            run(r)
         torch.cuda.synchronize()
     finally:
-        ops.conv2d = orig
-        eng.ops.conv2d = orig
-        ops.cosine_proto_max = orig_cos
-    cos = None
-    if cos_rec:
-        # a 25 us kernel bracketed by its own pair of events also measures ~4 us of launch gap: time 20 launches of the
-        # step's last call back to back instead (same operands, one event pair) -- this agrees with rocprofv3's duration
-        qry, protos, ds, kw = cos_last[0]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.no_grad():
-            orig_cos(qry, protos, ds, **kw)
-            e0.record()
-            for _ in range(20):
-                orig_cos(qry, protos, ds, **kw)
-            e1.record()
-        torch.cuda.synchronize()
-        nbytes, nflop = cos_rec[-1][2], cos_rec[-1][3]           # algorithmic bytes / useful flops of one launch
-        cms = e0.elapsed_time(e1) / 20
-        gbs = nbytes / (cms * 1e-3) / 1e9
-        cos = {"bound": "hbm", "kernel": "cosine_mfma_kernel (pixel x prototype cosine, MFMA outer product)",
-               "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-               "avg_launch_us": round(cms * 1e3, 2),
-               "useful_mfma_tflops": round(nflop / (cms * 1e-3) / 1e12, 3)}
-    ms = sum(r[0].elapsed_time(r[1]) for r in records)
-    flops = sum(r[2] for r in records)
-    abytes = sum(r[3] for r in records)
-    n = len(records)
-    ach = flops / (ms * 1e-3) / 1e12
-    # HBM bytes per launch from the PMC counters cannot be collected in-process; they are measured with
-    # rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) on this same
-    # command and committed under profiles/.  Reported only when that file matches the batch size.
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-    if os.path.exists(tf):
-        with open(tf) as f:
-            rec = json.load(f)
-        if rec.get("episodes_per_step") == len(pool[0]["seeds"]):
-            traffic = rec.get("hbm_bytes_per_launch")
-    # MFMA pipe utilisation from the PMC counters (rocprofv3 --pmc MfmaUtil on this command), likewise committed
-    mfma_util = None
-    mf = os.path.join(ROOT, "profiles", "r01_mfma_util.json")
-    if os.path.exists(mf):
-        with open(mf) as f:
-            rec = json.load(f)
-        if rec.get("episodes_per_step") == len(pool[0]["seeds"]):
-            mfma_util = rec.get("conv_mfma_util_pct_time_weighted")
-    # where the time goes: the six GEMM shapes (rows M, Cout N, K, with shortcut) with the largest share of conv time
-    by = {}
-    for r in records:
-        t = by.setdefault(r[4], [0.0, 0.0])
-        t[0] += r[0].elapsed_time(r[1])
-        t[1] += r[2]
-    top = sorted(by.items(), key=lambda kv: -kv[1][0])[:6]
-    by_layer = [{"M": k[0], "N": k[1], "K": k[2], "shortcut": k[3], "share": round(v[0] / ms, 3),
+        _lib._lib = real
+    return proxy.rec
+
+
+def summarize(rec, reps, step_ms=None):
+    """Per-class time / work of a step from the instrumented records, and the roofline object of the conv class."""
+    by, layers = {}, {}
+    conv_ms = conv_fl = conv_by = 0.0
+    conv_n = 0
+    for name, e0, e1, a in rec:
+        ms = e0.elapsed_time(e1)
+        cls = CLASS_OF.get(name, "other")
+        c = by.setdefault(cls, {"ms": 0.0, "launches": 0, "gflop": 0.0})
+        c["ms"] += ms
+        c["launches"] += 1
+        if cls in ("conv", "wgrad"):
+            fl, nb, shape = _conv_work(name, a)
+            c["gflop"] += fl / 1e9
+            conv_ms += ms
+            conv_fl += fl
+            conv_by += nb
+            conv_n += 1
+            t = layers.setdefault((cls,) + shape, [0.0, 0.0])
+            t[0] += ms
+            t[1] += fl
+    out = {}
+    for cls, c in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
+        e = {"ms_per_step": round(c["ms"] / reps, 3), "launches_per_step": c["launches"] // reps}
+        if c["gflop"]:
+            e["gflop_per_step"] = round(c["gflop"] / reps, 1)
+            e["tflops"] = round(c["gflop"] / c["ms"], 1)
+            e["frac_of_fp32_mfma_peak"] = round(c["gflop"] / c["ms"] / PEAK_F32_MFMA_TFLOPS, 4)
+        out[cls] = e
+    top = sorted(layers.items(), key=lambda kv: -kv[1][0])[:6]
+    by_layer = [{"kind": k[0], "M": k[1], "N": k[2], "K": k[3], "shortcut": k[4], "share": round(v[0] / max(conv_ms, 1e-9), 3),
                  "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)} for k, v in top]
-    return {"bound": "mfma", "kernel": "conv_dma_kernel + conv_igemm_kernel (all conv launches of a step)",
-            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "mfma_util_pmc_pct": mfma_util,
-            "algorithmic_bytes_per_launch": int(abytes / n),
-            "launches_per_step": n // reps, "avg_launch_us": round(ms * 1e3 / n, 2),
-            "gflop_per_step": round(flops / reps / 1e9, 2), "conv_ms_per_step": round(ms / reps, 4),
-            "by_layer": by_layer, "cosine_kernel": cos}
+    ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0
+    roof = {"bound": "mfma",
+            "kernel": "conv_dma2_kernel / conv_dma_kernel / conv_wgrad_kernel (every implicit-GEMM launch of a step: forward, input-gradient, weight-gradient)",
+            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": None, "algorithmic_bytes_per_launch": int(conv_by / max(conv_n, 1)),
+            "launches_per_step": conv_n // reps, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
+            "gflop_per_step": round(conv_fl / reps / 1e9, 2), "conv_ms_per_step": round(conv_ms / reps, 4),
+            "timing": "HIP events around every launch on its own stream, eager pass of the same workload inside bench.py",
+            "by_layer": by_layer, "by_class": out}
+    if step_ms:
+        roof["step_effective_tflops"] = round(conv_fl / reps / 1e9 / step_ms, 2)
+    return roof
 
 
-def cpu_baseline(sd, shot, n_eps):
-    """Oracle test_step (forward + CE + argmax) on the host cores, bounded sample."""
+def attach_pmc(roof, workload_key):
+    """HBM bytes and MFMA-pipe utilisation come from rocprofv3 --pmc passes (they cannot be collected in-process).  A
+    committed profile is quoted ONLY when it was taken on exactly this kernel source (csrc digest) and workload."""
+    from pemp_amd import build
+    digest = build.csrc_digest()
+    for fname, field, key in (("r02_conv_traffic.json", "traffic", "hbm_bytes_per_launch"),
+                              ("r02_mfma_util.json", "mfma_util_pmc_pct", "conv_mfma_util_pct_time_weighted")):
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("csrc_digest") == digest and rec.get("workload_key") == workload_key:
+            roof[field] = rec.get(key)
+            roof.setdefault("pmc_source", []).append(f"profiles/{fname} (rocprofv3 --pmc, replayed: same kernel source {digest})")
+    return roof
+
+
+def cosine_roofline(net, pool):
+    """The pixel x prototype cosine kernel against the HBM roofline: 20 back-to-back launches on the step's operands
+    between one pair of events (a 25 us kernel bracketed by its own events also measures the launch gap)."""
+    from pemp_amd import ops
+    last = []
+    orig = ops.cosine_proto_max
+
+    def spy(qry, protos, dist_scalar, **kw):
+        last[:] = [(qry, protos, dist_scalar, kw)]
+        return orig(qry, protos, dist_scalar, **kw)
+
+    ops.cosine_proto_max = spy
+    try:
+        ep = pool[0]
+        with torch.no_grad():
+            net.lowres(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
+    finally:
+        ops.cosine_proto_max = orig
+    if not last:
+        return None
+    qry, protos, ds, kw = last[0]
+    b, h, w, c = qry.shape
+    nbytes = 4.0 * (b * h * w * c + protos.numel() + 2 * b * h * w)
+    nflop = 2.0 * b * h * w * c * protos.shape[1]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        orig(qry, protos, ds, **kw)
+        e0.record()
+        for _ in range(20):
+            orig(qry, protos, ds, **kw)
+        e1.record()
+    torch.cuda.synchronize()
+    cms = e0.elapsed_time(e1) / 20
+    gbs = nbytes / (cms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "cosine_mfma_kernel (pixel x prototype cosine, MFMA outer product)",
+            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "avg_launch_us": round(cms * 1e3, 2), "useful_mfma_tflops": round(nflop / (cms * 1e-3) / 1e12, 3)}
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the host cores, each thread setting in its own process
+# ---------------------------------------------------------------------------------------------
+def cpu_leg(args):
+    """Child process (no GPU call): time the oracle with ``--cpu-leg`` threads and print one JSON object."""
     from oracle import ref_cpu
     from pemp_amd import synth
+    threads = int(args.cpu_leg)
+    torch.set_num_threads(threads)
+    kind = "stage2" if args.model == "stage2" else "stage1"
+    _, sd = build_model(None, "stage1", 1)
+    sd2 = build_model(None, "stage2", args.shot)[1] if kind == "stage2" else None
+    t = lambda a: torch.from_numpy(a)
+    budget = float(os.environ.get("PEMP_CPU_BUDGET_S", "25"))
+    times = []
+    if args.mode == "train":
+        B = max(1, min(args.batch, int(os.environ.get("PEMP_CPU_TRAIN_BATCH", str(args.batch)))))
+        n = 0
+        while True:
+            b = synth.make_batch([1234 + n * B + i for i in range(B)], shot=args.shot, out_hw=(401, 401))
+            ins = (t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0]))
+            t0 = time.time()
+            if kind == "stage2":
+                with torch.no_grad():
+                    prior = ref_cpu.stage1_forward(sd, *ins[:3], (401, 401)).argmax(dim=1, keepdim=True)
+                ref_cpu.train_step(sd2, *ins, model="stage2", qry_prior=prior)
+            else:
+                ref_cpu.train_step(sd, *ins, model="stage1")
+            times.append(time.time() - t0)
+            n += 1
+            if sum(times) > budget or n >= 3:
+                break
+        per = B
+        what = f"{len(times)} train step(s) of {B} episode(s) (oracle/ref_cpu.py train_step: train-mode forward, CE, autograd backward, clip, SGD)"
+    else:
+        with torch.no_grad():
+            for i in range(args.cpu_episodes + 1):
+                ep = synth.make_episode(5678 + i, shot=args.shot, index=i, dataset=args.dataset)
+                sup, msk, qry = t(ep["sup_img"])[None], t(ep["sup_mask"])[None], t(ep["qry_img"])[None]
+                gt = t(ep["qry_mask"])
+                t0 = time.time()
+                if kind == "stage2":
+                    prior = ref_cpu.stage1_forward(sd, sup, msk, qry, tuple(sup.shape[-2:])).argmax(dim=1, keepdim=True)
+                    fwd = lambda a, b, c, hw: ref_cpu.stage2_forward(sd2, a, b, c, prior, hw)
+                else:
+                    fwd = lambda a, b, c, hw: ref_cpu.stage1_forward(sd, a, b, c, hw)
+                ref_cpu.test_step(fwd, (sup, msk, qry), gt)
+                dt = time.time() - t0
+                if i > 0:                      # first episode warms the allocator / oneDNN primitives
+                    times.append(dt)
+                if sum(times) > budget:
+                    break
+        per = 1
+        what = f"{len(times)} episodes (seeds 5679..), oracle/ref_cpu.py test_step"
+    tot = sum(times)
+    print(json.dumps({"value": round(len(times) * per / tot, 3), "threads": threads,
+                      "sample": f"{what}, torch {torch.__version__} CPU, {threads} thread(s), median {np.median(times) * 1e3:.0f} ms/step"}))
+
+
+def cpu_baseline(args):
+    """Oracle legs in child processes (switching set_num_threads inside one process inflates the timings):
+    all cores of this box's share (<= 16) and one thread."""
+    import subprocess
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    # a 1-GPU box owns a 16-core share of its host; more threads than that only oversubscribe it
     cores = max(1, min(cores, int(os.environ.get("PEMP_CPU_THREADS", "16"))))
-    torch.set_num_threads(cores)
-    times = []
-    with torch.no_grad():
-        for i in range(n_eps + 1):
-            ep = synth.make_episode(5678 + i, shot=shot, index=i)
-            t = lambda a: torch.from_numpy(a)[None]
-            sup, msk, qry, gt = t(ep["sup_img"]), t(ep["sup_mask"]), t(ep["qry_img"]), torch.from_numpy(ep["qry_mask"])
-            t0 = time.time()
-            fwd = lambda a, b, c, hw: ref_cpu.stage1_forward(sd, a, b, c, hw)
-            ref_cpu.test_step(fwd, (sup, msk, qry), gt)
-            dt = time.time() - t0
-            if i > 0:                      # first episode warms the allocator / oneDNN primitives
-                times.append(dt)
-            if sum(times) > 30.0:
-                break
-    tot = sum(times)
-    return {"value": round(len(times) / tot, 3), "unit": "episodes/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} episodes (seeds 5679..), oracle/ref_cpu.py test_step, torch {torch.__version__} CPU, "
-                      f"{cores} threads, median {np.median(times) * 1e3:.0f} ms/episode"}
+    legs = {}
+    for threads in (cores, 1):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+        if threads == 1:
+            env.setdefault("PEMP_CPU_BUDGET_S", "20")
+            env.setdefault("PEMP_CPU_TRAIN_BATCH", "1")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(threads), "--mode", args.mode, "--model", args.model,
+               "--shot", str(args.shot), "--batch", str(args.batch), "--dataset", args.dataset,
+               "--cpu-episodes", str(args.cpu_episodes if threads > 1 else max(2, args.cpu_episodes // 3))]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        legs[threads] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-300:]}
+    main = legs[cores]
+    if "error" in main:
+        return main
+    out = {"value": main["value"], "unit": "episodes/s", "cores": cores, "kind": "port", "sample": main["sample"]}
+    one = legs.get(1, {})
+    out["one_thread"] = {"value": one.get("value"), "cores": 1, "sample": one.get("sample", one.get("error"))}
+    return out
 
 
+# ---------------------------------------------------------------------------------------------
+# staging-inclusive figure (SURVEY.md §8d ii)
+# ---------------------------------------------------------------------------------------------
 def end_to_end(net, args, dev):
-    """Episodes/s INCLUDING input staging (SURVEY.md §8d ii): decoded uint8 samples in host memory -> one
-    pinned blob per step -> async H2D -> Pillow-exact resize/normalise on the device (pemp_episode_preprocess)
-    -> the same eval step, double-buffered on a side stream.  JPEG decode is not included (no dataset)."""
+    """Episodes/s INCLUDING input staging: decoded uint8 samples in host memory -> one pinned blob per step -> async H2D
+    -> Pillow-exact resize/normalise on the device (pemp_episode_preprocess) -> the same eval step, double-buffered on a
+    side stream.  JPEG decode is not included (no dataset)."""
     from pemp_amd import ops
     from pemp_amd.data_kits import synth_u8
     from pemp_amd.data_kits.episode import EpisodeLoader, EpisodeTransform, test_samples
@@ -343,22 +492,48 @@ def end_to_end(net, args, dev):
                     "double-buffered on a side stream; JPEG decode excluded"}
 
 
+def single_episode(net, dev, args, n=120):
+    """The reference's own protocol: ONE episode per test_step (data_kits/datasets.py:23 test_bs = 1,
+    entry/pemp_stage1.py:47-53), no host synchronisation per episode (statistics are fetched once per round).
+    Results are bit-identical to the batched step (every image's rows are independent in the conv GEMMs).
+    ``in_flight`` > 1: episodes issued round-robin over that many engine replicas on their own streams."""
+    from pemp_amd.entry.pemp_stage1 import Evaluator
+    pool = episode_pool(dev, args.shot, 1, 0, n_groups=5, dataset=args.dataset)
+    out = {}
+    for lanes in (1, int(os.environ.get("PEMP_EVAL_LANES", "4"))):
+        ev = Evaluator(net, device=dev, lanes=lanes)
+        eps = [((p["sup_img"], p["sup_mask"], p["qry_img"]), p["qry_mask"][None]) for p in pool]
+        rows = ev.test_steps_device([eps[i % len(eps)] for i in range(2 * len(eps) * lanes)])     # warm-up: graphs captured
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rows = ev.test_steps_device([eps[i % len(eps)] for i in range(n)])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = rows.cpu().numpy()
+        assert np.isfinite(st).all() and (st[:, 1] > 0).all()
+        key = "value" if lanes == 1 else f"value_{lanes}_in_flight"
+        out[key] = round(n / dt, 2)
+        out["ms_per_episode" if lanes == 1 else f"ms_per_episode_{lanes}_in_flight"] = round(dt / n * 1e3, 4)
+    out.update(unit="episodes/s", episodes_per_step=1,
+               protocol="one episode per test_step (reference data.test_bs = 1), hipGraph replay, statistics fetched once per round")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# --mode train
+# ---------------------------------------------------------------------------------------------
 def main_train(args, world, rank, dev):
-    """--mode train: Trainer.train_step (reference entry/pemp_stage1.py:57-65) on `--batch` episodes per
-    rank (the reference's data.bs = 4), data-parallel: one flat-gradient all-reduce per step over RCCL."""
+    """Trainer.train_step (reference entry/pemp_stage1.py:57-65) on `--batch` episodes per rank (the reference's
+    data.bs = 4), data-parallel: bucketed flat-gradient all-reduce over RCCL, overlapped with backward."""
     from pemp_amd import synth
-    from pemp_amd.networks import pemp_stage1 as m
     from pemp_amd.train_engine import Stage1Trainer
-    net = m.ModelClass(None)
-    net.load_state_dict(synth.wgen_state_dict_for(net))
+    net, _ = build_model(None, "stage1", 1)
     # eager by default: the weight-gradient kernels run on a side stream concurrently with the input-gradient chain
-    # (21.4 ms/step); a hipGraph replay of the same two-stream capture does not overlap its branches (23.6 ms/step)
     use_graph = args.train_graph
-    if args.model == "stage2":          # frozen stage-1 prior + stage-2 step (entry/pemp_stage2.py:72-83)
-        from pemp_amd.networks import pemp_stage2 as m2
+    s2 = args.model == "stage2"
+    if s2:          # frozen stage-1 prior + stage-2 step (entry/pemp_stage2.py:72-83)
         from pemp_amd.train_stage2 import Stage2Trainer
-        net2 = m2.ModelClass(args.shot, 1, None)
-        net2.load_state_dict(synth.wgen_state_dict_for(net2, seed=4321))
+        net2, _ = build_model(None, "stage2", args.shot)
         tr = Stage2Trainer(net.to(dev).eval(), net2, device=dev, use_graph=use_graph)
     else:
         tr = Stage1Trainer(net, device=dev, use_graph=use_graph)
@@ -389,26 +564,58 @@ def main_train(args, world, rank, dev):
         dt = float(tmax.item())
     ls = torch.stack(losses).cpu().numpy()
     assert np.isfinite(ls).all()
+    out = None
     if rank == 0:
-        gflop = 3 * 2 * 64.94 * B                       # fwd + dgrad + wgrad, 2 images/episode, GFLOP
-        s2 = args.model == "stage2"
-        print(json.dumps({
-            "metric": "train episodes/sec (PEMP %s train_step, ResNet-50, 1-shot, 401x401)" % ("stage-2" if s2 else "stage-1"),
+        step_ms = dt / args.steps * 1e3
+        out = {
+            "metric": "train episodes/sec (PEMP %s train_step, ResNet-50, %d-shot, 401x401)" % ("stage-2" if s2 else "stage-1", args.shot),
             "value": round(args.steps * B * world / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("pemp_stage2 train_step (stage-1 prior, batch-stat BN, CM, Dropout2d 0.5, CE, SGD), "
+            "config": {"workload": ("pemp_stage2 train_step (frozen stage-1 prior pass, batch-stat BN, CM, Dropout2d 0.5, CE, SGD), "
                                     if s2 else "pemp_stage1 train_step (batch-stat BN, DropBlock 0.1, CE, clip 1.1, SGD), ") +
-                                   "%d episodes/rank/step" % B, "episodes_per_step": B, "shot": args.shot,
-                       "first_loss": round(float(ls[0]), 5), "last_loss": round(float(ls[-1]), 5),
-                       "effective_tflops": round(gflop * world / (dt / args.steps) / 1e3, 2)}}))
+                                   "ResNet-50, %d-shot, 401x401, %d episodes/rank/step, synthetic E(seed) episodes + Wgen weights" % (args.shot, B),
+                       "episodes_per_step": B, "shot": args.shot, "hipgraph": use_graph,
+                       "first_loss": round(float(ls[0]), 5), "last_loss": round(float(ls[-1]), 5)}}
+
+        def guarded(key, fn):
+            try:
+                out[key] = fn()
+            except Exception as exc:  # noqa: BLE001
+                out[key] = {"error": f"{type(exc).__name__}: {exc}"}
+
+        if not args.no_roofline and not use_graph:
+            def roof():
+                # kernels of the two streams overlap in the timed step; for per-kernel durations the instrumented pass
+                # keeps everything on one stream (same kernels, same operands)
+                flat = tr.eng.flat
+                side, bside = flat.side_stream, tr.eng.buckets.side
+                flat.side_stream = tr.eng.buckets.side = None
+                try:
+                    rec = instrumented(lambda r: tr.train_step(*pool[r % len(pool)]), reps=2)
+                finally:
+                    flat.side_stream, tr.eng.buckets.side = side, bside
+                r = summarize(rec, 2, step_ms)
+                r["note"] = ("per-kernel durations from a single-stream pass; the timed step overlaps the weight-gradient kernels "
+                             "with the input-gradient chain on a side stream (step_effective_tflops = conv flops / timed step)")
+                return r
+            guarded("roofline", roof)
+        if world == 1 and args.cpu_episodes > 0:
+            guarded("cpu_baseline", lambda: cpu_baseline(args))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
 
 
+# ---------------------------------------------------------------------------------------------
+# eval (headline)
+# ---------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.cpu_leg:
+        return cpu_leg(args)
     if args.mode == "train" and "--batch" not in sys.argv:           # the reference trains with data.bs = 4
         args.batch = 4
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:              # no launcher around us: be the launcher
@@ -442,37 +649,24 @@ def main():
         dist.barrier()
     if args.mode == "train":
         return main_train(args, world, rank, dev)
-    if args.model in ("baseline", "panet"):        # BASELINE.json configs[0]: Baseline, VGG-16, 1-shot (PANet: same encoder)
-        from pemp_amd import synth
-        from pemp_amd.networks import baseline as mb, panet as mp
-        net = mb.Baseline(None, backbone="vgg16") if args.model == "baseline" else mp.PANet(None, backbone="vgg16")
-        sd = synth.wgen_state_dict_for(net)
-        net.load_state_dict(sd)
-        net = net.to(dev).eval()
-    else:
-        net, sd = build_model(dev)
-    pool = episode_pool(dev, args.shot, args.batch, rank)
+    vgg = args.model in ("baseline", "panet")
+    net, _ = build_model(dev, args.model if vgg else "stage1", args.shot)
+    pool = episode_pool(dev, args.shot, args.batch, rank, dataset=args.dataset)
     ws = {}
     stats_log = torch.zeros((args.steps, args.batch, 8), dtype=torch.float64, device=dev)
 
     aux_log, ws_align = [], {}
-    stage2 = None
-    if args.model == "stage2":          # BASELINE.json configs[3]: stage-1 prior + stage-2 (ResNet-50 + CM)
-        from pemp_amd import synth
-        from pemp_amd.networks import pemp_stage2 as m2
-        stage2 = m2.PEMPStage2(args.shot, 1, None)
-        stage2.load_state_dict(synth.wgen_state_dict_for(stage2, seed=4321))
-        stage2 = stage2.to(dev).eval()
+    stage2 = build_model(dev, "stage2", args.shot)[0] if args.model == "stage2" else None   # configs[3]: stage-1 prior + stage 2
 
-    def step(i, log=True):
+    def step(i, log=True, graph=not args.no_graph):
         ep = pool[i % len(pool)]
         ins = (ep["sup_img"], ep["sup_mask"], ep["qry_img"])
         with torch.no_grad():
-            pred, _ = net.lowres(*ins) if args.no_graph else net.lowres_graphed(*ins)
+            pred, _ = net.lowres_graphed(*ins) if graph else net.lowres(*ins)
             if stage2 is not None:
                 prior, _, _ = ops.eval_tail(pred, None, out_hw=ins[0].shape[-2:], ws_cache=ws)
                 prior = prior.unsqueeze(1).float()
-                pred, _ = stage2.lowres(*ins, prior) if args.no_graph else stage2.lowres_graphed(*ins, prior)
+                pred, _ = stage2.lowres_graphed(*ins, prior) if graph else stage2.lowres(*ins, prior)
             if args.model == "panet":       # auxiliary prototype-alignment loss of every episode (entry/panet.py:51-57)
                 from pemp_amd.networks.panet import align_forward
                 aux_log.append(align_forward(net._last_feats, pred, ins[1], ins[0].shape[0], args.shot, 1, 20, ws_align)["loss"])
@@ -508,19 +702,21 @@ def main():
     out = None
     if rank == 0:
         eps_total = args.steps * args.batch * world
+        name = "Baseline" if args.model == "baseline" else "PANet" if args.model == "panet" else \
+            "PEMP stage-1" if stage2 is None else "PEMP stage-1 prior + stage-2"
+        dsn = "PASCAL-5i" if args.dataset == "PASCAL" else "COCO-20i"
+        step_ms = dt / args.steps * 1e3
         out = {
-            "metric": "episodes/sec (%s eval step, PASCAL-5i-shaped %d-shot, %s)" % (
-                "Baseline" if args.model == "baseline" else "PANet" if args.model == "panet" else "PEMP stage-1" if stage2 is None else "PEMP stage-1 prior + stage-2",
-                args.shot, "VGG-16" if args.model in ("baseline", "panet") else "ResNet-50"),
+            "metric": "episodes/sec (%s eval step, %s-shaped %d-shot, %s)" % (name, dsn, args.shot, "VGG-16" if vgg else "ResNet-50"),
             "value": round(eps_total / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s eval test_step, %s, %d-shot, 401x401, %d episode(s)/step, "
+            "config": {"workload": "%s eval test_step, %s, %d-shot, 401x401, %d episode(s)/step, %s-shaped "
                                    "synthetic E(seed) episodes + Wgen(1234) weights" % (
-                                       args.model if args.model in ("baseline", "panet") else "pemp_" + args.model,
-                                       "VGG-16" if args.model in ("baseline", "panet") else "ResNet-50", args.shot, args.batch),
+                                       args.model if vgg else "pemp_" + args.model, "VGG-16" if vgg else "ResNet-50",
+                                       args.shot, args.batch, dsn),
                        "episodes_per_step": args.batch, "shot": args.shot, "hipgraph": not args.no_graph,
-                       "mean_ce_loss": round(mean_loss, 6)},
+                       "dataset": args.dataset, "mean_ce_loss": round(mean_loss, 6)},
         }
         # the auxiliary measurements must never cost the headline line: a failure is reported in place
         def guarded(key, fn):
@@ -529,14 +725,19 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 out[key] = {"error": f"{type(exc).__name__}: {exc}"}
 
-        if not args.no_roofline and stage2 is None:
-            guarded("roofline", lambda: conv_roofline(net, pool))
-            if args.model != "stage1" and "traffic" in out["roofline"]:
-                out["roofline"]["traffic"] = None        # the committed PMC run is the stage-1 workload
-        if world == 1 and args.model == "stage1" and not args.no_graph and not args.no_e2e:
+        if not args.no_roofline:
+            def roof():
+                rec = instrumented(lambda r: step(r, log=False, graph=False), reps=3)
+                r = summarize(rec, 3, step_ms)
+                r["cosine_kernel"] = cosine_roofline(net, pool)
+                return attach_pmc(r, f"{args.model}-eval-b{args.batch}-s{args.shot}")
+            guarded("roofline", roof)
+        if world == 1 and args.model == "stage1" and not args.no_graph and not args.no_single:
+            guarded("single_episode", lambda: single_episode(net, dev, args))
+        if world == 1 and args.model == "stage1" and not args.no_graph and not args.no_e2e and args.dataset == "PASCAL":
             guarded("end_to_end", lambda: end_to_end(net, args, dev))
-        if world == 1 and args.cpu_episodes > 0 and args.model not in ("baseline", "panet"):
-            guarded("cpu_baseline", lambda: cpu_baseline({k: v.cpu() for k, v in sd.items()}, args.shot, args.cpu_episodes))
+        if world == 1 and args.cpu_episodes > 0 and not vgg:
+            guarded("cpu_baseline", lambda: cpu_baseline(args))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

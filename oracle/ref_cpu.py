@@ -389,3 +389,47 @@ def celoss_dt(logits, target, sigma=5.0):
     loss = F.cross_entropy(logits, target, ignore_index=255, reduction="none")
     w = cedt_weight(target, sigma)
     return (loss * w).sum() / w.sum()
+
+
+# ------------------------------------------------------------------------------------------
+# one training step under autograd (the training cpu_baseline of bench.py; tests/golden/make_f64.py does the same in fp64)
+# ------------------------------------------------------------------------------------------
+def train_step(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", qry_prior=None, lr=1e-3, weight_decay=5e-4,
+               max_norm=1.1):
+    """Trainer.train_step (entry/pemp_stage1.py:57-65; stage 2: entry/pemp_stage2.py:72-83): forward with the model in
+    train() mode (batch-statistics BatchNorm; DropBlock / Dropout2d as identities, i.e. rate 0), CrossEntropyLoss(ignore 255),
+    backward by autograd, clip_grad_norm_(1.1) (stage 1 only, entry/pemp_stage1.py:63), one SGD step (momentum buffers empty:
+    first step, core/solver.py:87-91).  ``sd`` is updated in place (weights and BN running statistics).
+    Returns (loss, {name: gradient})."""
+    global TRAIN
+    frozen = lambda k: ("running" in k or "num_batches" in k or k.endswith("backbone.bn1.weight") or k.endswith("backbone.bn1.bias")
+                        or ".downsample.1." in k)                      # freeze_bn: stem + downsample BN affines (backbones.py:93-95,113-117)
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not frozen(k)}
+    old = TRAIN
+    TRAIN = True
+    try:
+        H, W = qry_msk.shape[-2:]
+        if model == "stage1":
+            logits = stage1_forward(sd, sup_img, sup_mask, qry_img, (H, W))
+        else:
+            logits = stage2_forward(sd, sup_img, sup_mask, qry_img, qry_prior, (H, W))
+        loss = ce_loss(logits, qry_msk.view(-1, H, W))
+        names = list(leaves)
+        grads = dict(zip(names, torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)))
+    finally:
+        TRAIN = old
+    with torch.no_grad():
+        live = [g for g in grads.values() if g is not None]
+        if model == "stage1" and max_norm > 0:
+            total = torch.sqrt(sum((g.double() ** 2).sum() for g in live)).float()
+            coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+            for g in live:
+                g.mul_(coef)
+        for k, g in grads.items():
+            if g is not None:
+                sd[k].requires_grad_(False)
+                sd[k].add_(g + weight_decay * sd[k], alpha=-lr)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(False)
+    return float(loss.detach()), grads

@@ -21,6 +21,18 @@ def _headers():
            [os.path.join(HERE, "..", "include", "pemp_hip.h")]
 
 
+def csrc_digest():
+    """Short content hash of every kernel source + the C-ABI header: profiles/*.json record it, so that a PMC figure is only
+    ever quoted next to the code it was measured on."""
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    with open(os.path.join(HERE, "..", "include", "pemp_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

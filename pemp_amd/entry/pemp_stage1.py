@@ -105,11 +105,19 @@ def allreduce_round(stat, loss_sum, count, device=None):
 
 
 class Evaluator:
-    def __init__(self, model, device=None, use_graph=True):
+    """``lanes`` > 1: single-episode steps (the reference's test_bs = 1 protocol) are issued round-robin over that many
+    engine replicas, each on its own HIP stream -- a one-episode step leaves most of the 256 CUs idle (M = 5202 rows
+    give 1.3 waves per SIMD), several in flight fill them.  Per-episode results do not change (same kernels, same
+    operands); ``test_steps_device`` is the entry point that overlaps them."""
+
+    def __init__(self, model, device=None, use_graph=True, lanes=1):
         self.model = model
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.use_graph = use_graph
         self._ws = {}
+        self.lanes = max(1, int(lanes))
+        self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)] if self.lanes > 1 else []
+        self._lane_ws = [{} for _ in range(self.lanes)]
 
     def test_step_device(self, inputs, qry_msk):
         """-> (argmax uint8 [B,Ho,Wo], stats f64 [B,8]) both on the GPU, no host synchronisation."""
@@ -122,6 +130,32 @@ class Evaluator:
                 pred, _ = self.model.lowres(*dev_in)
             am, stats, _ = ops.eval_tail(pred, tgt, ws_cache=self._ws)
         return am, stats
+
+    def test_steps_device(self, episodes):
+        """``episodes``: list of (inputs, qry_msk), ONE episode each, evaluated one per step in the given order (the
+        reference protocol).  -> stats f64 [len(episodes), 8] on the GPU, no host synchronisation.  With ``lanes`` > 1
+        step i runs on lane i % lanes (own stream, own engine replica and graphs); the caller's stream waits for all
+        lanes before the result is used."""
+        n = len(episodes)
+        rows = torch.empty((n, 8), dtype=torch.float64, device=self.device)
+        if self.lanes == 1:
+            for i, (inputs, qry_msk) in enumerate(episodes):
+                rows[i:i + 1].copy_(self.test_step_device(inputs, qry_msk)[1])
+            return rows
+        cur = torch.cuda.current_stream()
+        for s in self._lane_streams:
+            s.wait_stream(cur)
+        for i, (inputs, qry_msk) in enumerate(episodes):
+            k = i % self.lanes
+            with torch.cuda.stream(self._lane_streams[k]), self.model.lane(k), torch.no_grad():
+                dev_in = [x.to(self.device, non_blocking=True) for x in inputs]
+                tgt = qry_msk.view(-1, *qry_msk.shape[-2:]).to(self.device, non_blocking=True)
+                pred = self._lowres(dev_in)
+                _, stats, _ = ops.eval_tail(pred, tgt, ws_cache=self._lane_ws[k])
+                rows[i:i + 1].copy_(stats)
+        for s in self._lane_streams:
+            cur.wait_stream(s)
+        return rows
 
     def test_step_batch(self, episodes):
         """``episodes``: list of (inputs, qry_msk) with one episode each (any query-label sizes).  One encoder + head
@@ -189,8 +223,18 @@ class Evaluator:
             dataset.sample_tasks()
             rows, classes = [], []
             group = []
+            pending = []
             for inputs, qry_msk, cls in self._episodes(dataset, shard_indices(len(dataset), rank, world)):
                 classes += [int(c) for c in cls]
+                if batch == 1 and self.lanes > 1:          # one episode per step, several steps in flight
+                    pending.append((inputs, qry_msk))
+                    if len(pending) == 4 * self.lanes:
+                        t0 = time.time()
+                        rows.append(self.test_steps_device(pending))
+                        timed += time.time() - t0
+                        calls += len(pending)
+                        pending = []
+                    continue
                 if batch > 1:
                     group.append((inputs, qry_msk))
                     if len(group) < batch:
@@ -206,6 +250,11 @@ class Evaluator:
                 rows.append(self.test_step_batch(group))
                 timed += time.time() - t0
                 calls += len(group)
+            if pending:
+                t0 = time.time()
+                rows.append(self.test_steps_device(pending))
+                timed += time.time() - t0
+                calls += len(pending)
             t0 = time.time()
             st = torch.cat(rows).cpu().numpy() if rows else np.zeros((0, 8))
             timed += time.time() - t0
@@ -236,7 +285,8 @@ def test(_config, split, shot, seed):
     model = ModelClass(logger).cuda().eval()
     dcfg = _config["data"]
     data = SyntheticEpisodes(dcfg["test_n"], dcfg["test_seed"], shot, split, dcfg["height"], dcfg["width"], dcfg["dataset"])
-    ev = Evaluator(model)
+    # the reference's protocol is one episode per step (data.test_bs = 1): keep it, with four steps in flight
+    ev = Evaluator(model, lanes=4 if dcfg["test_bs"] == 1 else 1)
     nclass = num_classes(dcfg["dataset"])
     loss, miou, biou = ev.start_eval_loop(data, nclass, split, _config["te"]["epochs"], logger, batch=dcfg["test_bs"],
                                           dataset_name=dcfg["dataset"])

@@ -34,6 +34,7 @@ class BaseModel(nn.Module):
     # any change of the parameters invalidates the packed device copies used by the engine
     def _invalidate(self, bridge=False):
         self.__dict__["_engine"] = None
+        self.__dict__["_engines"] = {}          # every lane's replica (pemp_stage1._HeadMixin._engine_for)
         if bridge:                       # parameters were re-created (device / dtype move): the flat buffers are stale
             self.__dict__["_bridge"] = None
 

@@ -65,13 +65,34 @@ class _HeadMixin:
     """Episode head shared by stage 1 / stage 2 / baseline: prototypes -> cosine map -> upsample."""
 
     def _engine_for(self, device):
-        eng = self.__dict__.get("_engine")
+        """The inference engine (packed weights + activation arena + captured graphs) of the current LANE.  Lane 0 is
+        the default; ``with model.lane(k):`` selects replica k -- same weights, its own arena and graphs -- so that
+        several single-episode steps can be in flight on different HIP streams (entry.pemp_stage1.Evaluator(lanes=K))."""
+        lane = self.__dict__.get("_lane", 0)
+        engines = self.__dict__.setdefault("_engines", {})
+        eng = engines.get(lane)
         if eng is None or eng["device"] != device:
             arena = engine.Arena(device)
             eng = {"device": device, "arena": arena}
             self._build_engine(eng, arena)
+            engines[lane] = eng
+        if lane == 0:
             self.__dict__["_engine"] = eng
         return eng
+
+    def lane(self, k):
+        """Context manager: run the enclosed inference calls on engine replica ``k``."""
+        model = self
+
+        class _Lane:
+            def __enter__(self_inner):
+                self_inner.prev = model.__dict__.get("_lane", 0)
+                model.__dict__["_lane"] = k
+
+            def __exit__(self_inner, *exc):
+                model.__dict__["_lane"] = self_inner.prev
+                return False
+        return _Lane()
 
     @staticmethod
     def _require_eval_gpu(model, *tensors):

@@ -63,6 +63,28 @@ def test_batched_evaluation_gives_identical_metrics(hip_lib, dev):
     assert l0 == l1 and np.array_equal(m0, m1) and np.array_equal(b0, b1)
 
 
+def test_single_episode_steps_in_flight_give_identical_statistics(hip_lib, dev):
+    """The reference protocol (one episode per test_step) with 1 and with 4 steps in flight (Evaluator(lanes=4): engine
+    replicas on their own HIP streams): the per-episode statistics rows are bit-identical, in order, for ragged label sizes;
+    the evaluation loop returns identical metrics; and both equal the batched step."""
+    from pemp_amd.entry import pemp_stage1 as e
+    net = e.ModelClass(None)
+    net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    net = net.to(dev).eval()
+    data = e.SyntheticEpisodes(11, 5678, 1, split=0, height=97, width=97)
+    data.sample_tasks()
+    eps = [data.task(i)[:2] for i in range(11)]
+    rows = [e.Evaluator(net, device=dev, lanes=k).test_steps_device(eps).cpu() for k in (1, 4)]
+    rows.append(e.Evaluator(net, device=dev).test_step_batch(eps).cpu())
+    assert torch.equal(rows[0], rows[1]) and torch.equal(rows[0], rows[2])
+    again = e.Evaluator(net, device=dev, lanes=4)
+    assert torch.equal(again.test_steps_device(eps).cpu(), rows[0]) and torch.equal(again.test_steps_device(eps[::-1]).cpu(), rows[0].flip(0))
+    res = [e.Evaluator(net, device=dev, lanes=k).start_eval_loop(e.SyntheticEpisodes(10, 5678, 1, split=0, height=97, width=97), 20, 0, te_epochs=2)
+           for k in (1, 3)]
+    (l0, m0, b0), (l1, m1, b1) = res
+    assert l0 == l1 and np.array_equal(m0, m1) and np.array_equal(b0, b1)
+
+
 def test_stage2_batched_evaluation_gives_identical_metrics(hip_lib, dev):
     """The stage-2 evaluator (stage-1 prior -> stage 2) through the same sharded loop: batch 3 == batch 1."""
     from pemp_amd.entry import pemp_stage2 as e2
