@@ -13,6 +13,8 @@
 //   The reduction over M is split over blockIdx.z; partial tiles go to a workspace and a second
 //   kernel adds them in a fixed order (deterministic, no atomics).
 #include "conv_common.h"
+#include <stdlib.h>
+#include <algorithm>
 
 namespace pemp {
 
@@ -245,6 +247,219 @@ __global__ __launch_bounds__(256) void conv_wgrad128_kernel(WgradArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second generation of the two kernels above (same GEMM view, LDS image, fragment reads and MFMA order: bit-identical
+// partial tiles), rebuilt the way conv_dma2.hip rebuilt the forward kernel:
+//   * both operands come in through `buffer_load_dwordx4 ... offen lds`.  The gradient rows are consecutive, so their
+//     per-lane offset is a constant and the reduction step lives in the SGPR offset; the activation rows follow the
+//     output pixel through (image, ho, wo) INCREMENTALLY (+32 pixels per step: one conditional wrap of wo, one of ho)
+//     instead of two integer divisions per row and step; rows / taps outside the image or beyond M get offset 2^31 and
+//     the buffer range check writes zeros;
+//   * one barrier per step, placed before the last quarter of the step's MFMAs (operands already in registers): the
+//     next step's first reads and the DMA of the step after that are issued in their shadow.
+// TW = 64 / 128: tile TW co x TW weight columns per block of 2x2 waves.  Needs Wo >= 32 (one wrap per step) and
+// operands below 2 GiB; the stem keeps conv_wgrad_kernel<true>.
+template <int TW>
+__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int QPR = TW / 4;            // quads per pixel row of a tile
+    constexpr int RPR = 256 / QPR;         // pixel rows per DMA round of the block
+    constexpr int NR = 32 / RPR;           // DMA rounds per operand and step
+    constexpr int T = TW / 64;             // 32x32 MFMA tiles per wave and dimension
+    constexpr int WNDS = 4 * T;            // ds_read2_b32 per quarter (the compiler pairs the 8 T dword reads)
+    constexpr int WPER = (WNDS + 2 * NR + 4 * T * T - 1) / (4 * T * T);
+    extern __shared__ __attribute__((aligned(16))) v4f smem[];
+    v4f* Gs = smem;                        // [2][32 px][QPR]
+    v4f* Xs = smem + 2 * 32 * QPR;         // [2][32 px][QPR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int co0 = blockIdx.x * TW;
+    const int ky = blockIdx.y;             // TW-column tile of the weight row: one tap, TW input channels
+    const int split = blockIdx.z;
+    const int s_begin = split * a.steps_per_split;
+    const int s_end = min(s_begin + a.steps_per_split, a.steps_total);
+    const int nsteps = s_end - s_begin;
+
+    const int cin_tiles = a.Cin / TW;
+    const int tap = ky / cin_tiles;
+    const int ci0 = (ky - tap * cin_tiles) * TW;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int dh = kh * a.dil - a.pad, dw = kw * a.dil - a.pad;
+
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0x80000000u, 0x00020000);
+
+    // loader role: thread (row = tid / QPR, q = tid % QPR) fetches quad q of pixel rows row + RPR i of the step
+    const int q = tid % QPR, row = tid / QPR;
+    unsigned g_voff[NR];
+    int x_m[NR], x_ho[NR], x_wo[NR];
+    unsigned x_off[NR];                    // byte offset of (img, ho*stride, wo*stride) + tap displacement + channel quad
+    const int ldx4 = a.ldx * 4;
+    const int inc32 = 32 * a.stride * ldx4;                                 // 32 output pixels further in the same row
+    const int incw = (a.stride * a.W - a.Wo * a.stride) * ldx4;             // wo wrapped: next output row
+    const int inch = (a.H * a.W - a.Ho * a.stride * a.W) * ldx4;            // ho wrapped: next image
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int m = s_begin * 32 + row + RPR * i;
+        g_voff[i] = (unsigned)((row + RPR * i) * a.ldg + co0 + q * 4) * 4u;
+        const int mm = m < a.M ? m : 0;
+        const int img = mm / a.HoWo;
+        const int rem = mm - img * a.HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        x_m[i] = m;
+        x_ho[i] = ho;
+        x_wo[i] = wo;
+        // may be "negative" (wraps) for out-of-image taps; only used when the tap is inside the image
+        x_off[i] = (unsigned)((((img * a.H + ho * a.stride + dh) * a.W + wo * a.stride + dw) * a.ldx + ci0 + q * 4) * 4);
+    }
+    int s_g = s_begin * 32 * a.ldg * 4;    // SGPR offset of the gradient rows of the step being fetched
+    const int s_ginc = 32 * a.ldg * 4;
+
+#define PEMP_WG2_DMA(buf_)                                                                                        \
+    do {                                                                                                          \
+        v4f* Gd_ = Gs + (buf_) * 32 * QPR + wave * 64;                                                            \
+        v4f* Xd_ = Xs + (buf_) * 32 * QPR + wave * 64;                                                            \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                          \
+            const bool mok = x_m[i] < a.M;                                                                        \
+            const int hi = x_ho[i] * a.stride + dh, wi = x_wo[i] * a.stride + dw;                                 \
+            const bool ok = mok & ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);   /* no branches */ \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lptr_t)(Gd_ + i * 256), 16, mok ? g_voff[i] : 0x80000000u, s_g, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(Xd_ + i * 256), 16, ok ? x_off[i] : 0x80000000u, 0, 0, 0);    \
+            /* advance this row by 32 output pixels (Wo >= 32: at most one wrap of wo, then at most one of ho) */ \
+            x_m[i] += 32;                                                                                         \
+            int wo_ = x_wo[i] + 32;                                                                               \
+            unsigned off_ = x_off[i] + (unsigned)inc32;                                                           \
+            const bool c1 = wo_ >= a.Wo;                                                                          \
+            wo_ = c1 ? wo_ - a.Wo : wo_;                                                                          \
+            off_ += c1 ? (unsigned)incw : 0u;                                                                     \
+            int ho_ = x_ho[i] + (c1 ? 1 : 0);                                                                     \
+            const bool c2 = ho_ >= a.Ho;                                                                          \
+            ho_ = c2 ? ho_ - a.Ho : ho_;                                                                          \
+            off_ += c2 ? (unsigned)inch : 0u;                                                                     \
+            x_wo[i] = wo_;                                                                                        \
+            x_ho[i] = ho_;                                                                                        \
+            x_off[i] = off_;                                                                                      \
+        }                                                                                                         \
+        s_g += s_ginc;                                                                                            \
+    } while (0)
+
+    f32x16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (nsteps > 0) {
+        PEMP_WG2_DMA(0);
+        if (nsteps > 1) {
+            PEMP_WG2_DMA(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NR) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const float* Gf = (const float*)Gs;
+    const float* Xf = (const float*)Xs;
+    const int gcol = wr * (TW / 2) + lr, xcol = wc * (TW / 2) + lr;
+    float ga[2][4][T], xa[2][4][T];        // [register buffer][t within the quarter][tile]
+
+    // quarter Q of a step = reduction sub-steps t = 4Q .. 4Q+3 (pixel pairs 2t, 2t+1)
+#define PEMP_WG2_READ(dst_, buf_, Q_)                                                                             \
+    do {                                                                                                          \
+        const float* Gb_ = Gf + (buf_) * 32 * TW + lh * TW + gcol;                                                \
+        const float* Xb_ = Xf + (buf_) * 32 * TW + lh * TW + xcol;                                                \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) _Pragma("unroll") for (int i_ = 0; i_ < T; ++i_) {       \
+            ga[dst_][t_][i_] = Gb_[(4 * (Q_) + t_) * 2 * TW + 32 * i_];                                           \
+            xa[dst_][t_][i_] = Xb_[(4 * (Q_) + t_) * 2 * TW + 32 * i_];                                           \
+        }                                                                                                         \
+    } while (0)
+#define PEMP_WG2_MMA(src_)                                                                                        \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) _Pragma("unroll") for (int i_ = 0; i_ < T; ++i_)         \
+            _Pragma("unroll") for (int j_ = 0; j_ < T; ++j_)                                                      \
+                acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[src_][t_][i_], xa[src_][t_][j_], acc[i_][j_], 0, 0, 0); \
+    } while (0)
+#define PEMP_WG2_STEP(buf_, DMA_, NEXT_)                                                                          \
+    do {                                                                                                          \
+        PEMP_WG2_READ(1, buf_, 1);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_WG2_MMA(0);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_WG2_READ(0, buf_, 2);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_WG2_MMA(1);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_WG2_READ(1, buf_, 3);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PEMP_WG2_MMA(0);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_waitcnt(0x0070);                /* vmcnt(0) lgkmcnt(0) */                              \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if (NEXT_) PEMP_WG2_READ(0, (buf_) ^ 1, 0);                                                               \
+        if (DMA_) PEMP_WG2_DMA(buf_);                                                                             \
+        PEMP_WG2_MMA(1);                                                                                          \
+        if (DMA_) {                     /* one LDS read / one DMA between consecutive MFMAs of the last quarter */ \
+            _Pragma("unroll") for (int k_ = 0; k_ < 4 * T * T; ++k_) {                                            \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+                _Pragma("unroll") for (int q_ = 0; q_ < WPER; ++q_) {                                             \
+                    const int it_ = k_ * WPER + q_;                                                               \
+                    if (it_ < WNDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+                    else if (it_ < WNDS + 2 * NR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+
+    if (nsteps > 0) {
+        PEMP_WG2_READ(0, 0, 0);
+        int k = 0;
+        for (; k + 2 < nsteps; ++k) {
+            const int buf = k & 1;
+            PEMP_WG2_STEP(buf, true, true);
+        }
+        if (k + 1 < nsteps) {
+            const int buf = k & 1;
+            PEMP_WG2_STEP(buf, false, true);
+            ++k;
+        }
+        {
+            const int buf = k & 1;
+            PEMP_WG2_STEP(buf, false, false);
+        }
+    }
+#undef PEMP_WG2_STEP
+#undef PEMP_WG2_MMA
+#undef PEMP_WG2_READ
+#undef PEMP_WG2_DMA
+
+    float* out = a.out + (size_t)split * a.Cout * a.Kpad;
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int col = ky * TW + wc * (TW / 2) + j * 32 + lr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wr * (TW / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                out[(size_t)co * a.Kpad + col] = acc[i][j][e];
+            }
+        }
+#endif
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int nsplit,
                                     int accumulate) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n / 4; i += (long long)gridDim.x * blockDim.x) {
@@ -337,7 +552,14 @@ extern "C" int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* 
     a.out = direct ? dw : (float*)ws;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(d->Cout / tw, tiles_k, a.nsplit);
-    if (big) {
+    // second-generation kernels: one wrap of wo per 32-pixel step, buffer offsets below 2 GiB (desc.tile = 1 asks for the
+    // first generation: the parity tests compare the two bit for bit)
+    const bool v2 = d->tile != 1 && !stem && d->Wo >= 32 && d->Cin % tw == 0 &&
+                    (long long)d->N * d->H * d->W * d->ldx * 4 < (1ll << 31) && (long long)a.M * d->ldy * 4 < (1ll << 31);
+    if (v2) {
+        if (big) hipLaunchKernelGGL(conv_wgrad2_kernel<128>, grid, dim3(256), 2 * 2 * 32 * 32 * sizeof(v4f), st, a);
+        else hipLaunchKernelGGL(conv_wgrad2_kernel<64>, grid, dim3(256), 2 * 2 * 32 * 16 * sizeof(v4f), st, a);
+    } else if (big) {
         hipLaunchKernelGGL(conv_wgrad128_kernel, grid, dim3(256), 2 * 2 * 32 * 32 * sizeof(v4f), st, a);
     } else {
         const size_t lds = 2 * 2 * 32 * 16 * sizeof(v4f);

@@ -91,9 +91,10 @@ def relu_bias_bwd(dy, y, g, add=None, relu=True, want_dbias=True, ws_cache=None,
     return dbias
 
 
-def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None):
+def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0):
     """dw (KRSC [Cout, Kpad_w]) (+)= wgrad of the conv described by ConvParams ``p`` (geometry only).
-    For the stem ``dw`` has row length ceil(KH*KW*4 / 64) * 64."""
+    For the stem ``dw`` has row length ceil(KH*KW*4 / 64) * 64.  ``variant`` = 1: the first-generation kernels
+    (pointer-addressed; the library picks the buffer-addressed second generation where it applies, bit-identical)."""
     lib = _lib.load()
     _chk_dev(x, g, dw)
     from .ops import _nhwc
@@ -108,7 +109,7 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None):
     if dw.shape[0] != cout or not dw.is_contiguous():
         raise ValueError("conv_wgrad: dw must be contiguous [Cout, Kpad]")
     d = ConvDesc(n, h, w, cin, ldx, ho, wo, cout, ldg, p.kh, p.kw, p.stride, p.pad, p.dil, 0, kpad,
-                 CONV_STEM4 if p.stem else 0, 0)
+                 CONV_STEM4 if p.stem else 0, int(variant))
     nbytes = lib.pemp_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = _ws(nbytes, x.device, ws_cache, ("wgrad", nbytes))
     _lib.check(lib.pemp_conv2d_wgrad_nhwc_f32(C.byref(d), _p(x), _p(g), _p(dw), 1 if accumulate else 0, _p(ws),

@@ -91,3 +91,36 @@ def test_conv_backward_fuzz(hip_lib, dev, case):
     if s == 1 and tuple(dx.shape[1:3]) != (H, W):
         pytest.skip("geometry whose input gradient is not a same-size conv")
     assert ((dx.permute(0, 3, 1, 2).cpu() - ref).abs() / (1 + ref.abs())).max().item() < 4e-5 * max(1.0, (Cout * k * k / 64) ** 0.5), case
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, k, s, p, d      (Wo >= 32: the shapes the buffer-addressed weight-gradient kernels take)
+    (2, 51, 51, 256, 256, 3, 1, 2, 2), (3, 51, 51, 128, 512, 1, 1, 0, 1), (2, 101, 101, 64, 64, 3, 1, 1, 1),
+    (2, 101, 101, 256, 128, 1, 2, 0, 1), (1, 40, 33, 128, 256, 3, 1, 6, 6), (2, 37, 45, 64, 192, 3, 1, 1, 1),
+    (1, 32, 32, 1024, 256, 1, 1, 0, 1), (2, 33, 64, 128, 128, 5, 1, 2, 1)], ids=lambda c: "x".join(str(v) for v in c))
+def test_wgrad_generations_bit_identical_and_match_autograd(hip_lib, dev, case):
+    """conv_wgrad2_kernel (buffer-addressed LDS-DMA, incremental pixel walk, barrier inside the MFMA stream) against the
+    first-generation kernels bit for bit (same split, same reduction order) and against torch autograd; plain and
+    accumulating, ragged M (not a multiple of the 32-pixel step)."""
+    from pemp_amd import ops, train_ops as T
+    N, H, W, Cin, Cout, k, s, p, d = case
+    x = _rand(N, Cin, H, W, seed=1).requires_grad_(False)
+    w = (_rand(Cout, Cin, k, k, seed=2) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p, d)
+    g = _rand(*y.shape, seed=3)
+    (gw,) = torch.autograd.grad(y, w, g)
+    ref = gw.permute(0, 2, 3, 1).reshape(Cout, -1)
+    prm = ops.ConvParams(None, None, None, Cin, Cout, k, k, s, p, d, k * k * Cin, False, False)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    gd = g.permute(0, 2, 3, 1).contiguous().to(dev)
+    outs = []
+    for variant in (1, 0):
+        dw = torch.full((Cout, k * k * Cin), float("nan"), device=dev)
+        T.conv_wgrad(xd, gd, prm, dw, variant=variant)
+        outs.append(dw.clone())
+        T.conv_wgrad(xd, gd, prm, dw, accumulate=True, variant=variant)
+        outs.append(dw.clone())
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    scale = ref.abs().max().item()
+    assert (outs[2].cpu() - ref).abs().max().item() <= 2e-5 * scale * max(1.0, (N * y.shape[2] * y.shape[3] / 4096) ** 0.5)
+    assert (outs[3].cpu() - 2 * ref).abs().max().item() <= 4e-5 * scale * max(1.0, (N * y.shape[2] * y.shape[3] / 4096) ** 0.5)
