@@ -250,7 +250,7 @@ def instrumented(run, reps=3):
 
 def summarize(rec, reps, step_ms=None):
     """Per-class time / work of a step from the instrumented records, and the roofline object of the conv class."""
-    by, layers = {}, {}
+    by, layers, entries = {}, {}, {}
     conv_ms = conv_fl = conv_by = 0.0
     conv_n = 0
     for name, e0, e1, a in rec:
@@ -259,6 +259,9 @@ def summarize(rec, reps, step_ms=None):
         c = by.setdefault(cls, {"ms": 0.0, "launches": 0, "gflop": 0.0})
         c["ms"] += ms
         c["launches"] += 1
+        en = entries.setdefault(name, [0.0, 0])
+        en[0] += ms
+        en[1] += 1
         if cls in ("conv", "wgrad"):
             fl, nb, shape = _conv_work(name, a)
             c["gflop"] += fl / 1e9
@@ -288,7 +291,9 @@ def summarize(rec, reps, step_ms=None):
             "launches_per_step": conv_n // reps, "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
             "gflop_per_step": round(conv_fl / reps / 1e9, 2), "conv_ms_per_step": round(conv_ms / reps, 4),
             "timing": "HIP events around every launch on its own stream, eager pass of the same workload inside bench.py",
-            "by_layer": by_layer, "by_class": out}
+            "by_layer": by_layer, "by_class": out,
+            "by_entry": {k: {"ms_per_step": round(v[0] / reps, 3), "calls_per_step": v[1] // reps}
+                         for k, v in sorted(entries.items(), key=lambda kv: -kv[1][0])[:10]}}
     if step_ms:
         roof["step_effective_tflops"] = round(conv_fl / reps / 1e9 / step_ms, 2)
     return roof

@@ -5,10 +5,12 @@
 // All reductions are two-stage with a fixed order (per-chunk partials in double, then a serial
 // sum over chunks), so every result is deterministic and independent of launch geometry.
 #include "common.h"
+#include <stdlib.h>
 
 namespace pemp {
 
-constexpr int RCHUNK = 256;   // rows per partial in the per-channel reductions
+constexpr int RCHUNK = 64;    // rows per partial in the per-channel reductions (4 per thread, all loads issued before the sums:
+                              // M = 20.8k rows x 256 channels gives 1300 blocks instead of 328, 12 loads in flight per thread)
 
 // -----------------------------------------------------------------------------------------------
 // per-channel sums over rows:  out[chunk][0][c] = sum_r a(r,c),  out[chunk][1][c] = sum_r b(r,c)
@@ -38,9 +40,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
                 is[e] = invstd[c + e];
             }
         }
-        for (int r = r0 + rl; r < r1; r += 16) {
-            float4 a = *(const float4*)(p0 + (size_t)r * ld0 + c);
-            float av[4] = {a.x, a.y, a.z, a.w};
+        constexpr int RPT = RCHUNK / 16;
+        float4 A[RPT], Y[RPT], Z[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {                 // every load of the thread first ...
+            const int r = r0 + rl + 16 * k;
+            A[k] = Y[k] = Z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < r1) {
+                A[k] = *(const float4*)(p0 + (size_t)r * ld0 + c);
+                if (MODE != 0 && relu) Y[k] = *(const float4*)(p1 + (size_t)r * ld1 + c);
+                if (MODE == 1) Z[k] = *(const float4*)(p2 + (size_t)r * ld2 + c);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {                 // ... then the sums, rows in ascending order
+            if (r0 + rl + 16 * k >= r1) continue;
+            float av[4] = {A[k].x, A[k].y, A[k].z, A[k].w};
             if (MODE == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -49,14 +64,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
                 }
             } else {
                 if (relu) {
-                    float4 y = *(const float4*)(p1 + (size_t)r * ld1 + c);
-                    float yv[4] = {y.x, y.y, y.z, y.w};
+                    const float yv[4] = {Y[k].x, Y[k].y, Y[k].z, Y[k].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) av[e] = yv[e] > 0.f ? av[e] : 0.f;
                 }
                 if (MODE == 1) {
-                    float4 z = *(const float4*)(p2 + (size_t)r * ld2 + c);
-                    float zv[4] = {z.x, z.y, z.z, z.w};
+                    const float zv[4] = {Z[k].x, Z[k].y, Z[k].z, Z[k].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         sa[e] += av[e];
@@ -225,6 +238,144 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, int lddy, const fl
         *(float4*)(g + m * ldg + c) = d;
     }
 }
+
+
+// -----------------------------------------------------------------------------------------------
+// Row-walking forms of the three element-wise passes (C/4 divides 256, i.e. C in {64, 128, 256, 512, 1024}): a thread
+// owns ONE channel quad for its whole life -- the per-channel constants sit in registers, there is no 64-bit
+// index division per element -- and handles ROWS_PT rows with all loads issued before the arithmetic.  The arithmetic
+// per element is the expression of the grid-stride kernels above, so the results are bit-identical.
+constexpr int ROWS_PT = 4;
+
+__global__ __launch_bounds__(256) void bn_apply_rows_kernel(const float* __restrict__ z, int ldz,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ res, int ldr, float* __restrict__ y,
+                                                            int ldy, int M, int C4, int relu) {
+    const int c = (threadIdx.x % C4) * 4, rpb = 256 / C4;
+    float alpha[4], bt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        alpha[e] = invstd[c + e] * gamma[c + e];
+        bt[e] = beta[c + e] - mean[c + e] * alpha[e];
+    }
+    const int r0 = blockIdx.x * rpb * ROWS_PT + threadIdx.x / C4;
+    float4 v[ROWS_PT], rv[ROWS_PT];
+#pragma unroll
+    for (int k = 0; k < ROWS_PT; ++k) {
+        const int m = r0 + k * rpb;
+        if (m < M) {
+            v[k] = *(const float4*)(z + (size_t)m * ldz + c);
+            if (res) rv[k] = *(const float4*)(res + (size_t)m * ldr + c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS_PT; ++k) {
+        const int m = r0 + k * rpb;
+        if (m >= M) continue;
+        const float zv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = zv[e] * alpha[e] + bt[e];
+        if (res) {
+            o[0] += rv[k].x; o[1] += rv[k].y; o[2] += rv[k].z; o[3] += rv[k].w;
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        *(float4*)(y + (size_t)m * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y,
+                                                                int ldy, const float* __restrict__ z, int ldz,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ sum_g,
+                                                                const float* __restrict__ sum_gx, float* __restrict__ dz, int lddz,
+                                                                float* __restrict__ gout, int ldg, int M, int C4, int relu) {
+    const int c = (threadIdx.x % C4) * 4, rpb = 256 / C4;
+    const float invM = 1.f / (float)M;
+    float is[4], mu[4], sg[4], sgx[4], isg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        is[e] = invstd[c + e];
+        mu[e] = mean[c + e];
+        sg[e] = sum_g[c + e] * invM;
+        sgx[e] = sum_gx[c + e] * invM;
+        isg[e] = is[e] * gamma[c + e];
+    }
+    const int r0 = blockIdx.x * rpb * ROWS_PT + threadIdx.x / C4;
+    float4 d4[ROWS_PT], y4[ROWS_PT], z4[ROWS_PT];
+#pragma unroll
+    for (int k = 0; k < ROWS_PT; ++k) {
+        const int m = r0 + k * rpb;
+        if (m < M) {
+            d4[k] = *(const float4*)(dy + (size_t)m * lddy + c);
+            if (relu) y4[k] = *(const float4*)(y + (size_t)m * ldy + c);
+            z4[k] = *(const float4*)(z + (size_t)m * ldz + c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS_PT; ++k) {
+        const int m = r0 + k * rpb;
+        if (m >= M) continue;
+        float g[4] = {d4[k].x, d4[k].y, d4[k].z, d4[k].w};
+        if (relu) {
+            const float yv[4] = {y4[k].x, y4[k].y, y4[k].z, y4[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+        }
+        const float zv[4] = {z4[k].x, z4[k].y, z4[k].z, z4[k].w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (zv[e] - mu[e]) * is[e];
+            o[e] = (g[e] - sg[e] - xh * sgx[e]) * isg[e];
+        }
+        *(float4*)(dz + (size_t)m * lddz + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (gout) *(float4*)(gout + (size_t)m * ldg + c) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_rows_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y,
+                                                            int ldy, const float* __restrict__ add, int lda,
+                                                            float* __restrict__ g, int ldg, int M, int C4, int relu) {
+    const int c = (threadIdx.x % C4) * 4, rpb = 256 / C4;
+    const int r0 = blockIdx.x * rpb * ROWS_PT + threadIdx.x / C4;
+    float4 d[ROWS_PT], a4[ROWS_PT], yv[ROWS_PT];
+#pragma unroll
+    for (int k = 0; k < ROWS_PT; ++k) {
+        const int m = r0 + k * rpb;
+        if (m < M) {
+            d[k] = *(const float4*)(dy + (size_t)m * lddy + c);
+            if (add) a4[k] = *(const float4*)(add + (size_t)m * lda + c);
+            if (relu) yv[k] = *(const float4*)(y + (size_t)m * ldy + c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS_PT; ++k) {
+        const int m = r0 + k * rpb;
+        if (m >= M) continue;
+        float4 v = d[k];
+        if (add) {
+            v.x += a4[k].x; v.y += a4[k].y; v.z += a4[k].z; v.w += a4[k].w;
+        }
+        if (relu) {
+            v.x = yv[k].x > 0.f ? v.x : 0.f;
+            v.y = yv[k].y > 0.f ? v.y : 0.f;
+            v.z = yv[k].z > 0.f ? v.z : 0.f;
+            v.w = yv[k].w > 0.f ? v.w : 0.f;
+        }
+        *(float4*)(g + (size_t)m * ldg + c) = v;
+    }
+}
+
+static inline bool rows_form(int C) {
+    static const bool off = getenv("PEMP_BN_GRIDSTRIDE") != nullptr;      // A/B switch: the grid-stride kernels
+    return !off && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0;
+}
+static inline int rows_grid(int M, int C) { return cdiv(M, (256 / (C / 4)) * ROWS_PT); }
 
 // max-pool backward as a gather: dx[p] = sum over the output windows that contain p and whose
 // (first, scan-order) maximum is p.
@@ -399,8 +550,12 @@ extern "C" int pemp_bn_apply_f32(const float* z, int ldz, const float* mean, con
     PEMP_REQUIRE(M > 0 && mean && invstd && gamma && beta, "bn_apply: null pointer");
     if (residual) CHK_VEC(residual, ldr, C, "bn_apply");
     const long long total = (long long)M * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz, mean,
-                       invstd, gamma, beta, residual, ldr, y, ldy, (long long)M, C / 4, relu);
+    if (rows_form(C))
+        hipLaunchKernelGGL(bn_apply_rows_kernel, dim3(rows_grid(M, C)), dim3(256), 0, (hipStream_t)stream, z, ldz, mean, invstd,
+                           gamma, beta, residual, ldr, y, ldy, M, C / 4, relu);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz, mean,
+                           invstd, gamma, beta, residual, ldr, y, ldy, (long long)M, C / 4, relu);
     return launch_status("bn_apply");
 }
 
@@ -421,8 +576,12 @@ extern "C" int pemp_bn_bwd_f32(const float* dy, int lddy, const float* y, int ld
                        (double*)ws, M, C, relu);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nck, C, dbeta, dgamma);
     const long long total = (long long)M * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean,
-                       invstd, gamma, dbeta, dgamma, dz, lddz, gout, ldg, (long long)M, C / 4, relu);
+    if (rows_form(C))
+        hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3(rows_grid(M, C)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean,
+                           invstd, gamma, dbeta, dgamma, dz, lddz, gout, ldg, M, C / 4, relu);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean,
+                           invstd, gamma, dbeta, dgamma, dz, lddz, gout, ldg, (long long)M, C / 4, relu);
     return launch_status("bn_bwd");
 }
 
@@ -436,8 +595,12 @@ extern "C" int pemp_relu_bias_bwd_f32(const float* dy, int lddy, const float* y,
     PEMP_REQUIRE(M > 0, "relu_bias_bwd: M <= 0");
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)M * (C / 4);
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, lddy, y, ldy, add, lda, g, ldg,
-                       (long long)M, C / 4, relu);
+    if (rows_form(C))
+        hipLaunchKernelGGL(relu_bwd_rows_kernel, dim3(rows_grid(M, C)), dim3(256), 0, st, dy, lddy, y, ldy, add, lda, g, ldg,
+                           M, C / 4, relu);
+    else
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, lddy, y, ldy, add, lda, g, ldg,
+                           (long long)M, C / 4, relu);
     if (dbias) {
         PEMP_REQUIRE(ws && ws_bytes >= pemp_colsum_workspace_bytes(M, C), "relu_bias_bwd: workspace too small");
         const int nck = nchunks_rows(M);

@@ -7,7 +7,7 @@ is bit-equal to the reference in fp32 on every eval fixture) under torch autogra
 ``<case>_trainstep_f64.npz`` with the same sampled tensors as the fp32 fixture (keys ``g64__<name>``)
 and all gradient norms (``grad_norms64``).
 
-    python tests/golden/make_f64.py stage1 | stage2 | stage1_full | stage2_full
+    python tests/golden/make_f64.py stage1 | stage2 | stage1_full | stage2_full | baseline_rn50 | baseline_vgg16 | stage1_vgg16
 """
 import sys
 from pathlib import Path
@@ -26,7 +26,10 @@ from tests import util                  # noqa: E402
 CASES = {"stage1": ("stage1_rn50_trainstep", "stage1_rn50", 1234), "stage2": ("stage2_rn50cm_trainstep", "stage2_rn50cm", 4321),
          # the shapes BASELINE.json configs[2] / configs[3] run at (401x401; 4 one-shot episodes / one 5-shot episode)
          "stage1_full": ("stage1_rn50_trainstep_full", "stage1_rn50", 1234),
-         "stage2_full": ("stage2_rn50cm_trainstep5_full", "stage2_rn50cm", 4321)}
+         "stage2_full": ("stage2_rn50cm_trainstep5_full", "stage2_rn50cm", 4321),
+         "baseline_rn50": ("baseline_rn50_trainstep", "baseline_rn50", 1234),
+         "baseline_vgg16": ("baseline_vgg16_trainstep", "baseline_vgg16", 1234),
+         "stage1_vgg16": ("stage1_vgg16_trainstep", "stage1_vgg16", 1234)}
 
 
 def main(case):
@@ -50,8 +53,10 @@ def main(case):
     R.TRAIN = True
     try:
         ins = (t(b["sup_img"]).double(), t(b["sup_mask"]).double(), t(b["qry_img"]).double())
-        if case.startswith("stage1"):
-            logits = R.stage1_forward(sd, *ins, (H, H))
+        if case.startswith("baseline"):
+            logits = R.baseline_forward(sd, *ins, (H, H), backbone="resnet50" if case.endswith("rn50") else "vgg16")
+        elif case.startswith("stage1"):
+            logits = R.stage1_forward(sd, *ins, (H, H), backbone="vgg16" if case.endswith("vgg16") else "resnet50")
         else:
             from tests.golden.make_golden import stage2_train_prior
             prior = t(stage2_train_prior(b["qry_mask"])).double()
