@@ -136,7 +136,7 @@ def test_stage1_vgg16_trains_through_the_bridge(hip_lib, dev):
     loss = F.cross_entropy(net(sup, msk, qry, (97, 97)), gt, ignore_index=255)
     loss.backward()
     assert abs(loss.item() - float(g["loss"])) < 2e-5
-    util.check_gradients(g, util.gold("stage1_vgg16_trainstep_f64"), dict(net.named_parameters()), "bridge stage1 vgg16", eps=5e-4)
+    util.check_gradients(g, util.gold("stage1_vgg16_trainstep_f64"), dict(net.named_parameters()), "bridge stage1 vgg16")
     net.zero_grad()
     opt = torch.optim.SGD(net.parameters(), lr=2e-3, momentum=0.9, weight_decay=5e-4)
     sup, msk, qry, gt, _ = _batch(dev)

@@ -192,7 +192,8 @@ def check_gradients(g, g64, params, what, eps=3e-3):
         L2 :  |hip - g64|_2 <= 2 * |ref32 - g64|_2 + eps/2 * |g64|_2        (robust against single switched pixels)
         max:  |hip - g64|_oo <= 3 * |ref32 - g64|_oo + eps * |g64|_oo
     and for every parameter's gradient NORM  |n_hip - n_64| <= 2 * |n_ref32 - n_64| + eps * n_64.
-    ``eps`` = 3e-3 for the batch-statistics-BatchNorm models, 5e-4 for VGG-16 (no BatchNorm)."""
+    ``eps`` = 3e-3: one switched arg-max of VGG-16's stride-1 max pool already costs 1e-3 in L2 (scratch/vgg_layerwise.py: the
+    gradient is exact to 3e-6 above that pool and 1.3e-3 off below it, with no ReLU mask differing)."""
     bad, worst = [], 0.0
     for name, ref, ref64 in zip(g["grad_names"], g["grad_norms"], g64["grad_norms64"]):
         p = params[str(name)]
