@@ -47,6 +47,15 @@ class TrainingLoop:
                 self.scheduler.step()
             self._lr_counter = 0
 
+    def sync_buffers(self):
+        """BatchNorm running statistics (and every other buffer) of the trained model: rank 0's copy to all ranks, as
+        DDP's ``broadcast_buffers`` does.  Each rank updates them from its own batches; without this the sharded
+        evaluation would mix slightly different models and the saved checkpoint (rank 0's) would not reproduce the
+        logged validation mIoU."""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            for b in self.trainer.model.buffers():
+                dist.broadcast(b.data, 0)
+
     def _save(self, name):
         if self.rank != 0:
             return None
@@ -56,6 +65,7 @@ class TrainingLoop:
         return path
 
     def try_snapshot(self, epoch=-1, final=False):
+        self.sync_buffers()
         if final:
             return self._save("ckpt.pth")
         ce = self.cfg["tr"]["ckpt_epoch"]
@@ -64,6 +74,7 @@ class TrainingLoop:
         return None
 
     def evaluation(self, epoch, dataset, num_classes, split):
+        self.sync_buffers()
         self.trainer.model.eval()
         d = self.cfg["data"]
         mloss, miou, biou = self.evaluator.start_eval_loop(dataset, num_classes, split, self.cfg["te"]["epochs"], None,

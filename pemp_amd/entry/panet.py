@@ -87,13 +87,16 @@ class Trainer:
 
 
 @ex.command
-def test(_config, split, shot):
+def test(_config, split, shot, exp_id, ckpt):
     import logging
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     logger = logging.getLogger(NAME)
     if split < 0:
         raise ValueError("Argument `split` is required! For example: `python -m pemp_amd.entry.panet test with split=0`")
-    model = ModelClass(logger).cuda().eval()
+    from ..core.snapshots import load_for_eval
+    model = ModelClass(logger)
+    load_for_eval(model, _config, exp_id, ckpt, logger)          # find_snapshot + load_weights, as the reference's test
+    model = model.cuda().eval()
     ev = Evaluator(model)
     d = _config["data"]
     data = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"], d["dataset"])

@@ -274,15 +274,20 @@ class Evaluator:
 
 
 @ex.command
-def test(_config, split, shot, seed):
-    """``python -m pemp_amd.entry.pemp_stage1 test with split=0`` on synthetic episodes."""
+def test(_config, split, shot, seed, exp_id, ckpt):
+    """``python -m pemp_amd.entry.pemp_stage1 test with split=0 exp_id=1`` on synthetic episodes: the checkpoint is looked up
+    with the reference's rules (``exp_id`` / ``ckpt``, entry/pemp_stage1.py:157-158, utils/misc.py:123-147) and loaded; no
+    checkpoint -> FileNotFoundError (``ckpt=wgen`` opts into synthetic weights explicitly)."""
     import logging
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     logger = logging.getLogger(NAME)
     if split < 0:
         raise ValueError("Argument `split` is required! For example: `python -m pemp_amd.entry.pemp_stage1 test with split=0`")
     torch.manual_seed(seed)
-    model = ModelClass(logger).cuda().eval()
+    from ..core.snapshots import load_for_eval
+    model = ModelClass(logger)
+    load_for_eval(model, _config, exp_id, ckpt, logger)
+    model = model.cuda().eval()
     dcfg = _config["data"]
     data = SyntheticEpisodes(dcfg["test_n"], dcfg["test_seed"], shot, split, dcfg["height"], dcfg["width"], dcfg["dataset"])
     # the reference's protocol is one episode per step (data.test_bs = 1): keep it, with four steps in flight
@@ -294,7 +299,10 @@ def test(_config, split, shot, seed):
 
 
 def run_training(_config, name, make_trainer, make_evaluator, split, shot, seed, exp_id):
-    """Shared body of the three ``train`` commands: process-group setup, model broadcast, TrainingLoop on synthetic episodes."""
+    """Shared body of the ``train`` commands: process-group setup, broadcast of every model involved (the trained one and,
+    for stage 2, the frozen stage-1 prior network), TrainingLoop on synthetic episodes.  Checkpoints go to a FRESH run
+    directory ``<g.model_dir>/<tag>/<next id>`` (Sacred numbers its runs the same way); ``exp_id`` only ever names a run to
+    LOAD from."""
     import logging
     import os
     from ..core.base_trainer import TrainingLoop
@@ -310,9 +318,15 @@ def run_training(_config, name, make_trainer, make_evaluator, split, shot, seed,
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(seed + rank)
     d = _config["data"]
+    from ..core.snapshots import next_run_id
     trainer = make_trainer(logger if rank == 0 else None, dev)
     broadcast_model(trainer.model)
-    loop = TrainingLoop(_config, trainer, make_evaluator(trainer, dev), logger, run_id=exp_id if exp_id >= 0 else None)
+    if getattr(trainer, "stage1", None) is not None:          # the frozen prior network must be the same on every rank
+        broadcast_model(trainer.stage1)
+    run_id = torch.tensor([next_run_id(_config)], device=dev)
+    if world > 1:
+        dist.broadcast(run_id, 0)                             # rank 0 names the run
+    loop = TrainingLoop(_config, trainer, make_evaluator(trainer, dev), logger, run_id=int(run_id.item()))
     val = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"], d["dataset"])
 
     def batches(epoch):
@@ -383,15 +397,18 @@ def evaluate_and_save(model, dataset, out_dir, n_episodes, device=None):
 
 
 @ex.command
-def visualize(_config, split, shot, seed, tag, exp_id):
+def visualize(_config, split, shot, seed, tag, exp_id, ckpt):
     """``python -m pemp_amd.entry.pemp_stage1 visualize with split=0 test_n=20``: predictions and response maps of
     the first ``test_n`` evaluation episodes into ``http/static/<exp>`` (the layout the reference's html viewer reads)."""
     if split < 0:
         raise ValueError("Argument `split` is required!")
     torch.manual_seed(seed)
-    model = ModelClass(None).cuda().eval()
+    from ..core.snapshots import load_for_eval
+    model = ModelClass(None)
+    load_for_eval(model, _config, exp_id, ckpt)                  # entry/pemp_stage1.py:208-209
+    model = model.cuda().eval()
     dcfg = _config["data"]
-    data = SyntheticDecodedEpisodes(dcfg["test_n"], dcfg["test_seed"], shot, split, dcfg["height"], dcfg["width"])
+    data = SyntheticDecodedEpisodes(dcfg["test_n"], dcfg["test_seed"], shot, split, dcfg["height"], dcfg["width"], dcfg["dataset"])
     out = f"http/static/{exp_id}_{dcfg['dataset'].lower()}_{shot}shot_{tag}_s{split}"
     accs = evaluate_and_save(model, data, out, dcfg["test_n"])
     return f"saved {len(accs)} episodes to {out}; mean Dice {np.mean(accs):.3f}"

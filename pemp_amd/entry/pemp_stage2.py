@@ -81,8 +81,18 @@ class Trainer:
         return _Trainer(stage1, model, **kw)
 
 
+def load_stage1(_config, s1, logger=None, device=None):
+    """The frozen prior network of stage 2: ``PriorNet`` with the stage-1 checkpoint named by ``s1.id`` / ``s1.ckpt``
+    (entry/pemp_stage2.py:121-124: find_snapshot(cfg, s1.id, s1.ckpt) + load_weights + maybe_fix_params(fix=True))."""
+    from ..core.snapshots import load_for_eval
+    stage1 = PriorNet(logger)
+    load_for_eval(stage1, _config, s1["id"], s1["ckpt"], logger)
+    stage1.maybe_fix_params(True)
+    return (stage1.to(device) if device is not None else stage1.cuda()).eval()
+
+
 @ex.command
-def test(_config, split, shot, seed):
+def test(_config, split, shot, seed, exp_id, ckpt, s1):
     """``python -m pemp_amd.entry.pemp_stage2 test with split=0 shot=5``: stage-1 prior -> stage 2 on synthetic episodes."""
     import logging
     import numpy as np
@@ -91,8 +101,11 @@ def test(_config, split, shot, seed):
     if split < 0:
         raise ValueError("Argument `split` is required! For example: `python -m pemp_amd.entry.pemp_stage2 test with split=0`")
     torch.manual_seed(seed)
-    stage1 = PriorNet(logger).cuda().eval()
-    model = ModelClass(shot, _config["query"], logger).cuda().eval()
+    from ..core.snapshots import load_for_eval
+    stage1 = load_stage1(_config, s1, logger)
+    model = ModelClass(shot, _config["query"], logger)
+    load_for_eval(model, _config, exp_id, ckpt, logger, wgen_seed=4321)      # entry/pemp_stage2.py:176-177
+    model = model.cuda().eval()
     d = _config["data"]
     data = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"], d["dataset"])
     ev = Evaluator(stage1, model)
@@ -102,15 +115,14 @@ def test(_config, split, shot, seed):
 
 
 @ex.command
-def train(_config, split, shot, seed, loss, sigma, exp_id):
-    """Stage-2 training procedure (entry/pemp_stage2.py:67-83,86-140): the stage-1 model is frozen
-    (``maybe_fix_params(True)``, :126-129) and only provides the prior; clipping only for VGG (never here)."""
+def train(_config, split, shot, seed, loss, sigma, exp_id, s1):
+    """Stage-2 training procedure (entry/pemp_stage2.py:67-83,86-140): the stage-1 model is loaded from ``s1.id`` /
+    ``s1.ckpt``, frozen (``maybe_fix_params(True)``, :121-124) and only provides the prior; clipping only for VGG (never here)."""
     from .pemp_stage1 import run_training
     holder = {}
 
     def make_trainer(logger, dev):
-        stage1 = PriorNet(logger).to(dev).eval()
-        stage1.maybe_fix_params(True)
+        stage1 = load_stage1(_config, s1, logger, dev)
         holder["s1"] = stage1
         return Trainer(stage1, ModelClass(shot, _config["query"], logger), lr=_config["tr"]["lr"], device=dev, loss=loss, sigma=sigma)
 

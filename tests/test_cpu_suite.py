@@ -583,3 +583,67 @@ def test_committed_bench_line_honours_the_contract():
     assert abs(d["value"] - d["steps"] * d["config"]["episodes_per_step"] * d["n_gpus"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1.0
     t = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_traffic.json")))
     assert t["episodes_per_step"] == d["config"]["episodes_per_step"] and t["hbm_bytes_per_launch"] == r["traffic"]
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoint lookup (reference utils/misc.py:87-147) and loading before evaluation
+# ---------------------------------------------------------------------------------------------
+def test_find_snapshot_follows_the_reference_rules(tmp_path):
+    from pemp_amd.core import snapshots as S
+    cfg = {"g": {"model_dir": str(tmp_path)}, "tag": "pemp_stage2", "ckpt": "bestckpt.pth"}
+    with pytest.raises(FileNotFoundError, match="ckpt=wgen"):
+        S.find_snapshot(cfg, -1, None)
+    (tmp_path / "pemp_stage2" / "3").mkdir(parents=True)
+    (tmp_path / "pemp_stage2" / "3" / "ckpt.pth").write_bytes(b"x")
+    (tmp_path / "pemp_stage2" / "12").mkdir()
+    (tmp_path / "pemp_stage2" / "12" / "bestckpt.pth").write_bytes(b"x")
+    (tmp_path / "pemp_stage2" / "12" / "ckpt.pth").write_bytes(b"x")
+    (tmp_path / "pemp_stage1" / "7").mkdir(parents=True)
+    (tmp_path / "pemp_stage1" / "7" / "bestckpt.pth").write_bytes(b"x")
+    # 1. exp_id under the own tag: the named file, else bestckpt.pth, else ckpt.pth
+    assert S.find_snapshot(cfg, 3, None) == (tmp_path / "pemp_stage2" / "3" / "ckpt.pth", 3)
+    assert S.find_snapshot(cfg, 12, "ckpt.pth") == (tmp_path / "pemp_stage2" / "12" / "ckpt.pth", 12)
+    assert S.find_snapshot(cfg, 12, None) == (tmp_path / "pemp_stage2" / "12" / "bestckpt.pth", 12)
+    # 2. exp_id of another tag (the stage-1 run a stage-2 job names with s1.id)
+    assert S.find_snapshot(cfg, 7, "bestckpt.pth") == (tmp_path / "pemp_stage1" / "7" / "bestckpt.pth", 7)
+    # 3. a direct path
+    direct = tmp_path / "somewhere.pth"
+    direct.write_bytes(b"x")
+    assert S.find_snapshot(cfg, -1, str(direct)) == (direct, S.DIRECT)
+    # 4. no id, no path: the run with the largest id
+    assert S.find_snapshot(cfg, -1, None) == (tmp_path / "pemp_stage2" / "12" / "bestckpt.pth", 12)
+    # a fresh run never reuses an existing directory
+    assert S.next_run_id(cfg) == 13 and S.next_run_id({"g": {"model_dir": str(tmp_path)}, "tag": "baseline"}) == 1
+
+
+def test_commands_load_the_checkpoint_they_evaluate(tmp_path):
+    """``test`` / ``visualize`` / the stage-2 prior load a checkpoint before running (reference entry/pemp_stage1.py:157-158,
+    entry/pemp_stage2.py:121-124); a missing one is an error, ``ckpt=wgen`` is the explicit synthetic opt-in."""
+    import logging
+    from pemp_amd.core import snapshots as S
+    from pemp_amd.entry import pemp_stage2 as e2
+    from pemp_amd.networks import pemp_stage1 as m
+    cfg = {"g": {"model_dir": str(tmp_path)}, "tag": "pemp_stage1", "ckpt": "bestckpt.pth"}
+    src = m.ModelClass(None)
+    sd = util.wgen_state_dict("stage1_rn50", seed=77)
+    src.load_state_dict(sd)
+    (tmp_path / "pemp_stage1" / "4").mkdir(parents=True)
+    torch.save(src.state_dict(), tmp_path / "pemp_stage1" / "4" / "bestckpt.pth")
+    fresh = m.ModelClass(None)
+    assert S.load_for_eval(fresh, cfg, 4, None, logging.getLogger("t")) == tmp_path / "pemp_stage1" / "4" / "bestckpt.pth"
+    same = lambda a, b: all(torch.equal(v.reshape(-1), b[k].reshape(-1)) for k, v in a.items())     # (0-d counters travel as [1])
+    assert same(fresh.state_dict(), sd)
+    with pytest.raises(FileNotFoundError):
+        S.load_for_eval(m.ModelClass(None), dict(cfg, tag="baseline"), 99, "nothing.pth")
+    w = m.ModelClass(None)
+    assert S.load_for_eval(w, cfg, -1, "wgen") == "wgen"
+    assert same(w.state_dict(), util.wgen_state_dict("stage1_rn50"))
+    # the stage-2 prior network: s1.id names the stage-1 run (found under another tag), parameters frozen, eval mode
+    s1 = e2.load_stage1(dict(cfg, tag="pemp_stage2"), {"id": 4, "ckpt": "bestckpt.pth"}, None, torch.device("cpu"))
+    assert not s1.training and not any(p.requires_grad for p in s1.parameters())
+    assert same(s1.state_dict(), sd)
+    # the commands declare the keys they need
+    import inspect
+    from pemp_amd.entry import baseline as eb, panet as ep, pemp_stage1 as e1
+    for fn in (e1.test, e1.visualize, e2.test, eb.test, ep.test):
+        assert {"exp_id", "ckpt"} <= set(inspect.signature(getattr(fn, "__wrapped__", fn)).parameters), fn

@@ -209,3 +209,53 @@ def test_bench_under_an_external_launcher_uses_its_world_size():
                        env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _buffer_sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from pemp_amd.core.base_trainer import TrainingLoop
+        from pemp_amd.entry.train_stage1 import broadcast_model
+        torch.manual_seed(100 + rank)                       # every rank starts (and drifts) differently
+        model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8))
+        prior = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+        broadcast_model(model)
+        broadcast_model(prior)                              # run_training does this for trainer.stage1
+        model.train()
+        model(torch.randn(4, 3, 9, 9) * (1 + rank))         # rank-local batches move the running statistics apart
+        before = model[1].running_mean.clone()
+        loop = SimpleNamespace(trainer=SimpleNamespace(model=model))
+        TrainingLoop.sync_buffers(loop)                     # what evaluation() / try_snapshot() call first
+        q.put((rank, before.numpy(), model[1].running_mean.numpy().copy(), model[1].num_batches_tracked.item(),
+               [p.detach().numpy().copy() for p in prior.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_buffers_and_prior_network_are_synchronised():
+    """BN running statistics are rank 0's on every rank before an evaluation / snapshot (each rank updates them from its
+    own batches), and the frozen stage-1 prior network is identical on all ranks."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_buffer_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, b0, a0, n0, pr0), (_, b1, a1, n1, pr1) = res
+    assert not np.allclose(b0, b1)                          # they had drifted apart ...
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b0) and n0 == n1     # ... and both hold rank 0's afterwards
+    assert all(np.array_equal(x, y) for x, y in zip(pr0, pr1))

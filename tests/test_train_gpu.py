@@ -285,3 +285,37 @@ def test_overlapped_gradient_buckets_on_one_rank_match_the_plain_step(hip_lib, d
         assert torch.equal(weights[0], weights[1])
     finally:
         dist.destroy_process_group()
+
+
+def test_train_command_writes_a_fresh_run_and_test_command_loads_it(hip_lib, dev, tmp_path):
+    """The command layer end to end (reference entry/pemp_stage1.py:68-113,116-167): ``train`` writes checkpoints into a
+    FRESH run directory (never into an existing one), ``test with exp_id=<run>`` finds that checkpoint with the
+    reference's lookup rules and evaluates THOSE weights; ``test`` without any checkpoint is an error, not an evaluation
+    of random weights."""
+    from pemp_amd.entry import pemp_stage1 as e
+    common = ["split=0", f"g.model_dir={tmp_path}", "data.height=97", "data.width=97", "data.test_n=6", "te.epochs=1", "data.test_bs=2"]
+
+    def run(*argv):
+        try:
+            return e.ex.run_commandline(["prog", *argv])
+        finally:
+            for ing in e.INGREDIENTS + [e.ex]:
+                ing._updates.clear()
+                ing._cfg = None
+
+    with pytest.raises(FileNotFoundError):
+        run("test", "with", *common)
+    (tmp_path / "pemp_stage1" / "1").mkdir(parents=True)           # an older run exists: the new one must not reuse its id
+    msg = run("train", "with", *common, "tr.total_epochs=1", "data.train_n=4", "data.bs=2", "exp_id=1")
+    d = tmp_path / "pemp_stage1" / "2"
+    assert sorted(p.name for p in d.iterdir()) == ["bestckpt.pth", "ckpt.pth"] and not list((tmp_path / "pemp_stage1" / "1").iterdir())
+    assert "pemp_stage1/2" in msg.replace("\\", "/")
+    out = run("test", "with", *common, "exp_id=2")
+    assert out.startswith("Loss:") and "mIoU" in out
+    # the evaluated weights are the checkpoint's: the same numbers as an evaluator fed from the file directly
+    net = e.ModelClass(None)
+    net.load_weights(d / "bestckpt.pth", __import__("logging").getLogger("t"))
+    ev = e.Evaluator(net.to(dev).eval(), device=dev)
+    loss, miou, biou = ev.start_eval_loop(e.SyntheticEpisodes(6, 5678, 1, 0, 97, 97), 20, 0, te_epochs=1, batch=2)
+    assert out == f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
+    assert run("test", "with", *common, "ckpt=wgen").startswith("Loss:")
