@@ -160,6 +160,28 @@ def vgg16(x, sd, p, last_relu=False):
     return x
 
 
+_VGG_CM = (  # VGG16CM (networks/backbones.py:424-466): (layer, [conv indices], dilation, pool stride | None)
+    ("layer1", (0, 2), 1, 2), ("layer2", (0, 2), 1, 2), ("layer3", (0, 2, 4), 1, 2), ("layer4", (0, 2, 4), 1, 1),
+    ("layer5", (0, 2, 4), 2, None),
+)
+
+
+def vgg16_cm(x, mask, sd, p, spq, last_relu=False):
+    """VGG16CM.forward (networks/backbones.py:482-500): after each of the first four stages the communication module's
+    two channels are concatenated; the mask is pooled inside ``comm`` only (strides 2, 2, 2, 1)."""
+    for li, (layer, convs, d, pool) in enumerate(_VGG_CM):
+        for k, idx in enumerate(convs):
+            x = _conv(x, sd, f"{p}.{layer}.{idx}", padding=d, dilation=d)
+            if not (pool is None and k == len(convs) - 1 and not last_relu):
+                x = F.relu(x)
+        if pool is None:
+            return x
+        x = F.max_pool2d(x, 3, pool, 1)
+        c, mask = _comm(x, mask, sd, f"{p}.linear{li + 1}", pool, spq)
+        x = torch.cat([x, c], 1)
+    return x
+
+
 def encoder_stage1(x, sd, backbone="resnet50"):
     """PEMPStage1.encoder (networks/pemp_stage1.py:60-100)."""
     if backbone == "vgg16":
@@ -303,15 +325,18 @@ def panet_forward(sd, sup_img, sup_mask, qry_img, out_shape=None, backbone="vgg1
 
 
 def stage2_forward(sd, sup_img, sup_mask, qry_img, qry_prior, out_shape=None, ret_ind=False,
-                   protos2=3, dist_scalar=20, ret_lowres=False):
-    """PEMPStage2.forward, ResNet-50+CM (networks/pemp_stage2.py:104-162)."""
+                   protos2=3, dist_scalar=20, ret_lowres=False, backbone2="resnet50"):
+    """PEMPStage2.forward (networks/pemp_stage2.py:104-162): ResNet-50+CM with the purifier, or VGG16CM (no purifier)."""
     B, S, ch, H, W = sup_img.shape
     Q = qry_img.shape[1]
     img = torch.cat((sup_img, qry_img), dim=1).view(B * (S + Q), ch, H, W)
     prior = torch.cat((sup_mask[:, :, :1], qry_prior.view(B, Q, *qry_prior.shape[-3:]).float()), dim=1)
     prior = prior.view(B * (S + Q), 1, H, W)
-    f = resnet_cm(torch.cat((img, prior), dim=1), prior, sd, "encoder.backbone", S + Q)
-    f = purifier(f, sd, "encoder.purifier", v2=False)
+    if backbone2 == "vgg16":
+        f = vgg16_cm(torch.cat((img, prior), dim=1), prior, sd, "encoder.backbone", S + Q)
+    else:
+        f = resnet_cm(torch.cat((img, prior), dim=1), prior, sd, "encoder.backbone", S + Q)
+        f = purifier(f, sd, "encoder.purifier", v2=False)
     _, c, h, w = f.shape
     f = f.view(B, S + Q, c, h, w)
     m = F.interpolate(sup_mask.view(B * S, 2, H, W), (h, w), mode="nearest")

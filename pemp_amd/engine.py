@@ -51,11 +51,12 @@ class Arena:
         self.bufs = {}
         self.ws = {}
 
-    def get(self, name, shape, dtype=torch.float32):
+    def get(self, name, shape, dtype=torch.float32, zero=False):
+        """``zero``: cleared ONCE, when the buffer is created (for buffers with regions nobody writes afterwards)."""
         key = (name, tuple(shape), dtype)
         t = self.bufs.get(key)
         if t is None:
-            t = torch.empty(shape, dtype=dtype, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self.bufs[key] = t
         return t
 
@@ -159,6 +160,69 @@ class ResNetCMEngine(ResNetEngine):
             x = self._block(x, b0, (si, 0), c1_shift, ds_shift)
             for bi, bp in enumerate(blocks[1:], start=1):
                 x = self._block(x, bp, (si, bi & 1))
+        return x
+
+
+class VGG16CMEngine:
+    """VGG16CM (reference: networks/backbones.py:424-500).
+
+    Unlike ResNetCM, whose communication channels enter 1x1 convs (a per-image bias), here they enter zero-padded 3x3
+    convs: at the image border some taps of the constant planes read padding, so their contribution is not constant
+    over space.  They are therefore really concatenated: every stage's pooled output is written into the first C
+    channels of a [N,h,w,C+32] buffer (the max-pool kernel takes an output stride), the two broadcast values into
+    channels C, C+1, and the next stage's first conv runs over C+32 input channels with zero weights on the 30 padding
+    channels (the conv engine wants Cin % 32 == 0): 50 / 25 / 12 / 6 % more K on four of the thirteen convs."""
+    PADC = 32
+
+    def __init__(self, prm, arena):
+        from .networks.backbones import VGG_CM_LAYOUT
+        self.arena, self.spq = arena, prm.spq
+        self.stages = []
+        first = True
+        for si, (name, nconv, cout, d, pool) in enumerate(VGG_CM_LAYOUT):
+            seq = getattr(prm, name)
+            convs = []
+            for k in range(nconv):
+                conv = seq[2 * k]
+                relu = not (pool is None and k == nconv - 1 and not prm.last_relu)
+                if k == 0 and not first:
+                    convs.append(self._pack_extra(conv, relu))
+                else:
+                    convs.append(conv_params(conv, None, relu=relu, stem4=first and k == 0))
+            self.stages.append((convs, cout, pool))
+            first = False
+        self.lin = [(l.weight.detach().float().contiguous(), l.bias.detach().float().contiguous())
+                    for l in (prm.linear1, prm.linear2, prm.linear3, prm.linear4)]
+        self.group, self.n_groups = None, 0
+
+    def _pack_extra(self, conv, relu):
+        """[Cout, C+2, 3, 3] -> KRSC over C + PADC input channels (zero weights on the padding channels)."""
+        w = conv.weight.detach().float()
+        co, ci, kh, kw = w.shape
+        wp = torch.zeros((co, kh, kw, ci - 2 + self.PADC), dtype=torch.float32, device=w.device)
+        wp[..., :ci] = w.permute(0, 2, 3, 1)
+        cin = ci - 2 + self.PADC
+        return ConvParams(wp.reshape(co, kh * kw * cin).contiguous(), None, conv.bias.detach().float().contiguous(), cin, co,
+                          kh, kw, 1, conv.padding[0], conv.dilation[0], kh * kw * cin, False, relu)
+
+    def forward(self, x4, prior):
+        """x4: NHWC4 input (RGB + prior); prior: [N,H,W] fp32 mask plane -> NHWC features [N,h,w,512]."""
+        a = self.arena
+        x, mask = x4, prior
+        for si, (convs, cout, pool) in enumerate(self.stages):
+            for k, cp in enumerate(convs):
+                n, h, w, _ = x.shape
+                x = ops.conv2d(x, cp, out=a.get(("vcm", si, k & 1), (n, h, w, cp.cout)))
+            if pool is None:
+                return x
+            n, h, w, c = x.shape
+            ho, wo = ops._pool_out(h, 3, pool, 1, False), ops._pool_out(w, 3, pool, 1, False)
+            wide = a.get(("vcm_cat", si), (n, ho, wo, c + self.PADC), zero=True)      # padding channels stay zero
+            xs = ops.maxpool2d(x, 3, pool, 1, out=wide[..., :c])
+            mask, stat = ops.cm_reduce(xs, mask, pool)                                # comm: mask pooled with the stage's stride
+            _, feat = ops.cm_linear(stat, self.group, self.lin[si][0], self.lin[si][1], self.n_groups)
+            wide[..., c:c + 2] = feat.index_select(0, self.group.long()).view(n, 1, 1, 2)   # broadcast over space (and the episode)
+            x = wide
         return x
 
 

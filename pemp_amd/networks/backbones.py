@@ -120,6 +120,38 @@ class ResNetCMParams(ResNetParams):
         self.linear3 = nn.Linear(2 * 512, 2)
 
 
+#: VGG16CM stages (reference networks/backbones.py:431-463): (name, (cin of each conv), cout, dilation, pool stride | None);
+#: the first conv of layer2..5 takes the previous stage's channels + the 2 communication channels
+VGG_CM_LAYOUT = (("layer1", 2, 64, 1, 2), ("layer2", 2, 128, 1, 2), ("layer3", 3, 256, 1, 2), ("layer4", 3, 512, 1, 1),
+                 ("layer5", 3, 512, 2, None))
+
+
+class VGG16CMParams(nn.Module):
+    """VGG16 with communication modules: ``layer{1..5}.{0,2,4}.{weight,bias}``, ``linear{1..4}`` (backbones.py:424-470).
+    ReLU / MaxPool positions of the reference's nn.Sequentials are kept as parameter-free placeholders so that the
+    state_dict keys are the reference's."""
+
+    def __init__(self, init=4, last_relu=False, shot_query=None):
+        super().__init__()
+        self.spq, self.last_relu = shot_query, last_relu
+        cin = init
+        for name, nconv, cout, d, pool in VGG_CM_LAYOUT:
+            mods = []
+            for k in range(nconv):
+                mods += [_conv(cin if k == 0 else cout, cout, 3, 1, d, d, bias=True), nn.Identity()]
+            if pool is None and not last_relu:
+                mods.pop()
+            elif pool is not None:
+                mods.append(nn.Identity())
+            setattr(self, name, nn.Sequential(*mods))
+            cin = cout + 2
+        for i, c in enumerate((64, 128, 256, 512), start=1):
+            setattr(self, f"linear{i}", nn.Linear(2 * c, 2))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, nonlinearity="relu")
+
+
 _ASPP_DIL = (0, 0, 6, 12, 18)
 
 

@@ -39,6 +39,24 @@ def import_torchvision_trunk_cm(trunk, path, n=2):
     trunk.load_state_dict(cur)
 
 
+def import_torchvision_vgg_cm(trunk, path, n=2):
+    """VGG16CM.init_weights as written for ``cm = True`` (networks/backbones.py:503-533): the first 26 tensors of the
+    torchvision VGG-16 file in order, the stem zero-padded by one input channel, the first conv of layer2..5 (tensors 4, 8,
+    14, 20) by the n communication channels."""
+    pre = torch.load(str(path), map_location="cpu")
+    pre_keys = list(pre.keys())
+    cur = trunk.state_dict()
+    cur_keys = list(cur.keys())
+    for i in range(26):
+        w = pre[pre_keys[i]]
+        if i == 0:
+            w = torch.cat((w, torch.zeros((64, 1, 3, 3), dtype=w.dtype)), dim=1)
+        elif i in (4, 8, 14, 20):
+            w = torch.cat((w, torch.zeros((w.shape[0], n, 3, 3), dtype=w.dtype)), dim=1)
+        cur[cur_keys[i]] = w
+    trunk.load_state_dict(cur)
+
+
 class PEMPStage2(_HeadMixin, backbones.BaseModel):
     @net_ingredient.capture
     def __init__(self, shot, query, logger, backbone, backbone2, init_channels, out_channels, protos2, drop_rate2, cm):
@@ -46,27 +64,38 @@ class PEMPStage2(_HeadMixin, backbones.BaseModel):
         backbone2 = backbone2 or backbone
         if backbone2 not in pretrained_weights:
             raise ValueError(backbone_error.format(backbone2))
-        if backbone2 == "vgg16":
-            raise NotImplementedError(
-                "VGG16CM is broken in the reference as shipped (init_weights reads an undefined self.cm, "
-                "networks/backbones.py:518) and is not reproduced")
         self.spq = shot + query
+        self.backbone2_name = backbone2
         self.drop_rate2 = drop_rate2                                    # Dropout2d of the purifier / ASPP (train only)
-        trunk = backbones.ResNetCMParams(init_channels + 1, _RES_LAYERS[backbone2], freeze_bn=True, shot_query=self.spq)
-        self.encoder = nn.Sequential(OrderedDict([
-            ("backbone", trunk), ("purifier", backbones.purifier_params(out_channels, v2=False))]))
-        self.__class__.__name__ = "PEMP_Stage2/Resnet50" + cm * "+CM"
         pretrained = pretrained_weights[backbone2]
-        if Path(pretrained).exists():
-            import_torchvision_trunk_cm(trunk, pretrained)
+        if backbone2 == "vgg16":
+            # VGG16CM (networks/backbones.py:424-533) without a purifier (pemp_stage2.py:48-55).  As shipped the reference
+            # cannot get here with a pretrained file -- VGG16CM.init_weights reads ``self.cm``, which is never set (:518) --
+            # so only the crash is not reproduced: the import below is the one that method spells out for cm = True.
+            trunk = backbones.VGG16CMParams(init_channels + 1, last_relu=False, shot_query=self.spq)
+            self.encoder = nn.Sequential(OrderedDict([("backbone", trunk)]))
+            self.__class__.__name__ = "PEMP_Stage2/VGG16" + cm * "+CM"
+            if pretrained is not None and Path(pretrained).exists():
+                import_torchvision_vgg_cm(trunk, pretrained)
+        else:
+            trunk = backbones.ResNetCMParams(init_channels + 1, _RES_LAYERS[backbone2], freeze_bn=True, shot_query=self.spq)
+            self.encoder = nn.Sequential(OrderedDict([
+                ("backbone", trunk), ("purifier", backbones.purifier_params(out_channels, v2=False))]))
+            self.__class__.__name__ = "PEMP_Stage2/Resnet50" + cm * "+CM"
+            if pretrained is not None and Path(pretrained).exists():
+                import_torchvision_trunk_cm(trunk, pretrained)
         self.ctr = nn.Parameter(torch.rand(out_channels, protos2 * 2), requires_grad=True) if protos2 > 0 else None
         self.adaptive_p = None
         if logger is not None:
             logger.info(f"           ==> Model {self.__class__.__name__} created")
 
     def _build_engine(self, eng, arena):
-        eng["trunk"] = engine.ResNetCMEngine(self.encoder.backbone, arena)
-        eng["purifier"] = engine.PurifierEngine(self.encoder.purifier, arena)
+        if self.backbone2_name == "vgg16":
+            eng["trunk"] = engine.VGG16CMEngine(self.encoder.backbone, arena)
+            eng["purifier"] = None
+        else:
+            eng["trunk"] = engine.ResNetCMEngine(self.encoder.backbone, arena)
+            eng["purifier"] = engine.PurifierEngine(self.encoder.purifier, arena)
         eng["ctr"] = self.ctr.detach().float().contiguous() if self.ctr is not None else None
 
     def lowres(self, sup_img, sup_mask, qry_img, qry_prior, ret_ind=False, protos2=None, dist_scalar=None):
@@ -93,7 +122,9 @@ class PEMPStage2(_HeadMixin, backbones.BaseModel):
             g = torch.cat((torch.arange(B).repeat_interleave(S), torch.arange(B).repeat_interleave(Q)))
             a.ws[key] = g.to(device=sup_img.device, dtype=torch.int32)
         trunk.group, trunk.n_groups = a.ws[key], B
-        f = eng["purifier"].forward(trunk.forward(x4, prior))
+        f = trunk.forward(x4, prior)
+        if eng["purifier"] is not None:
+            f = eng["purifier"].forward(f)
         self.__dict__["_last_feats"] = f
         out = self._head(eng, f, sup_mask, B, S, Q, protos, dist_scalar, ret_ind, eng["ctr"])
         self.adaptive_p = self.__dict__["_last_protos"].permute(0, 2, 1)      # [B,c,2p], pemp_stage2.py:185
@@ -104,6 +135,10 @@ class PEMPStage2(_HeadMixin, backbones.BaseModel):
         if self.training:
             if ret_ind:
                 raise ValueError("ret_ind is an inference option; call model.eval()")
+            if self.backbone2_name == "vgg16":
+                raise NotImplementedError("stage 2 on VGG16CM is an inference path here: the reference cannot train it as "
+                                          "shipped (PEMPStage2 always builds VGG16CM with a pretrained file, which crashes, "
+                                          "networks/backbones.py:518), so there is nothing to be parity-checked against")
             return self._train_bridge("stage2", sup_img.device)(sup_img, sup_mask, qry_img, out_shape, qry_prior)
         self._require_eval_gpu(self, sup_img, sup_mask, qry_img, qry_prior)
         pred, resp = self.lowres(sup_img, sup_mask, qry_img, qry_prior, ret_ind)

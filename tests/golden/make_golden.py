@@ -239,6 +239,32 @@ def gen_stage2(tmp, stage1_model, cases):
 TRAIN_FULL = dict(seeds=(1234, 1235, 1236, 1237), H=401, out="stage1_rn50_trainstep_full")     # BASELINE.json configs[2]
 
 
+def gen_stage2_vgg(tmp, stage1_model, cases):
+    """G23: stage 2 on VGG16CM (networks/backbones.py:424-533).  As shipped the class cannot be built through
+    PEMPStage2 with a pretrained file (init_weights reads an attribute that is never set, :518); with
+    ``pretrained_weights["vgg16"] = None`` the unmodified constructor runs (no import step), which is what this does."""
+    from networks import pemp_stage2 as m
+    for cname, (seeds, shot, H, hws) in cases.items():
+        cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
+                   drop_rate=0.1, block_size=4, backbone2="vgg16", protos2=3, drop_rate2=0.5, cm=True)
+        m.net_ingredient.cfg = dict(cfg)
+        m.pretrained_weights["vgg16"] = None
+        model = m.PEMPStage2(shot, 1, logging.getLogger("golden")).eval()
+        _load_wgen(model, seed=4321)
+        _keys_fixture(model, "stage2_vgg16cm")
+        priors = []
+        for n, seed in enumerate(seeds):
+            ep = synth.make_episode(seed, shot=shot, height=H, width=H, out_hw=hws[n])
+            with torch.no_grad():
+                p = stage1_model(_t(ep["sup_img"])[None], _t(ep["sup_mask"])[None], _t(ep["qry_img"])[None])
+            priors.append(p.argmax(dim=1, keepdim=True))
+        res = _episode_case(model, "stage2", seeds, shot, H, hws, extra={"prior": priors})
+        for n, p in enumerate(priors):
+            res[f"e{n}_prior_bits"] = np.packbits(p.numpy().astype(np.uint8).reshape(-1))
+        np.savez_compressed(OUT / f"stage2_vgg16cm_{cname}.npz", **res)
+        print("wrote stage2 vgg16cm", cname)
+
+
 def gen_train_step(tmp, seeds=(31, 32), H=97, out="stage1_rn50_trainstep"):
     """G9: one training step's loss and gradients of the reference in train() mode (batch-stat BN;
     DropBlock = identity, i.e. drop_rate 0), B=2 episodes, 97x97, CE loss (entry/pemp_stage1.py:57-65).
@@ -598,6 +624,10 @@ def main():
             gen_train_step(tmp, **TRAIN_FULL)
         if only in ("", "train2full"):
             gen_train_step_stage2(tmp, shot=5, seeds=(1234,), out="stage2_rn50cm_trainstep5_full", H=401)
+        if only in ("", "stage2vgg"):
+            if s1 is None:
+                s1 = gen_stage1(tmp, "resnet50", "stage1_rn50", {})
+            gen_stage2_vgg(tmp, s1, {"small": ([3, 4], 1, 97, [(80, 120), (97, 97)]), "small5": ([5], 5, 97, [(64, 90)])})
         if only in ("", "stage2full"):         # BASELINE.json configs[3]: 5-shot stage 2 at 401x401 (12 encoder passes)
             if s1 is None:
                 s1 = gen_stage1(tmp, "resnet50", "stage1_rn50", {})

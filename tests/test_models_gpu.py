@@ -119,6 +119,34 @@ def test_stage2_matches_reference_golden(hip_lib, dev, fixture):
         util.assert_response_exact(resp[0, ::7, ::7], g[f"e{e}_resp_s7"], margin[0, ::7, ::7], what=fixture)
 
 
+@pytest.mark.parametrize("fixture", ["stage2_vgg16cm_small", "stage2_vgg16cm_small5"])
+def test_stage2_vgg16cm_matches_reference_golden(hip_lib, dev, fixture):
+    """stage 2 on VGG16CM (reference networks/backbones.py:424-533) -- communication channels concatenated in
+    front of zero-padded 3x3 convs, four Linear(2c -> 2), no purifier -- against vectors the reference's own classes produced
+    (built with pretrained = None: the shipped import step crashes)."""
+    from pemp_amd.networks import pemp_stage2 as m
+    g = util.gold(fixture)
+    shot, H = int(g["shot"]), int(g["H"])
+    net = m.PEMPStage2(shot, 1, None, backbone2="vgg16")
+    net.load_state_dict(util.wgen_state_dict("stage2_vgg16cm", seed=4321))
+    net = net.to(dev).eval()
+    for e, seed in enumerate(g["seeds"]):
+        hw = tuple(int(v) for v in g[f"e{e}_out_hw"])
+        t = util.episode_tensors(seed, shot, H, hw, dev)
+        prior = torch.from_numpy(np.unpackbits(g[f"e{e}_prior_bits"])[: H * H].reshape(1, 1, H, H).astype(np.int64)).to(dev)
+        with torch.no_grad():
+            out, resp = net(t["sup_img"], t["sup_mask"], t["qry_img"], prior, hw, ret_ind=True)
+            again, _ = net.lowres_graphed(t["sup_img"], t["sup_mask"], t["qry_img"], prior.float())
+            again2, _ = net.lowres_graphed(t["sup_img"], t["sup_mask"], t["qry_img"], prior.float())
+        _compare(g, e, out, t["qry_mask"], net._last_feats, H)
+        ap = net.adaptive_p.cpu()
+        ref = torch.from_numpy(g[f"e{e}_adaptive_p"])
+        assert ((ap - ref).abs() / (1 + ref.abs())).max().item() < 2e-3
+        _, margin = util.response_reference(net._last_feats, t["sup_mask"], net.ctr, 1, shot, 3, 20, hw)
+        util.assert_response_exact(resp[0, ::7, ::7], g[f"e{e}_resp_s7"], margin[0, ::7, ::7], what=fixture)
+        assert torch.equal(again, again2)                      # hipGraph replay of the VGG16CM engine is stable
+
+
 def test_stage2_prior_from_stage1_pipeline(hip_lib, dev):
     """Evaluator.test_step of stage 2 (entry/pemp_stage2.py:58-65): stage-1 argmax at 401-style full size
     feeds stage 2; the device-side argmax (eval_tail without target) must equal the logits' argmax."""
