@@ -4,7 +4,7 @@ produced (tests/golden/stage1_rn50_trainstep.npz: model.train(), batch-stat BN, 
 
 Tolerances: loss 2e-5; gradients are held to an fp64-RELATIVE bound (tests/util.py::check_gradients): with g64 the same
 step evaluated in double precision (tests/golden/*_trainstep*_f64.npz, oracle under autograd) and ref32 the reference's
-own fp32 gradients, every sampled tensor must satisfy  |hip - g64|_2 <= 2 |ref32 - g64|_2 + 1.5e-3 |g64|_2  and
+own fp32 gradients, every sampled tensor must satisfy  |hip - g64|_2 <= 3 |ref32 - g64|_2 + 3e-3 |g64|_2  and
 |hip - g64|_oo <= 3 |ref32 - g64|_oo + 3e-3 |g64|_oo, every parameter's gradient norm  |n - n64| <= 2 |n_ref32 - n64| + 3e-3 n64
 (also for VGG-16: a single arg-max switch in its stride-1 3x3 max pool -- two window elements 1e-6 apart -- moves the L2 error
 of every gradient below it from 3e-6 to 1e-3, scratch/vgg_layerwise.py).  Measured: the reference's own fp32 gradients sit 1e-5 .. 6e-3 of max|g| from

@@ -188,8 +188,9 @@ def check_gradients(g, g64, params, what, eps=3e-3):
     and every ReLU switch discretely, so a 1e-7 change of a batch statistic moves single pixels between branches and single
     gradient entries by ~1e-3 of the tensor's maximum (seen when only the partial-sum order of the BatchNorm reductions
     changed); the reference's own fp32 error scatters between 1e-6 and 6e-3 of max|g| from tensor to tensor.  So the bound is
-    RELATIVE to that error, per tensor, in two norms:
-        L2 :  |hip - g64|_2 <= 2 * |ref32 - g64|_2 + eps/2 * |g64|_2        (robust against single switched pixels)
+    RELATIVE to that error, per tensor, in two norms (factor 3: the reference's fp32 run shares its tie-breaking and op
+    structure with the fp64 evaluation, so its switches coincide with fp64's more often than another implementation's do):
+        L2 :  |hip - g64|_2 <= 3 * |ref32 - g64|_2 + eps * |g64|_2
         max:  |hip - g64|_oo <= 3 * |ref32 - g64|_oo + eps * |g64|_oo
     and for every parameter's gradient NORM  |n_hip - n_64| <= 2 * |n_ref32 - n_64| + eps * n_64.
     ``eps`` = 3e-3: one switched arg-max of VGG-16's stride-1 max pool already costs 1e-3 in L2 (scratch/vgg_layerwise.py: the
@@ -216,7 +217,7 @@ def check_gradients(g, g64, params, what, eps=3e-3):
         l_ref, l_hip = (ref.double() - ref64).norm().item(), (got.double() - ref64).norm().item()
         print(f"{what} {name:46s} max: hip {e_hip / max(scale, 1e-30):.1e} ref32 {e_ref / max(scale, 1e-30):.1e} | "
               f"L2: hip {l_hip / max(n2, 1e-30):.1e} ref32 {l_ref / max(n2, 1e-30):.1e}")
-        assert l_hip <= 2 * l_ref + 0.5 * eps * n2 + 1e-7, (what, name, "L2", l_hip / max(n2, 1e-30), l_ref / max(n2, 1e-30))
+        assert l_hip <= 3 * l_ref + eps * n2 + 1e-7, (what, name, "L2", l_hip / max(n2, 1e-30), l_ref / max(n2, 1e-30))
         assert e_hip <= 3 * e_ref + eps * scale + 1e-7, (what, name, "max", e_hip / max(scale, 1e-30), e_ref / max(scale, 1e-30))
         worst = max(worst, e_hip / (3 * e_ref + eps * scale + 1e-7))
     return worst
