@@ -36,9 +36,13 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int nblk) {
 // wave transposes its tile through a private 4 KB LDS patch so that a lane owns 4 consecutive channels
 // of one pixel: float4 residual loads and float4 stores, 8 lanes = one 128-B row segment.  Same
 // arithmetic, in the same order, as the scalar form:  v = acc * scale + (shift (+ per-image) (+ res)).
-template <int TM, int TN>
-__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
-                                                  int n_base, int lane) {
+// ``pre`` (optional): the residual quads of the wave's tiles, loaded by the caller ahead of time in the order
+// [mi][ni][i] (row = (lane >> 3) + 8 i of tile (mi, ni), channels (lane & 7) * 4 ..) -- conv_dma2.hip issues those loads
+// under its last K step so that their latency is not exposed here.
+template <int TM, int TN, int NPRE>
+__device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
+                                                      int n_base, int lane, const v4f (&pre)[NPRE]) {
+    constexpr bool PRE = NPRE == TM * TN * 4;       // (an array of 1 = "no prefetched residual": registers, never scratch)
     const bool relu = a.flags & PEMP_CONV_RELU;
     const bool per_img = a.flags & PEMP_CONV_SHIFT_PER_IMAGE;
     const int lr = lane & 31, lh = lane >> 5;
@@ -62,7 +66,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
                 if (m < a.M) {
                     v4f add = sh;
                     if (per_img) add += *(const v4f*)(a.shift + (size_t)(m / a.HoWo) * a.Cout + n);
-                    if (a.res) add += *(const v4f*)(a.res + (size_t)m * a.ldr + n);
+                    if (a.res) {
+                        if constexpr (PRE) add += pre[(mi * TN + ni) * 4 + i];
+                        else add += *(const v4f*)(a.res + (size_t)m * a.ldr + n);
+                    }
                     v4f o;
                     o.x = __builtin_fmaf(v.x, sc.x, add.x);      // explicit: every epilogue variant must round identically
                     o.y = __builtin_fmaf(v.y, sc.y, add.y);
@@ -80,6 +87,14 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the patch is rewritten
         }
     }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
+                                                  int n_base, int lane) {
+    const v4f none[1] = {{0.f, 0.f, 0.f, 0.f}};
+    static_assert(TM * TN * 4 != 1, "tile");
+    conv_epilogue_lds_pre<TM, TN, 1>(a, acc, S, m_base, n_base, lane, none);
 }
 
 // conv_dma.hip

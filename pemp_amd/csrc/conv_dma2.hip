@@ -18,16 +18,17 @@
 //    step with address arithmetic + a dozen LDS reads + a full wait while the matrix pipe drains.
 //
 // Not handled here (conv_dma.hip keeps them): the NHWC4 stem (a K step spans 8 taps, the tap differs per lane), more
-// than 32 taps, operands of 2 GiB or more, and a per-channel padding VALUE (padv): the in-image and the out-of-image
-// lanes of a piece would have to come from two descriptors, and an exec-masked LDS-DMA does not leave the inactive
-// lanes' 16-byte slots alone (tried: two masked DMAs per piece give wrong data), so a piece cannot be assembled from two.
+// than 32 taps, operands of 2 GiB or more, and a per-channel padding VALUE (padv) that does not lie behind the
+// activations in the same 2 GiB window: the in-image and the out-of-image lanes of a piece must come through ONE
+// descriptor (an exec-masked LDS-DMA does not leave the inactive lanes' 16-byte slots alone -- tried: two masked DMAs per
+// piece give wrong data -- so a piece cannot be assembled from two).
 #include "conv_common.h"
 
 namespace pemp {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WGM, int NW>
+template <int BM, int BN, int WGM, int NW, bool PADV>
 __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the launch stub (buffer-resource builtins / "s" asm operands are device-only)
     constexpr int WGN = NW / WGM;
@@ -65,6 +66,11 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
         __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - (ptrdiff_t)bias_pix * a.ldx), 0, 0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x80000000u, 0x00020000);
 
+    // PADV (ops.fold_input_affine: a BatchNorm in front of a zero-padded conv): out-of-image taps read a per-channel VALUE
+    // instead of zero.  One descriptor must serve both kinds of lane, so this variant needs the [Cin] vector INSIDE the
+    // activation descriptor's range, behind the tensor (the engine allocates it there); an out-of-image lane then gets
+    // the offset of its channel quad of that vector, minus the tap displacement the SGPR offset is about to add.
+    const unsigned padv_off = PADV ? (unsigned)((const char*)a.padv - (const char*)(a.x - (ptrdiff_t)bias_pix * a.ldx)) + sq * 16 : 0x80000000u;
     unsigned a_voff[AL], a_inv[AL], b_voff[BL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
@@ -105,8 +111,9 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
         const int sa_ = kh_i * taph + kw_i * tapw + cb * 128;                                                     \
         const int sb_ = (tap * a.Cin + cb * 32) * 4;                                                              \
         const int sh_ = 31 - tap;                                                                                 \
+        const unsigned oob_ = PADV ? padv_off - (unsigned)(kh_i * taph + kw_i * tapw) : 0x80000000u;              \
         _Pragma("unroll") for (int i = 0; i < AL; ++i) {                                                          \
-            const unsigned vo_ = ((int)(a_inv[i] << sh_) < 0) ? 0x80000000u : a_voff[i];                          \
+            const unsigned vo_ = ((int)(a_inv[i] << sh_) < 0) ? oob_ : a_voff[i];                                 \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(Ad_ + i * RPI * 8), 16, vo_, sa_, 0, 0);        \
         }                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < BL; ++i)                                                            \
@@ -241,6 +248,26 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
         PEMP_STEP(buf, false, true);
         ++kt;
     }
+    // Residual (shortcut) quads of small tiles are requested HERE, in front of the last K step's MFMAs, instead of inside
+    // the epilogue where every tile would wait out a full memory latency between its LDS transpose and its stores.
+    constexpr bool PRE = TM * TN <= 2;
+    v4f rpre[PRE ? TM * TN * 4 : 1];
+#pragma unroll
+    for (int i = 0; i < (PRE ? TM * TN * 4 : 1); ++i) rpre[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PRE) {
+        if (a.res) {
+            const int rr_ = lane >> 3, c4_ = (lane & 7) * 4;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = m0 + wm0 + mi * 32 + rr_ + 8 * i, n = n0 + wn0 + ni * 32 + c4_;
+                        rpre[(mi * TN + ni) * 4 + i] = m < a.M ? *(const v4f*)(a.res + (size_t)m * a.ldr + n) : v4f{0.f, 0.f, 0.f, 0.f};
+                    }
+        }
+    }
     {
         const int buf = kt & 1;
         PEMP_STEP(buf, false, false);
@@ -252,14 +279,15 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 #undef PEMP_MMA
 
     // ---- epilogue: transpose through LDS.  No LDS read and no DMA is outstanding after the loop's last barrier. ----
-    conv_epilogue_lds<TM, TN>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
+    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre);
+    else conv_epilogue_lds<TM, TN>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
 #endif
 }
 
 template <int BM, int BN, int WGM, int NW>
 static int launch_dma2(const ConvArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
-    auto kern = conv_dma2_kernel<BM, BN, WGM, NW>;
+    auto kern = a.padv ? conv_dma2_kernel<BM, BN, WGM, NW, true> : conv_dma2_kernel<BM, BN, WGM, NW, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -274,10 +302,17 @@ static int launch_dma2(const ConvArgs& a, hipStream_t st) {
 
 // true when the geometry / operands fit this variant (the caller falls back to conv_dma.hip otherwise)
 bool conv_dma2_supported(const ConvArgs& a) {
-    if ((a.flags & PEMP_CONV_STEM4) || a.padv || a.ntaps > 32) return false;
+    if ((a.flags & PEMP_CONV_STEM4) || a.ntaps > 32) return false;
     const long long xbytes = ((long long)a.N * a.H * a.W + (long long)a.pad * a.W + a.pad + (long long)a.dil * (a.KH - 1) * a.W +
                               (long long)a.dil * (a.KW - 1)) * a.ldx * 4;
     const long long wbytes = (long long)a.Cout * a.Kpad * 4;
+    if (a.padv) {           // the padding vector must sit behind the activations, inside the 2 GiB window of their descriptor,
+                            // and far enough in that subtracting the largest tap displacement leaves a non-negative offset
+        const long long behind = (const char*)a.padv - (const char*)a.x - (long long)a.N * a.H * a.W * a.ldx * 4;
+        const long long d = (const char*)a.padv - (const char*)a.x + ((long long)a.pad * a.W + a.pad) * a.ldx * 4;
+        const long long tapmax = ((long long)a.dil * (a.KH - 1) * a.W + (long long)a.dil * (a.KW - 1)) * a.ldx * 4;
+        if (behind < 0 || d < tapmax || d + (long long)a.Cin * 4 >= (1ll << 31)) return false;
+    }
     return xbytes < (1ll << 31) && wbytes < (1ll << 31);
 }
 

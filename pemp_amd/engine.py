@@ -246,8 +246,11 @@ class ASPPV2Engine:
         # PEMP_ASPP_COPIES=1 (or a zero BN scale) keeps the copy path.
         folded = [ops.fold_input_affine(self.br[i], *self.bn[i]) for i in range(5)]
         self.folded = None if (os.environ.get("PEMP_ASPP_COPIES") or any(f is None for f in folded)) else folded
+        self._tails = set()
 
-    def forward(self, x):
+    def forward(self, x, tail=None):
+        """``tail`` [>= 4, c]: spare rows right behind ``x`` in the same allocation; the padding vectors are parked there
+        (once per buffer) so that the buffer-addressed conv kernels reach them through the activations' descriptor."""
         a = self.arena
         n, h, w, c = x.shape
         midc = self.midc
@@ -256,8 +259,14 @@ class ASPPV2Engine:
         if self.folded is not None:
             g2 = ops.conv2d(g.view(n, 1, 1, c), self.folded[0][0], out=a.get("gap_c", (n, 1, 1, midc)))
             bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
+            if tail is not None and tail.data_ptr() not in self._tails:
+                for i in range(4):
+                    tail[i].copy_(self.folded[i + 1][1])
+                self._tails.add(tail.data_ptr())
             for i in range(4):
                 q, padv = self.folded[i + 1]
+                if tail is not None:
+                    padv = tail[i]
                 ops.conv2d(x, q, out=cat[..., i * midc:(i + 1) * midc], pad_value=padv if q.kh * q.kw > 1 else None)
             return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),
                               shift_override=bias6.view(n, -1), per_image_shift=True)
@@ -311,7 +320,13 @@ class PurifierEngine:
         a = self.arena
         n, h, w, _ = x.shape
         y = ops.conv2d(x, self.p0, out=a.get("pur0", (n, h, w, self.p0.cout)))
-        y = ops.conv2d(y, self.p3, out=a.get("pur3", (n, h, w, self.p3.cout)))
+        # the ASPP input carries 8 spare pixel rows behind it: the folded-BatchNorm branches keep their per-channel
+        # padding vectors there, inside the buffer-descriptor window of the tensor (conv_dma2.hip, PADV)
+        c = self.p3.cout
+        flat = a.get("pur3+tail", (n * h * w + 8, c))
+        y = ops.conv2d(y, self.p3, out=flat[:n * h * w].view(n, h, w, c))
+        if isinstance(self.aspp, ASPPV2Engine):
+            return self.aspp.forward(y, tail=flat[n * h * w:])
         return self.aspp.forward(y)
 
 

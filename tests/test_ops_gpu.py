@@ -112,6 +112,16 @@ def test_conv2d_pad_value_folds_a_leading_batchnorm(hip_lib, dev, Cin, Cout, k, 
         outs.append(y)
         assert ((_nchw(y.cpu()) - ref).abs() / (1 + ref.abs())).max().item() < tol, tile
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+    if k > 1:
+        # the buffer-addressed kernels (2x ids) fetch the padding vector through the activations' descriptor: that needs the
+        # vector BEHIND the tensor in the same allocation (the engine parks it in spare rows there); with it elsewhere -- the
+        # loop above -- those ids hand the launch to conv_dma.hip.  Same results, bit for bit, either way.
+        flat = torch.empty(N * HW * HW + 4, Cin, device=dev)
+        flat[:N * HW * HW].copy_(xd.view(-1, Cin))
+        flat[N * HW * HW + 2].copy_(padv)
+        xin, pin = flat[:N * HW * HW].view(N, HW, HW, Cin), flat[N * HW * HW + 2]
+        for tile in (23, 22, 25) + ((21, 24, 26) if Cout % 128 == 0 else ()) + ((27,) if Cout % 256 == 0 else ()):
+            assert torch.equal(ops.conv2d(xin, q, tile=tile, pad_value=pin), outs[0]), tile
     if k > 1:       # zero padding is NOT the same thing (the border differs), and 1x1 convs reject a pad value
         y0 = ops.conv2d(xd, q, tile=3)
         assert not torch.allclose(_nchw(y0.cpu()), ref, rtol=1e-3, atol=1e-3)
