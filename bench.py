@@ -589,20 +589,22 @@ def main_train(args, world, rank, dev):
             except Exception as exc:  # noqa: BLE001
                 out[key] = {"error": f"{type(exc).__name__}: {exc}"}
 
-        if not args.no_roofline and not use_graph:
+        if not args.no_roofline:
             def roof():
                 # kernels of the two streams overlap in the timed step; for per-kernel durations the instrumented pass
                 # keeps everything on one stream (same kernels, same operands)
                 flat = tr.eng.flat
-                side, bside = flat.side_stream, tr.eng.buckets.side
+                side, bside, ug = flat.side_stream, tr.eng.buckets.side, tr.use_graph
                 flat.side_stream = tr.eng.buckets.side = None
+                tr.use_graph = False
                 try:
                     rec = instrumented(lambda r: tr.train_step(*pool[r % len(pool)]), reps=2)
                 finally:
-                    flat.side_stream, tr.eng.buckets.side = side, bside
+                    flat.side_stream, tr.eng.buckets.side, tr.use_graph = side, bside, ug
                 r = summarize(rec, 2, step_ms)
-                r["note"] = ("per-kernel durations from a single-stream pass; the timed step overlaps the weight-gradient kernels "
-                             "with the input-gradient chain on a side stream (step_effective_tflops = conv flops / timed step)")
+                r["note"] = ("per-kernel durations from a single-stream eager pass; the timed step overlaps the weight-gradient kernels "
+                             "with the input-gradient chain on a side stream%s (step_effective_tflops = conv flops / timed step)"
+                             % (" and replays a chain of hipGraph segments" if use_graph else ""))
                 return r
             guarded("roofline", roof)
         if world == 1 and args.cpu_episodes > 0:

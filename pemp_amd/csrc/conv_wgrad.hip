@@ -485,7 +485,8 @@ static int pick_split(int tiles, int steps) {
     // input-gradient chain on the other stream, so it need not fill it alone, and every split costs a [Cout][K] partial
     // that the reduce pass has to read again: 1536 / 1024 / 768 / 512 / 384 blocks -> 20.88 / 20.78 / 20.53 / 20.59 /
     // 20.76 ms per training step.
-    int s = cdiv(768, tiles);
+    static const int target = getenv("PEMP_WGRAD_BLOCKS") ? atoi(getenv("PEMP_WGRAD_BLOCKS")) : 768;      // tuning knob
+    int s = cdiv(target, tiles);
     if (s > steps / 8) s = steps / 8;
     if (s < 1) s = 1;
     if (s > 512) s = 512;

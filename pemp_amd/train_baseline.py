@@ -68,6 +68,7 @@ class _VGGEngine(Stage1TrainEngine):
         for kind, obj, relu, x, y in reversed(self.tape["vgg"]):
             if kind == "pool":
                 dx = T.maxpool_idx_bwd(y, dx.contiguous(), x, 3, obj, 1)
+                self.flat.cut()                    # stage boundary (segmented graph capture; no-op otherwise)
                 continue
             g = torch.empty_like(y)
             obj.conv.bias.grad.copy_(T.relu_bias_bwd(dx, y, g, relu=relu, ws_cache=self.ws))

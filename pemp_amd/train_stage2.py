@@ -120,6 +120,8 @@ class Stage2TrainEngine(Stage1TrainEngine):
             b, rec = self.blocks[bi], tp["blocks"][bi]
             dx = self._block_bwd(dx, b, rec)
             if bi not in self.stage_first:
+                if bi % 2 == 1:
+                    self.flat.cut()
                 continue
             si = self.stage_first.index(bi)
             cm, lin = tp["cm"][si], self.lin[si]
@@ -131,6 +133,7 @@ class Stage2TrainEngine(Stage1TrainEngine):
             b["ds"][0].ext_backward(ops.global_avgpool(dzd) * hw_out, cm["feat"], group, dfi, accumulate=True)
             dstat = T.cm_linear_bwd(dfi, group, cm["agg"], lin.weight.data, lin.weight.grad, lin.bias.grad)
             T.cm_bwd_add(cm["x"], cm["mask"], dstat.view(n, 2, c), dx, argmax=cm["arg"])   # [N,2,C]: d(mean), d(max) per image
+            self.flat.cut()                        # stage boundary (segmented graph capture; no-op otherwise)
         dy = T.maxpool_idx_bwd(tp["pool_idx"], dx, tp["pool_in"].shape[1:3], 3, 2, 1)
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
 

@@ -319,3 +319,49 @@ def test_train_command_writes_a_fresh_run_and_test_command_loads_it(hip_lib, dev
     loss, miou, biou = ev.start_eval_loop(e.SyntheticEpisodes(6, 5678, 1, 0, 97, 97), 20, 0, te_epochs=1, batch=2)
     assert out == f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
     assert run("test", "with", *common, "ckpt=wgen").startswith("Loss:")
+
+
+@pytest.mark.parametrize("model", ["stage1", "stage2", "baseline"])
+def test_segmented_graph_step_equals_the_eager_step(hip_lib, dev, model):
+    """The training step replayed from a CHAIN of hipGraphs (train_engine.SegmentedCapture: main-stream segments + side-stream
+    weight-gradient segments that run beside the next main segment) leaves bit-identical weights, losses and BatchNorm buffers
+    to the eager two-stream step -- regularisers off (their Philox stream advances identically, but keep the check about the
+    graphs) -- over several replays with changing inputs."""
+    from pemp_amd import synth
+    from pemp_amd.networks import baseline as mb, pemp_stage1 as m1, pemp_stage2 as m2
+    from pemp_amd.train_baseline import BaselineTrainer
+    from pemp_amd.train_engine import Stage1Trainer
+    from pemp_amd.train_stage2 import Stage2Trainer
+    from tests.golden.make_golden import stage2_train_prior
+    batches = []
+    for s in range(5):
+        b = synth.make_batch([31 + 2 * s, 32 + 2 * s], shot=1, height=97, width=97, out_hw=(97, 97))
+        t = lambda a: torch.from_numpy(a).to(dev)
+        batches.append((t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0]), t(stage2_train_prior(b["qry_mask"]))))
+    out = []
+    for use_graph in (False, True):
+        if model == "stage1":
+            net = m1.ModelClass(None)
+            net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+            tr = Stage1Trainer(net, device=dev, lr=2e-3, drop_rate=0.0, use_graph=use_graph)
+        elif model == "stage2":
+            net = m2.ModelClass(1, 1, None)
+            net.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+            tr = Stage2Trainer(None, net, device=dev, lr=2e-3, drop_rate2=0.0, use_graph=use_graph)
+        else:
+            net = mb.Baseline(None, backbone="vgg16")
+            net.load_state_dict(util.wgen_state_dict("baseline_vgg16"))
+            tr = BaselineTrainer(net, device=dev, lr=2e-3, use_graph=use_graph)
+        losses = []
+        for sup, msk, qry, gt, prior in batches:
+            losses.append(tr.train_step(sup, msk, qry, gt, prior) if model == "stage2" else tr.train_step(sup, msk, qry, gt))
+        torch.cuda.synchronize()
+        if use_graph:
+            cap = next(iter(tr._graphs.values()))["cap"]
+            assert len(cap.main) >= 3 and sum(g is not None for g in cap.side) >= 3        # really a chain, really two streams
+        out.append((torch.stack(losses).cpu(), tr.eng.flat.data.clone().cpu(),
+                    {k: v.clone().cpu() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}))
+    (l0, w0, b0), (l1, w1, b1) = out
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(w0, w1)
+    assert all(torch.equal(b0[k], b1[k]) for k in b0)
