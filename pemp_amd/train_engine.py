@@ -28,6 +28,7 @@ from . import ops, train_ops as T
 from .ops import ConvParams
 
 BN_MOM = 0.1
+SEG_EVERY = int(os.environ.get("PEMP_SEG_EVERY", "1"))     # residual blocks per graph segment of the backward pass
 
 
 # ---------------------------------------------------------------------------------------------
@@ -555,8 +556,8 @@ class Stage1TrainEngine:
         for bi in range(len(self.blocks) - 1, -1, -1):                          # residual blocks, last to first
             dx = self._block_bwd(dx, self.blocks[bi], tp["blocks"][bi])
             self.buckets.ready_from(self.block_off[bi])
-            if bi % 2 == 1:
-                self.flat.cut()                    # every second block: its weight gradients run under the next two blocks' chain
+            if bi % SEG_EVERY == SEG_EVERY - 1:
+                self.flat.cut()                    # every SEG_EVERY-th block: its weight gradients run under the next blocks' chain
         # stem: max pool, BN+ReLU, 7x7 conv (weight gradient only)
         dy = T.maxpool_idx_bwd(tp["pool_idx"], dx, tp["pool_in"].shape[1:3], 3, 2, 1)
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
