@@ -105,7 +105,8 @@ def test_reference_trainer_body_runs_on_baseline_and_stage2(hip_lib, dev):
         loss = F.cross_entropy(net(sup, msk, qry, (97, 97)), gt, ignore_index=255)
         loss.backward()
         assert abs(loss.item() - float(g["loss"])) < 2e-5
-        util.check_gradients(g, util.gold(tag + "_trainstep_f64"), dict(net.named_parameters()), "bridge " + tag)
+        util.check_gradients(g, util.gold(tag + "_trainstep_f64"), dict(net.named_parameters()), "bridge " + tag,
+                             eps=3e-3 if backbone == "vgg16" else 8e-3)          # see test_baseline_train_step_matches_reference
     g = util.gold("stage2_rn50cm_trainstep")
     net = m2.ModelClass(1, 1, None, drop_rate2=0.0).to(dev)
     net.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
