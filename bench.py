@@ -183,6 +183,7 @@ def episode_pool(dev, shot, batch, rank, n_groups=5, dataset="PASCAL"):
 # ---------------------------------------------------------------------------------------------
 CLASS_OF = {
     "pemp_conv2d_nhwc_f32": "conv", "pemp_conv2d_padv_nhwc_f32": "conv", "pemp_conv2d_wgrad_nhwc_f32": "wgrad",
+    "pemp_conv2d_stats_nhwc_f32": "conv", "pemp_bn_stats_partials_f32": "batchnorm",
     "pemp_bn_stats_f32": "batchnorm", "pemp_bn_apply_f32": "batchnorm", "pemp_bn_bwd_f32": "batchnorm",
     "pemp_relu_bias_bwd_f32": "batchnorm",
     "pemp_mpm_protos_f32": "head", "pemp_masked_avg_pool_f32": "head", "pemp_cosine_proto_max_f32": "head",
@@ -225,7 +226,7 @@ def _conv_work(name, a):
     m = d.N * d.Ho * d.Wo
     k = d.KH * d.KW * cin
     flops = 2.0 * m * d.Cout * k
-    res = name != "pemp_conv2d_wgrad_nhwc_f32" and bool(a[6])
+    res = name in ("pemp_conv2d_nhwc_f32", "pemp_conv2d_padv_nhwc_f32") and bool(a[6])
     nbytes = 4.0 * (d.N * d.H * d.W * d.Cin + m * d.Cout * (2 if res else 1) + d.Cout * d.KH * d.KW * d.Cin)
     return flops, nbytes, (m, d.Cout, k, res)
 

@@ -208,6 +208,19 @@ int pemp_cm_bwd_add_arg_f32(const float* mask, const float* dstat, const int32_t
  * core/base_trainer.py:189).
  * ---------------------------------------------------------------------------------------------- */
 
+/* The conv in front of a train-mode BatchNorm with the BatchNorm's batch statistics started in its epilogue
+ * (networks/backbones.py:48-52,66-75 with the model in train(), core/base_trainer.py:189): y = conv(x, w) (no affine,
+ * no residual, no ReLU) and, for every group of 32 consecutive output rows r, the per-channel partial sums
+ *   stats[r][0][c] = sum y[m][c],  stats[r][1][c] = sum y[m][c]^2        (m in rows 32 r .. 32 r + 31, m < M)
+ * i.e. ceil(M/32) x 2 x Cout floats.  pemp_bn_stats_partials_f32 adds them in a fixed order (double) into mean /
+ * 1/sqrt(var+eps) and the running-statistics update: the separate pass over y that pemp_bn_stats_f32 makes is gone.
+ * Deterministic (no atomics).  Non-stem convs whose operands lie below 2 GiB (the buffer-addressed kernels); returns
+ * -2 where that does not hold (use pemp_conv2d_nhwc_f32 + pemp_bn_stats_f32 then).  d->tile: 0 or 21..27.            */
+int pemp_conv2d_stats_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,
+                               void* stream);
+int pemp_bn_stats_partials_f32(const float* stats, int M, int C, float eps, float momentum, float* mean,
+                               float* invstd, float* run_mean, float* run_var, void* stream);
+
 /* Weight gradient of pemp_conv2d_nhwc_f32 (autograd of nn.Conv2d, same call sites):
  *   dw[co][kh][kw][ci] (+)= sum_m g[m][co] * x[pix(m,kh,kw)][ci]      dw is KRSC with row length d->Kpad
  * `d` describes the FORWARD conv (d->ldy = per-pixel stride of g).  STEM4 needs Kpad % 64 == 0. */

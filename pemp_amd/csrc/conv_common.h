@@ -15,6 +15,7 @@ struct ConvArgs {
     const float* shift;
     const float* res;
     const float* padv;      // per-input-channel value of out-of-image taps (NULL: zero padding)
+    float* stats;           // [ceil(M/32)][2][Cout] per-32-row partial sums of y and y^2 (NULL: none; conv_dma2.hip only)
     int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, KH, KW, stride, pad, dil, ldr, Kpad;
     unsigned flags;
     int M, HoWo, cin_steps, nk, ntaps;
@@ -39,7 +40,9 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int nblk) {
 // ``pre`` (optional): the residual quads of the wave's tiles, loaded by the caller ahead of time in the order
 // [mi][ni][i] (row = (lane >> 3) + 8 i of tile (mi, ni), channels (lane & 7) * 4 ..) -- conv_dma2.hip issues those loads
 // under its last K step so that their latency is not exposed here.
-template <int TM, int TN, int NPRE>
+// STATS: per-channel sums of the stored values and of their squares over each 32-row tile, written to a.stats (the batch
+// statistics of the BatchNorm behind the conv; fixed layout, fixed order -> deterministic).
+template <int TM, int TN, int NPRE, bool STATS = false>
 __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
                                                       int n_base, int lane, const v4f (&pre)[NPRE]) {
     constexpr bool PRE = NPRE == TM * TN * 4;       // (an array of 1 = "no prefetched residual": registers, never scratch)
@@ -58,6 +61,7 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
 #pragma unroll
             for (int e = 0; e < 16; ++e) S[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + lr] = acc[mi][ni][e];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's writes have landed (DS is in-order per wave)
+            v4f s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rr + 8 * i;
@@ -82,6 +86,25 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
                         o.w = fmaxf(o.w, 0.f);
                     }
                     *(v4f*)(a.y + (size_t)m * a.ldy + n) = o;
+                    if constexpr (STATS) {
+                        s1 += o;
+                        s2 += o * o;
+                    }
+                }
+            }
+            if constexpr (STATS) {
+                // lanes that share the channel quad differ in lane bits 3..5 (the row inside the 8-row group): fixed butterfly
+#pragma unroll
+                for (int off = 8; off < 64; off <<= 1) {
+                    s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64);
+                    s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
+                    s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64);
+                    s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
+                }
+                const int r32 = (m_base + mi * 32) >> 5;
+                if (lane < 8 && m_base + mi * 32 < a.M) {
+                    *(v4f*)(a.stats + ((size_t)r32 * 2 + 0) * a.Cout + n) = s1;
+                    *(v4f*)(a.stats + ((size_t)r32 * 2 + 1) * a.Cout + n) = s2;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the patch is rewritten

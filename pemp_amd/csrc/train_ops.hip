@@ -136,6 +136,35 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
     }
 }
 
+// the same from the per-32-row partial sums a conv epilogue left (pemp_conv2d_stats_nhwc_f32): [nrows32][2][C] floats
+__global__ __launch_bounds__(256) void bn_stats_partials_kernel(const float* __restrict__ part, int n32, int M, int C, float eps,
+                                                                float momentum, float* __restrict__ mean,
+                                                                float* __restrict__ invstd, float* __restrict__ run_mean,
+                                                                float* __restrict__ run_var) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = lane; k < n32; k += 64) {               // lane l adds partials l, l+64, ... in order, then a fixed butterfly
+        s += (double)part[((size_t)k * 2 + 0) * C + c];
+        ss += (double)part[((size_t)k * 2 + 1) * C + c];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+    }
+    if (lane != 0) return;
+    const double mu = s / M;
+    double var = ss / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unbiased);
+    }
+}
+
 // backward sums: out0[c] = sum a, out1[c] = sum b  (fp32 results)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, int nchunk, int C,
                                                            float* __restrict__ out0, float* __restrict__ out1) {
@@ -540,6 +569,15 @@ extern "C" int pemp_bn_stats_f32(const float* z, int ldz, int M, int C, float ep
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nck, M, C, eps,
                        momentum, mean, invstd, run_mean, run_var);
     return launch_status("bn_stats");
+}
+
+extern "C" int pemp_bn_stats_partials_f32(const float* stats, int M, int C, float eps, float momentum, float* mean,
+                                          float* invstd, float* run_mean, float* run_var, void* stream) {
+    PEMP_REQUIRE(stats && mean && invstd && M > 0 && C > 0, "bn_stats_partials: bad arguments");
+    PEMP_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "bn_stats_partials: running stats must both be given or both NULL");
+    hipLaunchKernelGGL(bn_stats_partials_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, stats, cdiv(M, 32), M, C, eps,
+                       momentum, mean, invstd, run_mean, run_var);
+    return launch_status("bn_stats_partials");
 }
 
 extern "C" int pemp_bn_apply_f32(const float* z, int ldz, const float* mean, const float* invstd, const float* gamma,

@@ -78,11 +78,11 @@ if _TILE_CACHE_FILE and os.path.exists(_TILE_CACHE_FILE):
         _TILE_CACHE.update({tuple(json.loads(k)): int(v) for k, v in json.load(_f).items()})
 
 
-def _pick_tile(launch, p, key, cout):
+def _pick_tile(launch, p, key, cout, only=None):
     """Time the candidate variants for this (layer, input shape) and remember the fastest: two rounds over all
     candidates (the minimum of a variant's two timings counts: a round can be disturbed by whatever else the GPU is
     finishing), then a run-off between the best three with more repetitions."""
-    cands = [t for t, (bm, bn) in TILE_VARIANTS.items() if cout % bn == 0]
+    cands = [t for t, (bm, bn) in TILE_VARIANTS.items() if cout % bn == 0 and (only is None or t in only)]
 
     def timed(t, reps):
         launch(t)                                   # warm
@@ -177,6 +177,50 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
                 tile = DEFAULT_TILE
     launch(tile)
     return out
+
+
+def conv2d_stats(x, p, out=None, tile=0):
+    """z = conv(x, w) with the per-32-row partial sums of z and z^2 left by the epilogue (pemp_conv2d_stats_nhwc_f32):
+    -> (z, partials [ceil(M/32), 2, Cout]).  Raises PempHipError where the buffer-addressed kernels do not apply
+    (callers then use conv2d + bn_stats); ``stats_supported`` says so beforehand."""
+    lib = _lib.load()
+    _chk_dev(x, p.w, out)
+    ldx = _nhwc(x, "x")
+    n, h, w, cin = x.shape
+    if cin != p.cin:
+        raise ValueError(f"conv2d_stats: input has {cin} channels, layer expects {p.cin}")
+    if p.stem or p.scale is not None:
+        raise ValueError("conv2d_stats: plain (non-stem, unscaled) convs only")
+    ho = conv_out_size(h, p.kh, p.stride, p.pad, p.dil)
+    wo = conv_out_size(w, p.kw, p.stride, p.pad, p.dil)
+    if out is None:
+        out = torch.empty((n, ho, wo, p.cout), dtype=torch.float32, device=x.device)
+    ldy = _nhwc(out, "out")
+    m = n * ho * wo
+    part = torch.empty(((m + 31) // 32, 2, p.cout), dtype=torch.float32, device=x.device)
+
+    def launch(t):
+        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, 0, p.kpad, 0, t)
+        _lib.check(lib.pemp_conv2d_stats_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(part), _stream()),
+                   "pemp_conv2d_stats_nhwc_f32")
+
+    if tile == 0:
+        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 2, n, h, w, 0, 0)     # 2: the stats epilogue
+        tile = _TILE_CACHE.get(key)
+        if tile is None:
+            if AUTOTUNE and m >= 1024 and not torch.cuda.is_current_stream_capturing():
+                tile = _pick_tile(launch, p, key, p.cout, only=range(21, 28))
+            else:
+                tile = DEFAULT_TILE + 10
+    launch(tile)
+    return out, part
+
+
+def stats_supported(x, p):
+    """Whether conv2d_stats applies to this (input, layer): what conv_dma2_supported checks in csrc/conv_dma2.hip."""
+    n, h, w, cin = x.shape
+    return (not p.stem and p.scale is None and p.kh * p.kw <= 32 and cin % 32 == 0 and p.cout % 64 == 0
+            and x.numel() * 4 < 2 ** 31 - (1 << 20) and p.w.numel() * 4 < 2 ** 31)
 
 
 def fold_input_affine(p, s, t):

@@ -28,6 +28,7 @@ from . import ops, train_ops as T
 from .ops import ConvParams
 
 BN_MOM = 0.1
+FUSE_BN_STATS = os.environ.get("PEMP_FUSE_BN_STATS", "1") != "0"   # conv epilogue starts the batch statistics (A/B switch)
 SEG_EVERY = int(os.environ.get("PEMP_SEG_EVERY", "1"))     # residual blocks per graph segment of the backward pass
 
 
@@ -290,6 +291,9 @@ class _BN:
     def stats(self, z, ws):
         return T.bn_stats(z, self.bn.eps, BN_MOM, self.bn.running_mean, self.bn.running_var, ws_cache=ws)
 
+    def stats_from(self, part, m):
+        return T.bn_stats_partials(part, m, self.bn.eps, BN_MOM, self.bn.running_mean, self.bn.running_var)
+
     def grad_out(self):
         """(dgamma, dbeta) destinations inside the flat gradient buffer, or None for a frozen BatchNorm."""
         return (self.bn.weight.grad, self.bn.bias.grad) if self.bn.weight.requires_grad else None
@@ -363,8 +367,12 @@ class Stage1TrainEngine:
     def _cbn_fwd(self, x, conv, bn, relu, residual=None, img_bias=None):
         """conv -> (+ per-image bias [N,Cout]) -> batch-stat BN (+residual)(+ReLU); returns (y, tape record)."""
         prm = conv.fwd_params(relu=False, with_bias=False)
-        z = ops.conv2d(x, prm) if img_bias is None else ops.conv2d(x, prm, shift_override=img_bias, per_image_shift=True)
-        mean, invstd = bn.stats(z, self.ws)
+        if FUSE_BN_STATS and img_bias is None and ops.stats_supported(x, prm):
+            z, part = ops.conv2d_stats(x, prm)         # batch statistics started in the conv epilogue
+            mean, invstd = bn.stats_from(part, z.shape[0] * z.shape[1] * z.shape[2])
+        else:
+            z = ops.conv2d(x, prm) if img_bias is None else ops.conv2d(x, prm, shift_override=img_bias, per_image_shift=True)
+            mean, invstd = bn.stats(z, self.ws)
         y = T.bn_apply(z, mean, invstd, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(z), residual=residual, relu=relu)
         return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu)
 

@@ -37,6 +37,20 @@ def bn_stats(z, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, ws_cache=No
     return mean, invstd
 
 
+def bn_stats_partials(part, m, eps=1e-5, momentum=0.1, run_mean=None, run_var=None):
+    """bn_stats from the [ceil(M/32), 2, C] partial sums a conv epilogue left (ops.conv2d_stats)."""
+    lib = _lib.load()
+    _chk_dev(part, run_mean, run_var)
+    c = part.shape[2]
+    if part.dtype != torch.float32 or not part.is_contiguous() or part.shape[0] != (m + 31) // 32 or part.shape[1] != 2:
+        raise ValueError(f"bn_stats_partials: partials must be contiguous fp32 [ceil({m}/32), 2, C], got {tuple(part.shape)}")
+    mean = torch.empty(c, dtype=torch.float32, device=part.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=part.device)
+    _lib.check(lib.pemp_bn_stats_partials_f32(_p(part), m, c, eps, momentum, _p(mean), _p(invstd), _p(run_mean),
+                                              _p(run_var), _stream()), "bn_stats_partials")
+    return mean, invstd
+
+
 def bn_apply(z, mean, invstd, gamma, beta, out, residual=None, relu=True):
     lib = _lib.load()
     _chk_dev(z, out, residual)

@@ -118,6 +118,64 @@ def test_bn_train_forward_backward(hip_lib, dev, M, C, relu, res):
         assert torch.allclose(gout.cpu(), r.grad, rtol=1e-6, atol=1e-7)
 
 
+STATS_CASES = [  # N, H, W, Cin, Cout, k, s, p, d
+    (2, 51, 51, 64, 64, 1, 1, 0, 1),        # M = 5202: the last 32-row group is ragged (18 rows)
+    (2, 51, 51, 64, 256, 3, 1, 1, 1),
+    (3, 26, 26, 256, 512, 1, 2, 0, 1),
+    (2, 26, 26, 128, 128, 3, 1, 2, 2),
+    (1, 5, 3, 64, 64, 1, 1, 0, 1),          # M = 15 < one row group
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES)
+def test_conv_with_batch_statistics_in_the_epilogue(hip_lib, dev, case):
+    """pemp_conv2d_stats_nhwc_f32: z is bit-identical to the plain conv on every tile; the partial sums are the column
+    sums of the stored z over each 32-row group (fp32 sums of 32 values: 1e-6 relative to sum |z|), identical on every
+    tile; mean / invstd / running statistics from them equal pemp_bn_stats_f32 of z to fp32 rounding."""
+    from pemp_amd import ops, train_ops as T
+    N, H, W, Cin, Cout, k, s, p, d = case
+    x = _nhwc(_rand(N, Cin, H, W, seed=1)).to(dev)
+    w = _rand(Cout, Cin, k, k, seed=2, lo=-0.1, hi=0.1)
+    packed, kpad = ops.pack_conv_weight(w.to(dev))
+    prm = ops.ConvParams(packed, None, None, Cin, Cout, k, k, s, p, d, kpad, False, False)
+    assert ops.stats_supported(x, prm)
+    z_ref = ops.conv2d(x, prm, tile=13)
+    M = z_ref.numel() // Cout
+    zr = z_ref.reshape(M, Cout).double().cpu()
+    pad = (-M) % 32
+    zp = torch.cat([zr, torch.zeros(pad, Cout, dtype=torch.float64)]).view(-1, 32, Cout)
+    first = None
+    for tile in [t for t in range(21, 28) if Cout % ops.TILE_VARIANTS[t][1] == 0]:
+        z, part = ops.conv2d_stats(x, prm, tile=tile)
+        assert torch.equal(z, z_ref), tile
+        assert part.shape == ((M + 31) // 32, 2, Cout)
+        pc = part.double().cpu()
+        assert ((pc[:, 0] - zp.sum(1)).abs() <= 1e-6 * zp.abs().sum(1) + 1e-30).all(), tile
+        assert ((pc[:, 1] - (zp * zp).sum(1)).abs() <= 1e-6 * (zp * zp).sum(1) + 1e-30).all(), tile
+        if first is None:
+            first = part.clone()
+        assert torch.equal(part, first), tile
+    rm, rv = _rand(Cout, seed=5), _rand(Cout, seed=6, lo=0.5, hi=1.5)
+    rm1, rv1, rm2, rv2 = rm.to(dev), rv.to(dev), rm.to(dev), rv.to(dev)
+    mean, invstd = T.bn_stats_partials(first, M, 1e-5, 0.1, rm1, rv1)
+    mean0, invstd0 = T.bn_stats(z_ref.reshape(M, Cout), 1e-5, 0.1, rm2, rv2)
+    assert torch.allclose(mean, mean0, rtol=1e-5, atol=1e-7) and torch.allclose(invstd, invstd0, rtol=1e-5)
+    assert torch.allclose(rm1, rm2, rtol=1e-5, atol=1e-7) and torch.allclose(rv1, rv2, rtol=1e-5, atol=1e-7)
+    mu = zr.mean(0)
+    assert torch.allclose(mean.double().cpu(), mu, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(invstd.double().cpu(), 1 / (zr.var(0, unbiased=False) + 1e-5).sqrt(), rtol=1e-5)
+
+
+def test_conv_with_batch_statistics_refuses_what_it_cannot_run(hip_lib, dev):
+    from pemp_amd import _lib, ops
+    x = torch.zeros(1, 8, 8, 64, device=dev)
+    w = torch.zeros(64, 64, 1, 1, device=dev)
+    packed, kpad = ops.pack_conv_weight(w)
+    prm = ops.ConvParams(packed, None, None, 64, 64, 1, 1, 1, 0, 1, kpad, False, False)
+    with pytest.raises(_lib.PempHipError, match="tile must be 0 or 21..27"):
+        ops.conv2d_stats(x, prm, tile=13)
+
+
 def test_relu_bias_bwd_and_pools(hip_lib, dev):
     from pemp_amd import ops, train_ops as T
     M, C = 1000, 256
