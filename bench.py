@@ -184,6 +184,7 @@ def episode_pool(dev, shot, batch, rank, n_groups=5, dataset="PASCAL"):
 CLASS_OF = {
     "pemp_conv2d_nhwc_f32": "conv", "pemp_conv2d_padv_nhwc_f32": "conv", "pemp_conv2d_wgrad_nhwc_f32": "wgrad",
     "pemp_conv2d_stats_nhwc_f32": "conv", "pemp_bn_stats_partials_f32": "batchnorm",
+    "pemp_conv2d_bnbwd_nhwc_f32": "conv", "pemp_bn_bwd_partials_f32": "batchnorm", "pemp_bn_apply_mask_f32": "batchnorm",
     "pemp_bn_stats_f32": "batchnorm", "pemp_bn_apply_f32": "batchnorm", "pemp_bn_bwd_f32": "batchnorm",
     "pemp_relu_bias_bwd_f32": "batchnorm",
     "pemp_mpm_protos_f32": "head", "pemp_masked_avg_pool_f32": "head", "pemp_cosine_proto_max_f32": "head",
@@ -226,8 +227,9 @@ def _conv_work(name, a):
     m = d.N * d.Ho * d.Wo
     k = d.KH * d.KW * cin
     flops = 2.0 * m * d.Cout * k
-    res = name in ("pemp_conv2d_nhwc_f32", "pemp_conv2d_padv_nhwc_f32") and bool(a[6])
-    nbytes = 4.0 * (d.N * d.H * d.W * d.Cin + m * d.Cout * (2 if res else 1) + d.Cout * d.KH * d.KW * d.Cin)
+    res = (name in ("pemp_conv2d_nhwc_f32", "pemp_conv2d_padv_nhwc_f32") and bool(a[6])) or (name == "pemp_conv2d_bnbwd_nhwc_f32" and bool(a[4]))
+    outs = (2 if res else 1) + (1 if name == "pemp_conv2d_bnbwd_nhwc_f32" else 0)       # bnbwd also reads the BatchNorm's input z
+    nbytes = 4.0 * (d.N * d.H * d.W * d.Cin + m * d.Cout * outs + d.Cout * d.KH * d.KW * d.Cin)
     return flops, nbytes, (m, d.Cout, k, res)
 
 
@@ -281,7 +283,7 @@ def summarize(rec, reps, step_ms=None):
             e["tflops"] = round(c["gflop"] / c["ms"], 1)
             e["frac_of_fp32_mfma_peak"] = round(c["gflop"] / c["ms"] / PEAK_F32_MFMA_TFLOPS, 4)
         out[cls] = e
-    top = sorted(layers.items(), key=lambda kv: -kv[1][0])[:6]
+    top = sorted(layers.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("PEMP_BENCH_LAYERS", "6"))]
     by_layer = [{"kind": k[0], "M": k[1], "N": k[2], "K": k[3], "shortcut": k[4], "share": round(v[0] / max(conv_ms, 1e-9), 3),
                  "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)} for k, v in top]
     ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0
@@ -560,10 +562,14 @@ def main_train(args, world, rank, dev):
     barrier()
     t0 = time.perf_counter()
     losses = []
+    host = 0.0
     for i in range(args.steps):
+        h0 = time.perf_counter()
         losses.append(tr.train_step(*pool[i % len(pool)]))
+        host += time.perf_counter() - h0
     barrier()
     dt = time.perf_counter() - t0
+    host_ms = host / args.steps * 1e3          # host time to enqueue one step (no synchronisation inside)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -581,7 +587,7 @@ def main_train(args, world, rank, dev):
             "config": {"workload": ("pemp_stage2 train_step (frozen stage-1 prior pass, batch-stat BN, CM, Dropout2d 0.5, CE, SGD), "
                                     if s2 else "pemp_stage1 train_step (batch-stat BN, DropBlock 0.1, CE, clip 1.1, SGD), ") +
                                    "ResNet-50, %d-shot, 401x401, %d episodes/rank/step, synthetic E(seed) episodes + Wgen weights" % (args.shot, B),
-                       "episodes_per_step": B, "shot": args.shot, "hipgraph": use_graph,
+                       "episodes_per_step": B, "shot": args.shot, "hipgraph": use_graph, "host_enqueue_ms_per_step": round(host_ms, 2),
                        "first_loss": round(float(ls[0]), 5), "last_loss": round(float(ls[-1]), 5)}}
 
         def guarded(key, fn):

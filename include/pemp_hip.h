@@ -221,6 +221,22 @@ int pemp_conv2d_stats_nhwc_f32(const pemp_conv_desc* d, const float* x, const fl
 int pemp_bn_stats_partials_f32(const float* stats, int M, int C, float eps, float momentum, float* mean,
                                float* invstd, float* run_mean, float* run_var, void* stream);
 
+/* The input-gradient conv whose result is the gradient at the OUTPUT of a train-mode BatchNorm(+ReLU) (autograd of
+ * BottleNeck.forward, networks/backbones.py:66-75: conv -> bn -> relu chains), with the first half of that BatchNorm's
+ * backward in its epilogue:  o = conv(x, w) (+ residual);  g = o where the BatchNorm's ReLU let the value through
+ * (bit c % 32 of mask[m][c / 32], from pemp_bn_apply_mask_f32; mask NULL: no ReLU, g = o);  y = g;  and per 32-row group
+ *   stats[r][0][c] = sum g[m][c],   stats[r][1][c] = sum g[m][c] * (z[m][c] - mean[c]) * invstd[c]
+ * (z: the BatchNorm's input, d->Cout channels, per-pixel stride ldz).  pemp_bn_bwd_partials_f32 finishes: dbeta / dgamma
+ * from the partials (fixed order, double) and dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M): the separate reduction pass
+ * over (dy, y, z) of pemp_bn_bwd_f32 and its second read of y are gone, and g doubles as the residual-branch gradient.
+ * Same restrictions and return codes as pemp_conv2d_stats_nhwc_f32; d->ldr = per-pixel stride of residual.             */
+int pemp_conv2d_bnbwd_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* residual,
+                               const uint32_t* mask, const float* z, int ldz, const float* mean, const float* invstd,
+                               float* stats, void* stream);
+int pemp_bn_bwd_partials_f32(const float* g, int ldg, const float* z, int ldz, const float* mean, const float* invstd,
+                             const float* gamma, const float* stats, float* dz, int lddz, float* dgamma, float* dbeta,
+                             int M, int C, void* stream);
+
 /* Weight gradient of pemp_conv2d_nhwc_f32 (autograd of nn.Conv2d, same call sites):
  *   dw[co][kh][kw][ci] (+)= sum_m g[m][co] * x[pix(m,kh,kw)][ci]      dw is KRSC with row length d->Kpad
  * `d` describes the FORWARD conv (d->ldy = per-pixel stride of g).  STEM4 needs Kpad % 64 == 0. */
@@ -238,6 +254,11 @@ int pemp_bn_stats_f32(const float* z, int ldz, int M, int C, float eps, float mo
 int pemp_bn_apply_f32(const float* z, int ldz, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, const float* residual, int ldr,
                       float* y, int ldy, int M, int C, int relu, void* stream);
+/* The same, also leaving the sign of y as one bit per value (mask[m][c / 32] bit c % 32 = y[m][c] > 0; M x C/32 words; NULL:
+ * none) for the fused backward above.  C in {32, 64, 128, 256, 512, 1024} when mask is given.                          */
+int pemp_bn_apply_mask_f32(const float* z, int ldz, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, const float* residual, int ldr,
+                      float* y, int ldy, int M, int C, int relu, uint32_t* mask, void* stream);
 /* backward of the above: g = dy*(y>0 if relu) [optionally stored to gout = gradient of the residual
  * branch]; dgamma = sum g*xhat, dbeta = sum g, dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).     */
 int pemp_bn_bwd_f32(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,

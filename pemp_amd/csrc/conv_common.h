@@ -15,7 +15,13 @@ struct ConvArgs {
     const float* shift;
     const float* res;
     const float* padv;      // per-input-channel value of out-of-image taps (NULL: zero padding)
-    float* stats;           // [ceil(M/32)][2][Cout] per-32-row partial sums of y and y^2 (NULL: none; conv_dma2.hip only)
+    float* stats;           // [ceil(M/32)][2][Cout] per-32-row partial sums (NULL: none; conv_dma2.hip only): of y and y^2, or,
+                            // with bz set, of g and g*xhat (BatchNorm backward; see pemp_conv2d_bnbwd_nhwc_f32)
+    const uint32_t* bmask;  // sign bits of the BatchNorm's output (NULL: no ReLU)
+    const float* bz;        // the BatchNorm's input, per-pixel stride ldbz
+    const float* bmean;
+    const float* binvstd;
+    int ldbz;
     int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, KH, KW, stride, pad, dil, ldr, Kpad;
     unsigned flags;
     int M, HoWo, cin_steps, nk, ntaps;
@@ -40,9 +46,11 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int nblk) {
 // ``pre`` (optional): the residual quads of the wave's tiles, loaded by the caller ahead of time in the order
 // [mi][ni][i] (row = (lane >> 3) + 8 i of tile (mi, ni), channels (lane & 7) * 4 ..) -- conv_dma2.hip issues those loads
 // under its last K step so that their latency is not exposed here.
-// STATS: per-channel sums of the stored values and of their squares over each 32-row tile, written to a.stats (the batch
+// EPI 1: per-channel sums of the stored values and of their squares over each 32-row tile, written to a.stats (the batch
 // statistics of the BatchNorm behind the conv; fixed layout, fixed order -> deterministic).
-template <int TM, int TN, int NPRE, bool STATS = false>
+// EPI 2: the stored value is g = o masked by the sign bits of the BatchNorm output this gradient belongs to, the sums are
+// those of g and g * xhat (first half of that BatchNorm's backward; the expression of colsum_kernel<1> in train_ops.hip).
+template <int TM, int TN, int NPRE, int EPI = 0>
 __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
                                                       int n_base, int lane, const v4f (&pre)[NPRE]) {
     constexpr bool PRE = NPRE == TM * TN * 4;       // (an array of 1 = "no prefetched residual": registers, never scratch)
@@ -56,8 +64,27 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
         v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (a.scale) sc = *(const v4f*)(a.scale + n);
         if (a.shift && !per_img) sh = *(const v4f*)(a.shift + n);
+        v4f bmu = {0.f, 0.f, 0.f, 0.f}, bis = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == 2) {
+            bmu = *(const v4f*)(a.bmean + n);
+            bis = *(const v4f*)(a.binvstd + n);
+        }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
+            v4f zt[4];
+            uint32_t mw[4];
+            if constexpr (EPI == 2) {                              // issued before the accumulators go through LDS
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m_base + mi * 32 + rr + 8 * i;
+                    zt[i] = v4f{0.f, 0.f, 0.f, 0.f};
+                    mw[i] = 0xFFFFFFFFu;
+                    if (m < a.M) {
+                        zt[i] = *(const v4f*)(a.bz + (size_t)m * a.ldbz + n);
+                        if (a.bmask) mw[i] = a.bmask[(size_t)m * (a.Cout >> 5) + (n >> 5)];
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) S[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + lr] = acc[mi][ni][e];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's writes have landed (DS is in-order per wave)
@@ -85,14 +112,25 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
                         o.z = fmaxf(o.z, 0.f);
                         o.w = fmaxf(o.w, 0.f);
                     }
+                    if constexpr (EPI == 2) {
+                        const uint32_t b = mw[i] >> c4;
+                        o.x = (b & 1u) ? o.x : 0.f;
+                        o.y = (b & 2u) ? o.y : 0.f;
+                        o.z = (b & 4u) ? o.z : 0.f;
+                        o.w = (b & 8u) ? o.w : 0.f;
+                    }
                     *(v4f*)(a.y + (size_t)m * a.ldy + n) = o;
-                    if constexpr (STATS) {
+                    if constexpr (EPI == 1) {
                         s1 += o;
                         s2 += o * o;
                     }
+                    if constexpr (EPI == 2) {
+                        s1 += o;
+                        s2 += o * ((zt[i] - bmu) * bis);
+                    }
                 }
             }
-            if constexpr (STATS) {
+            if constexpr (EPI != 0) {
                 // lanes that share the channel quad differ in lane bits 3..5 (the row inside the 8-row group): fixed butterfly
 #pragma unroll
                 for (int off = 8; off < 64; off <<= 1) {

@@ -28,7 +28,7 @@ namespace pemp {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WGM, int NW, bool PADV, bool STATS = false>
+template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0>
 __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the launch stub (buffer-resource builtins / "s" asm operands are device-only)
     constexpr int WGN = NW / WGM;
@@ -279,10 +279,10 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 #undef PEMP_MMA
 
     // ---- epilogue: transpose through LDS.  No LDS read and no DMA is outstanding after the loop's last barrier. ----
-    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, STATS>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre);
-    else if constexpr (STATS) {
+    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre);
+    else if constexpr (EPI != 0) {
         const v4f none[1] = {{0.f, 0.f, 0.f, 0.f}};
-        conv_epilogue_lds_pre<TM, TN, 1, true>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, none);
+        conv_epilogue_lds_pre<TM, TN, 1, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, none);
     } else conv_epilogue_lds<TM, TN>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
 #endif
 }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 template <int BM, int BN, int WGM, int NW>
 static int launch_dma2(const ConvArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
-    auto kern = a.stats ? conv_dma2_kernel<BM, BN, WGM, NW, false, true>
+    auto kern = a.stats ? (a.bz ? conv_dma2_kernel<BM, BN, WGM, NW, false, 2> : conv_dma2_kernel<BM, BN, WGM, NW, false, 1>)
                         : a.padv ? conv_dma2_kernel<BM, BN, WGM, NW, true> : conv_dma2_kernel<BM, BN, WGM, NW, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -290,7 +290,7 @@ extern "C" int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x
     PEMP_REQUIRE(in_elems < (1ll << 31) && out_elems < (1ll << 31), "conv2d: tensor too large for 32-bit indexing");
 
     ConvArgs a;
-    a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual; a.padv = pad_value; a.stats = nullptr;
+    a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual; a.padv = pad_value; a.stats = nullptr; a.bz = nullptr;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cout = d->Cout; a.ldy = d->ldy; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.dil = d->dil; a.ldr = d->ldr; a.Kpad = d->Kpad; a.flags = d->flags;
@@ -334,36 +334,55 @@ extern "C" int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x
 }
 
 
-extern "C" int pemp_conv2d_stats_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,
-                                          void* stream) {
-    PEMP_REQUIRE(d && x && w && y && stats, "conv2d_stats: null pointer");
-    PEMP_REQUIRE(!(d->flags & (PEMP_CONV_STEM4 | PEMP_CONV_RELU | PEMP_CONV_SHIFT_PER_IMAGE)), "conv2d_stats: plain conv only (no stem / ReLU / per-image shift)");
+static int conv_stats_common(const char* what, const pemp_conv_desc* d, ConvArgs& a, hipStream_t st) {
+    PEMP_REQUIRE(!(d->flags & (PEMP_CONV_STEM4 | PEMP_CONV_RELU | PEMP_CONV_SHIFT_PER_IMAGE)), "%s: plain conv only (no stem / ReLU / per-image shift)", what);
     PEMP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0,
-                 "conv2d_stats: bad geometry");
+                 "%s: bad geometry", what);
     const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
     const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
-    PEMP_REQUIRE(ho == d->Ho && wo == d->Wo, "conv2d_stats: Ho/Wo do not match geometry");
+    PEMP_REQUIRE(ho == d->Ho && wo == d->Wo, "%s: Ho/Wo do not match geometry", what);
     PEMP_REQUIRE(d->Cout % 64 == 0 && d->Cin % 32 == 0 && d->ldx >= d->Cin && d->ldx % 4 == 0 && d->ldy >= d->Cout && d->ldy % 4 == 0,
-                 "conv2d_stats: Cout %% 64, Cin %% 32, strides %% 4");
-    PEMP_REQUIRE(d->Kpad == d->KH * d->KW * d->Cin, "conv2d_stats: Kpad must equal KH*KW*Cin");
-    PEMP_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats) & 15) == 0, "conv2d_stats: pointers must be 16-byte aligned");
-    ConvArgs a;
-    a.x = x; a.w = w; a.y = y; a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.padv = nullptr; a.stats = stats;
+                 "%s: Cout %% 64, Cin %% 32, strides %% 4", what);
+    PEMP_REQUIRE(d->Kpad == d->KH * d->KW * d->Cin, "%s: Kpad must equal KH*KW*Cin", what);
+    a.scale = nullptr; a.shift = nullptr; a.padv = nullptr;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cout = d->Cout; a.ldy = d->ldy; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
-    a.dil = d->dil; a.ldr = 0; a.Kpad = d->Kpad; a.flags = d->flags;
+    a.dil = d->dil; a.ldr = d->ldr; a.Kpad = d->Kpad; a.flags = d->flags;
     a.HoWo = d->Ho * d->Wo;
     a.M = d->N * a.HoWo;
     a.ntaps = d->KH * d->KW;
     a.cin_steps = d->Cin / 32;
     a.nk = d->Kpad / 32;
     if (!conv_dma2_supported(a)) {
-        set_error("conv2d_stats: geometry / operand size outside the buffer-addressed kernels");
+        set_error("%s: geometry / operand size outside the buffer-addressed kernels", what);
         return -2;
     }
     int t = d->tile == 0 ? 3 : d->tile - 20;
-    PEMP_REQUIRE(t >= 1 && t <= 7, "conv2d_stats: tile must be 0 or 21..27");
-    PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || a.Cout % 128 == 0, "conv2d_stats: tile N=128 needs Cout %% 128 == 0");
-    PEMP_REQUIRE(t != 7 || a.Cout % 256 == 0, "conv2d_stats: tile 256x256 needs Cout %% 256 == 0");
-    return launch_conv_dma2(t, a, (hipStream_t)stream);
+    PEMP_REQUIRE(t >= 1 && t <= 7, "%s: tile must be 0 or 21..27", what);
+    PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || a.Cout % 128 == 0, "%s: tile N=128 needs Cout %% 128 == 0", what);
+    PEMP_REQUIRE(t != 7 || a.Cout % 256 == 0, "%s: tile 256x256 needs Cout %% 256 == 0", what);
+    return launch_conv_dma2(t, a, st);
+}
+
+extern "C" int pemp_conv2d_stats_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,
+                                          void* stream) {
+    PEMP_REQUIRE(d && x && w && y && stats, "conv2d_stats: null pointer");
+    PEMP_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats) & 15) == 0, "conv2d_stats: pointers must be 16-byte aligned");
+    ConvArgs a;
+    a.x = x; a.w = w; a.y = y; a.res = nullptr; a.stats = stats;
+    a.bmask = nullptr; a.bz = nullptr; a.bmean = nullptr; a.binvstd = nullptr; a.ldbz = 0;
+    return conv_stats_common("conv2d_stats", d, a, (hipStream_t)stream);
+}
+
+extern "C" int pemp_conv2d_bnbwd_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* residual,
+                                          const uint32_t* mask, const float* z, int ldz, const float* mean, const float* invstd,
+                                          float* stats, void* stream) {
+    PEMP_REQUIRE(d && x && w && y && z && mean && invstd && stats, "conv2d_bnbwd: null pointer");
+    PEMP_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats | (uintptr_t)z | (uintptr_t)residual | (uintptr_t)mean |
+                   (uintptr_t)invstd) & 15) == 0 && ((uintptr_t)mask & 3) == 0, "conv2d_bnbwd: pointers must be 16-byte aligned");
+    PEMP_REQUIRE(ldz >= d->Cout && ldz % 4 == 0 && (!residual || (d->ldr >= d->Cout && d->ldr % 4 == 0)), "conv2d_bnbwd: ldz / ldr");
+    ConvArgs a;
+    a.x = x; a.w = w; a.y = y; a.res = residual; a.stats = stats;
+    a.bmask = mask; a.bz = z; a.bmean = mean; a.binvstd = invstd; a.ldbz = ldz;
+    return conv_stats_common("conv2d_bnbwd", d, a, (hipStream_t)stream);
 }

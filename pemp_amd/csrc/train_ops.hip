@@ -136,23 +136,57 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
     }
 }
 
-// the same from the per-32-row partial sums a conv epilogue left (pemp_conv2d_stats_nhwc_f32): [nrows32][2][C] floats
+// Totals of the per-32-row partial sums a conv epilogue left ([n32][2][C] floats; conv_common.h): a block owns 32 channels,
+// thread (rl = tid / 8, q = tid % 8) adds the partial rows rl, rl+32, ... of channel quad q in ascending order (double), the
+// 32 row-lanes are then added in ascending order: fixed order, independent of launch geometry.  Returns, in threads 0..31,
+// the two totals of channel blockIdx.x*32 + tid.
+__device__ __forceinline__ bool partials_total(const float* __restrict__ part, int n32, int C, double& tot0, double& tot1) {
+    __shared__ double red[32][65];
+    const int q = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 32 + q * 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    int k = rl;
+    for (; k + 96 < n32; k += 128) {                     // four rows in flight per thread
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *(const float4*)(part + ((size_t)(k + 32 * u) * 2 + 0) * C + c);
+            b[u] = *(const float4*)(part + ((size_t)(k + 32 * u) * 2 + 1) * C + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[0] += (double)a[u].x; s[1] += (double)a[u].y; s[2] += (double)a[u].z; s[3] += (double)a[u].w;
+            ss[0] += (double)b[u].x; ss[1] += (double)b[u].y; ss[2] += (double)b[u].z; ss[3] += (double)b[u].w;
+        }
+    }
+    for (; k < n32; k += 32) {
+        const float4 a = *(const float4*)(part + ((size_t)k * 2 + 0) * C + c);
+        const float4 b = *(const float4*)(part + ((size_t)k * 2 + 1) * C + c);
+        s[0] += (double)a.x; s[1] += (double)a.y; s[2] += (double)a.z; s[3] += (double)a.w;
+        ss[0] += (double)b.x; ss[1] += (double)b.y; ss[2] += (double)b.z; ss[3] += (double)b.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[rl][q * 4 + e] = s[e];
+        red[rl][32 + q * 4 + e] = ss[e];
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return false;
+    double t = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
+    tot0 = t;
+    tot1 = __shfl(t, (threadIdx.x & 31) + 32, 64);       // lane c < 32 also gets the second total of its channel
+    return threadIdx.x < 32;
+}
+
 __global__ __launch_bounds__(256) void bn_stats_partials_kernel(const float* __restrict__ part, int n32, int M, int C, float eps,
                                                                 float momentum, float* __restrict__ mean,
                                                                 float* __restrict__ invstd, float* __restrict__ run_mean,
                                                                 float* __restrict__ run_var) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = lane; k < n32; k += 64) {               // lane l adds partials l, l+64, ... in order, then a fixed butterfly
-        s += (double)part[((size_t)k * 2 + 0) * C + c];
-        ss += (double)part[((size_t)k * 2 + 1) * C + c];
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        ss += __shfl_xor(ss, o, 64);
-    }
-    if (lane != 0) return;
+    double s, ss;
+    if (!partials_total(part, n32, C, s, ss)) return;
+    const int c = blockIdx.x * 32 + threadIdx.x;
     const double mu = s / M;
     double var = ss / M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -163,6 +197,16 @@ __global__ __launch_bounds__(256) void bn_stats_partials_kernel(const float* __r
         run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
         run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unbiased);
     }
+}
+
+// BatchNorm backward sums from the partials of pemp_conv2d_bnbwd_nhwc_f32: out0 = sum g, out1 = sum g * xhat
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int n32, int C,
+                                                              float* __restrict__ out0, float* __restrict__ out1) {
+    double s, ss;
+    if (!partials_total(part, n32, C, s, ss)) return;
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    out0[c] = (float)s;
+    out1[c] = (float)ss;
 }
 
 // backward sums: out0[c] = sum a, out1[c] = sum b  (fp32 results)
@@ -280,7 +324,7 @@ __global__ __launch_bounds__(256) void bn_apply_rows_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ res, int ldr, float* __restrict__ y,
-                                                            int ldy, int M, int C4, int relu) {
+                                                            int ldy, int M, int C4, int relu, uint32_t* __restrict__ mask) {
     const int c = (threadIdx.x % C4) * 4, rpb = 256 / C4;
     float alpha[4], bt[4];
 #pragma unroll
@@ -301,19 +345,32 @@ __global__ __launch_bounds__(256) void bn_apply_rows_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < ROWS_PT; ++k) {
         const int m = r0 + k * rpb;
-        if (m >= M) continue;
-        const float zv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-        float o[4];
+        uint32_t nib = 0;
+        if (m < M) {
+            const float zv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = zv[e] * alpha[e] + bt[e];
-        if (res) {
-            o[0] += rv[k].x; o[1] += rv[k].y; o[2] += rv[k].z; o[3] += rv[k].w;
-        }
-        if (relu) {
+            for (int e = 0; e < 4; ++e) o[e] = zv[e] * alpha[e] + bt[e];
+            if (res) {
+                o[0] += rv[k].x; o[1] += rv[k].y; o[2] += rv[k].z; o[3] += rv[k].w;
+            }
+            if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+            *(float4*)(y + (size_t)m * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nib |= (o[e] > 0.f ? 1u : 0u) << e;
         }
-        *(float4*)(y + (size_t)m * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (mask) {
+            // bit c % 32 of mask[m][c / 32] = (y[m][c] > 0): the 8 lanes of a row that share a 32-channel word are
+            // consecutive (C4 % 8 == 0), one of them stores the word
+            uint32_t wv = nib << (4 * (threadIdx.x & 7));
+            wv |= __shfl_xor(wv, 1, 64);
+            wv |= __shfl_xor(wv, 2, 64);
+            wv |= __shfl_xor(wv, 4, 64);
+            if ((threadIdx.x & 7) == 0 && m < M) mask[(size_t)m * (C4 >> 3) + (c >> 5)] = wv;
+        }
     }
 }
 
@@ -573,9 +630,9 @@ extern "C" int pemp_bn_stats_f32(const float* z, int ldz, int M, int C, float ep
 
 extern "C" int pemp_bn_stats_partials_f32(const float* stats, int M, int C, float eps, float momentum, float* mean,
                                           float* invstd, float* run_mean, float* run_var, void* stream) {
-    PEMP_REQUIRE(stats && mean && invstd && M > 0 && C > 0, "bn_stats_partials: bad arguments");
+    PEMP_REQUIRE(stats && mean && invstd && M > 0 && C > 0 && C % 32 == 0, "bn_stats_partials: bad arguments (C %% 32)");
     PEMP_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "bn_stats_partials: running stats must both be given or both NULL");
-    hipLaunchKernelGGL(bn_stats_partials_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, stats, cdiv(M, 32), M, C, eps,
+    hipLaunchKernelGGL(bn_stats_partials_kernel, dim3(C / 32), dim3(256), 0, (hipStream_t)stream, stats, cdiv(M, 32), M, C, eps,
                        momentum, mean, invstd, run_mean, run_var);
     return launch_status("bn_stats_partials");
 }
@@ -583,14 +640,21 @@ extern "C" int pemp_bn_stats_partials_f32(const float* stats, int M, int C, floa
 extern "C" int pemp_bn_apply_f32(const float* z, int ldz, const float* mean, const float* invstd, const float* gamma,
                                  const float* beta, const float* residual, int ldr, float* y, int ldy, int M, int C,
                                  int relu, void* stream) {
+    return pemp_bn_apply_mask_f32(z, ldz, mean, invstd, gamma, beta, residual, ldr, y, ldy, M, C, relu, nullptr, stream);
+}
+
+extern "C" int pemp_bn_apply_mask_f32(const float* z, int ldz, const float* mean, const float* invstd, const float* gamma,
+                                      const float* beta, const float* residual, int ldr, float* y, int ldy, int M, int C,
+                                      int relu, uint32_t* mask, void* stream) {
     CHK_VEC(z, ldz, C, "bn_apply");
     CHK_VEC(y, ldy, C, "bn_apply");
     PEMP_REQUIRE(M > 0 && mean && invstd && gamma && beta, "bn_apply: null pointer");
     if (residual) CHK_VEC(residual, ldr, C, "bn_apply");
+    PEMP_REQUIRE(!mask || (C % 32 == 0 && C <= 1024 && 256 % (C / 4) == 0), "bn_apply: the sign mask needs C in {32, 64, 128, 256, 512, 1024}");
     const long long total = (long long)M * (C / 4);
-    if (rows_form(C))
+    if (rows_form(C) || mask)
         hipLaunchKernelGGL(bn_apply_rows_kernel, dim3(rows_grid(M, C)), dim3(256), 0, (hipStream_t)stream, z, ldz, mean, invstd,
-                           gamma, beta, residual, ldr, y, ldy, M, C / 4, relu);
+                           gamma, beta, residual, ldr, y, ldy, M, C / 4, relu, mask);
     else
         hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz, mean,
                            invstd, gamma, beta, residual, ldr, y, ldy, (long long)M, C / 4, relu);
@@ -621,6 +685,26 @@ extern "C" int pemp_bn_bwd_f32(const float* dy, int lddy, const float* y, int ld
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean,
                            invstd, gamma, dbeta, dgamma, dz, lddz, gout, ldg, (long long)M, C / 4, relu);
     return launch_status("bn_bwd");
+}
+
+extern "C" int pemp_bn_bwd_partials_f32(const float* g, int ldg, const float* z, int ldz, const float* mean,
+                                        const float* invstd, const float* gamma, const float* stats, float* dz, int lddz,
+                                        float* dgamma, float* dbeta, int M, int C, void* stream) {
+    CHK_VEC(g, ldg, C, "bn_bwd_partials");
+    CHK_VEC(z, ldz, C, "bn_bwd_partials");
+    CHK_VEC(dz, lddz, C, "bn_bwd_partials");
+    PEMP_REQUIRE(M > 0 && mean && invstd && gamma && dgamma && dbeta && stats, "bn_bwd_partials: null pointer");
+    PEMP_REQUIRE(C % 32 == 0, "bn_bwd_partials: C %% 32");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(C / 32), dim3(256), 0, st, stats, cdiv(M, 32), C, dbeta, dgamma);
+    const long long total = (long long)M * (C / 4);
+    if (rows_form(C))
+        hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3(rows_grid(M, C)), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, z,
+                           ldz, mean, invstd, gamma, dbeta, dgamma, dz, lddz, (float*)nullptr, 0, M, C / 4, 0);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, z,
+                           ldz, mean, invstd, gamma, dbeta, dgamma, dz, lddz, (float*)nullptr, 0, (long long)M, C / 4, 0);
+    return launch_status("bn_bwd_partials");
 }
 
 extern "C" int pemp_relu_bias_bwd_f32(const float* dy, int lddy, const float* y, int ldy, const float* add, int lda,

@@ -216,6 +216,57 @@ def conv2d_stats(x, p, out=None, tile=0):
     return out, part
 
 
+def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
+    """g = mask(conv(x, w) + residual) -- the gradient at the output of a train-mode BatchNorm(+ReLU), masked by that
+    BatchNorm's ReLU -- with the per-32-row partial sums of g and g * xhat left by the epilogue
+    (pemp_conv2d_bnbwd_nhwc_f32).  ``bn``: dict with z (the BatchNorm's input, NHWC like the result), mean, invstd and
+    mask (int32 [M, C/32] sign bits from train_ops.bn_apply, or None for a BatchNorm without ReLU).
+    -> (g, partials [ceil(M/32), 2, Cout])."""
+    lib = _lib.load()
+    z, mask = bn["z"], bn.get("mask")
+    _chk_dev(x, p.w, out, residual, z, mask, bn["mean"], bn["invstd"])
+    ldx = _nhwc(x, "x")
+    n, h, w, cin = x.shape
+    if cin != p.cin:
+        raise ValueError(f"conv2d_bnbwd: input has {cin} channels, layer expects {p.cin}")
+    if p.stem or p.scale is not None or p.shift is not None:
+        raise ValueError("conv2d_bnbwd: plain (non-stem, no affine) convs only")
+    ho = conv_out_size(h, p.kh, p.stride, p.pad, p.dil)
+    wo = conv_out_size(w, p.kw, p.stride, p.pad, p.dil)
+    if out is None:
+        out = torch.empty((n, ho, wo, p.cout), dtype=torch.float32, device=x.device)
+    ldy = _nhwc(out, "out")
+    if tuple(z.shape) != tuple(out.shape):
+        raise ValueError(f"conv2d_bnbwd: the BatchNorm input is {tuple(z.shape)}, the gradient {tuple(out.shape)}")
+    ldz = _nhwc(z, "z")
+    m = n * ho * wo
+    if mask is not None and (mask.dtype != torch.int32 or not mask.is_contiguous() or mask.numel() != m * (p.cout // 32)):
+        raise ValueError("conv2d_bnbwd: mask must be a contiguous int32 [M, Cout/32] tensor")
+    ldr = 0
+    if residual is not None:
+        ldr = _nhwc(residual, "residual")
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError("conv2d_bnbwd: residual shape mismatch")
+    part = torch.empty(((m + 31) // 32, 2, p.cout), dtype=torch.float32, device=x.device)
+
+    def launch(t):
+        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, 0, t)
+        _lib.check(lib.pemp_conv2d_bnbwd_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(residual), _p(mask), _p(z), ldz,
+                                                  _p(bn["mean"]), _p(bn["invstd"]), _p(part), _stream()),
+                   "pemp_conv2d_bnbwd_nhwc_f32")
+
+    if tile == 0:
+        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 3, n, h, w, int(residual is not None), 0)   # 3: this epilogue
+        tile = _TILE_CACHE.get(key)
+        if tile is None:
+            if AUTOTUNE and m >= 1024 and not torch.cuda.is_current_stream_capturing():
+                tile = _pick_tile(launch, p, key, p.cout, only=range(21, 28))
+            else:
+                tile = DEFAULT_TILE + 10
+    launch(tile)
+    return out, part
+
+
 def stats_supported(x, p):
     """Whether conv2d_stats applies to this (input, layer): what conv_dma2_supported checks in csrc/conv_dma2.hip."""
     n, h, w, cin = x.shape

@@ -29,6 +29,7 @@ from .ops import ConvParams
 
 BN_MOM = 0.1
 FUSE_BN_STATS = os.environ.get("PEMP_FUSE_BN_STATS", "1") != "0"   # conv epilogue starts the batch statistics (A/B switch)
+FUSE_BN_BWD = os.environ.get("PEMP_FUSE_BN_BWD", "1") != "0"       # input-gradient epilogue starts the BatchNorm backward
 SEG_EVERY = int(os.environ.get("PEMP_SEG_EVERY", "1"))     # residual blocks per graph segment of the backward pass
 
 
@@ -57,7 +58,8 @@ class FlatParams:
         self.grad_views = [self._view(self.grad, p, o) for p, o in zip(self.params, offs)]
         self.attach_grads()
         # weight-gradient kernels run on a side stream (see _Conv.wgrad); own workspace cache, joined by the engine
-        self.side_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.side_stream = (torch.cuda.Stream(device=device, priority=int(os.environ.get("PEMP_SIDE_PRIORITY", "0")))
+                            if torch.device(device).type == "cuda" else None)
         self.side_ws, self.side_keep = {}, []
         self.capture = None            # a SegmentedCapture while the step is being recorded (Stage1Trainer.use_graph)
 
@@ -373,19 +375,37 @@ class Stage1TrainEngine:
         else:
             z = ops.conv2d(x, prm) if img_bias is None else ops.conv2d(x, prm, shift_override=img_bias, per_image_shift=True)
             mean, invstd = bn.stats(z, self.ws)
-        y = T.bn_apply(z, mean, invstd, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(z), residual=residual, relu=relu)
-        return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu)
+        mask = None
+        if FUSE_BN_BWD and relu and T.mask_supported(z.shape[-1]):       # sign bits of y: what the backward needs of it
+            mask = torch.empty((z.numel() // z.shape[-1], z.shape[-1] // 32), dtype=torch.int32, device=z.device)
+        y = T.bn_apply(z, mean, invstd, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(z), residual=residual, relu=relu,
+                       mask=mask)
+        return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu, mask=mask)
 
-    def _cbn_bwd(self, dy, rec, conv, bn, want_gout=False, need_dx=True, add_to=None):
+    def _cbn_bwd(self, dy, rec, conv, bn, want_gout=False, need_dx=True, add_to=None, up=None):
         """-> (dx [compact for stride-2], gout).  ``add_to`` is added to dx inside the dgrad epilogue; the
-        gradient at the conv output stays in rec["dz"]."""
+        gradient at the conv output stays in rec["dz"].  ``up``: the tape record of the BatchNorm whose OUTPUT gradient dx
+        is (the conv -> bn -> relu in front of this one): the dgrad epilogue then masks dx with that BatchNorm's ReLU and
+        starts its column sums (ops.conv2d_bnbwd), and up["gpart"] tells its _cbn_bwd to finish from there."""
         dz = torch.empty_like(rec["z"])
-        gout = torch.empty_like(rec["z"]) if want_gout else None
-        T.bn_bwd(dy, rec["y"], rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, dz, gout=gout, relu=rec["relu"],
-                 ws_cache=self.ws, out=bn.grad_out())            # dgamma / dbeta go straight into the flat gradient buffer
+        if "gpart" in rec:           # dy is the masked gradient g already; its sums were started by the conv that made it
+            T.bn_bwd_partials(dy, rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, rec.pop("gpart"), dz,
+                              out=bn.grad_out())
+            gout = dy if want_gout else None
+        else:
+            gout = torch.empty_like(rec["z"]) if want_gout else None
+            T.bn_bwd(dy, rec["y"], rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, dz, gout=gout, relu=rec["relu"],
+                     ws_cache=self.ws, out=bn.grad_out())        # dgamma / dbeta go straight into the flat gradient buffer
         conv.wgrad(rec["x"], dz, self.ws)
         rec["dz"] = dz
-        dx = ops.conv2d(dz, conv.dgrad_params(), residual=add_to) if need_dx else None
+        if not need_dx:
+            return None, gout
+        prm = conv.dgrad_params()
+        if (up is not None and FUSE_BN_BWD and (up["mask"] is not None or not up["relu"]) and prm.shift is None
+                and ops.stats_supported(dz, prm)):
+            dx, up["gpart"] = ops.conv2d_bnbwd(dz, prm, up, residual=add_to)
+        else:
+            dx = ops.conv2d(dz, prm, residual=add_to)
         return dx, gout
 
     def _block_fwd(self, x, b, bias_c1=None, bias_ds=None):
@@ -399,15 +419,18 @@ class Stage1TrainEngine:
         out, rec["r3"] = self._cbn_fwd(y2, b["c3"], b["b3"], True, residual=res)
         return out, rec
 
-    def _block_bwd(self, dx, b, rec):
+    def _block_bwd(self, dx, b, rec, up=None):
+        """``up``: tape record of the BatchNorm(+ReLU) that produced this block's input (the previous block's bn3)."""
         x = rec["x"]
         stride = b["c1"].stride
-        dy2, gout = self._cbn_bwd(dx, rec["r3"], b["c3"], b["b3"], want_gout=True)
-        dy1, _ = self._cbn_bwd(dy2, rec["r2"], b["c2"], b["b2"])
+        dy2, gout = self._cbn_bwd(dx, rec["r3"], b["c3"], b["b3"], want_gout=True, up=rec["r2"])
+        dy1, _ = self._cbn_bwd(dy2, rec["r2"], b["c2"], b["b2"], up=rec["r1"])
+        if stride != 1:
+            up = None                # the compact stride-2 gradient is scattered first: not the producer's final value
         if b["ds"] is None:
-            return self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=gout)[0]
+            return self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=gout, up=up)[0]
         dxd, _ = self._cbn_bwd(gout, rec["rd"], b["ds"][0], b["ds"][1])
-        dxc, _ = self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=dxd)
+        dxc, _ = self._cbn_bwd(dy1, rec["r1"], b["c1"], b["b1"], add_to=dxd, up=up)
         return dxc if stride == 1 else T.scatter_strided(dxc, (x.shape[1], x.shape[2]), stride)
 
     # -- forward ------------------------------------------------------------------------------
@@ -562,7 +585,7 @@ class Stage1TrainEngine:
     def _trunk_backward(self, dx):
         tp = self.tape
         for bi in range(len(self.blocks) - 1, -1, -1):                          # residual blocks, last to first
-            dx = self._block_bwd(dx, self.blocks[bi], tp["blocks"][bi])
+            dx = self._block_bwd(dx, self.blocks[bi], tp["blocks"][bi], up=tp["blocks"][bi - 1]["r3"] if bi > 0 else None)
             self.buckets.ready_from(self.block_off[bi])
             if bi % SEG_EVERY == SEG_EVERY - 1:
                 self.flat.cut()                    # every SEG_EVERY-th block: its weight gradients run under the next blocks' chain

@@ -51,15 +51,41 @@ def bn_stats_partials(part, m, eps=1e-5, momentum=0.1, run_mean=None, run_var=No
     return mean, invstd
 
 
-def bn_apply(z, mean, invstd, gamma, beta, out, residual=None, relu=True):
+def bn_apply(z, mean, invstd, gamma, beta, out, residual=None, relu=True, mask=None):
+    """``mask``: int32 [M, C/32] tensor that receives the sign bits of the result (bit c % 32 of mask[m, c // 32])."""
     lib = _lib.load()
-    _chk_dev(z, out, residual)
+    _chk_dev(z, out, residual, mask)
     m, c, ldz = _rows(z, "z")
     _, _, ldy = _rows(out, "out")
     ldr = _rows(residual, "residual")[2] if residual is not None else 0
-    _lib.check(lib.pemp_bn_apply_f32(_p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), ldr,
-                                     _p(out), ldy, m, c, 1 if relu else 0, _stream()), "bn_apply")
+    if mask is not None and (mask.dtype != torch.int32 or not mask.is_contiguous() or mask.numel() != m * (c // 32) or c % 32):
+        raise ValueError(f"bn_apply: mask must be a contiguous int32 [{m}, {c}/32] tensor")
+    _lib.check(lib.pemp_bn_apply_mask_f32(_p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), ldr,
+                                          _p(out), ldy, m, c, 1 if relu else 0, _p(mask), _stream()), "bn_apply")
     return out
+
+
+def mask_supported(c):
+    return c in (32, 64, 128, 256, 512, 1024)
+
+
+def bn_bwd_partials(g, z, mean, invstd, gamma, part, dz, out=None):
+    """Second half of the BatchNorm backward after ops.conv2d_bnbwd: -> (dgamma, dbeta); writes dz."""
+    lib = _lib.load()
+    _chk_dev(g, z, dz, part)
+    m, c, ldg = _rows(g, "g")
+    ldz = _rows(z, "z")[2]
+    lddz = _rows(dz, "dz")[2]
+    if part.dtype != torch.float32 or not part.is_contiguous() or tuple(part.shape) != ((m + 31) // 32, 2, c):
+        raise ValueError(f"bn_bwd_partials: partials must be contiguous fp32 [ceil({m}/32), 2, {c}], got {tuple(part.shape)}")
+    if out is None:
+        dgamma = torch.empty(c, dtype=torch.float32, device=g.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=g.device)
+    else:
+        dgamma, dbeta = out
+    _lib.check(lib.pemp_bn_bwd_partials_f32(_p(g), ldg, _p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(part), _p(dz), lddz,
+                                            _p(dgamma), _p(dbeta), m, c, _stream()), "bn_bwd_partials")
+    return dgamma, dbeta
 
 
 def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=None, out=None):

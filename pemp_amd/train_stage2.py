@@ -118,7 +118,9 @@ class Stage2TrainEngine(Stage1TrainEngine):
         group = tp["group"]
         for bi in range(len(self.blocks) - 1, -1, -1):
             b, rec = self.blocks[bi], tp["blocks"][bi]
-            dx = self._block_bwd(dx, b, rec)
+            # (a stage's first block gets the context-module gradient added to dx below: not final when it leaves the conv)
+            up = tp["blocks"][bi - 1]["r3"] if bi > 0 and bi not in self.stage_first else None
+            dx = self._block_bwd(dx, b, rec, up=up)
             if bi not in self.stage_first:
                 if bi % 2 == 1:
                     self.flat.cut()

@@ -1,0 +1,41 @@
+"""Timeline of the steady-state training steps from a rocprofv3 kernel trace: how busy the GPU is, how much of the
+step two kernels run side by side, and where the main queue waits.  python scratch/timeline.py trace.csv out.json per_step"""
+import csv, json, sys, collections
+trace, out, per_step = sys.argv[1], sys.argv[2], int(sys.argv[3])
+steps = 20
+rows = [r for r in csv.DictReader(open(trace))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+is_gemm = lambda k: ("conv_dma" in k or "conv_igemm" in k or ("conv_wgrad" in k))
+gemm = [r for r in rows if is_gemm(r["Kernel_Name"])][-steps * per_step:]
+t0 = int(gemm[0]["Start_Timestamp"])
+tail = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
+t1 = max(int(r["End_Timestamp"]) for r in tail)
+ev = []
+for r in tail:
+    ev.append((int(r["Start_Timestamp"]), 1)); ev.append((int(r["End_Timestamp"]), -1))
+ev.sort()
+depth, last, busy, multi = 0, t0, 0, 0
+for t, d in ev:
+    if depth >= 1: busy += t - last
+    if depth >= 2: multi += t - last
+    depth += d; last = t
+qkey = "Queue_Id" if "Queue_Id" in tail[0] else "Stream_Id"
+queues = collections.defaultdict(list)
+for r in tail: queues[r[qkey]].append(r)
+qs = {}
+for q, rs in queues.items():
+    b = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs)
+    gaps = collections.Counter(); gap_ns = collections.Counter()
+    for a, c in zip(rs, rs[1:]):
+        g = int(c["Start_Timestamp"]) - int(a["End_Timestamp"])
+        if g > 0:
+            k = c["Kernel_Name"].split("(")[0][:60]
+            gaps[k] += 1; gap_ns[k] += g
+    qs[q] = {"launches_per_step": round(len(rs) / steps, 1), "busy_ms_per_step": round(b / steps / 1e6, 3),
+             "gap_before_ms_per_step": {k: round(v / steps / 1e6, 3) for k, v in gap_ns.most_common(8)},
+             "total_gap_ms_per_step": round(sum(gap_ns.values()) / steps / 1e6, 3)}
+rec = {"window_ms_per_step": round((t1 - t0) / steps / 1e6, 3), "busy_ms_per_step": round(busy / steps / 1e6, 3),
+       "idle_ms_per_step": round((t1 - t0 - busy) / steps / 1e6, 3), "two_or_more_kernels_ms_per_step": round(multi / steps / 1e6, 3),
+       "queues": qs}
+json.dump(rec, open(out, "w"), indent=1)
+print(json.dumps(rec, indent=1))

@@ -1,0 +1,10 @@
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r02b; mkdir -p $O
+rm -rf $O/kt
+timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 bench.py --mode train $TRAIN_EXTRA --steps 20 --warmup 5 --cpu-episodes 0 --no-e2e --no-single --no-roofline > $O/kt.log 2>&1 || { tail -20 $O/kt.log; exit 1; }
+grep '^{' $O/kt.log | tail -n 1 | cut -c1-300
+f=$(find $O/kt -name "*kernel_trace.csv" | head -1)
+head -1 $f
+python3 scratch/timeline.py $f $O/train_timeline.json 155 > $O/timeline.log 2>&1; tail -80 $O/timeline.log
+rm -rf $O/kt

@@ -166,6 +166,71 @@ def test_conv_with_batch_statistics_in_the_epilogue(hip_lib, dev, case):
     assert torch.allclose(invstd.double().cpu(), 1 / (zr.var(0, unbiased=False) + 1e-5).sqrt(), rtol=1e-5)
 
 
+BNBWD_CASES = [  # N, H, W, Cin, Cout, k, p, d, residual, relu
+    (2, 51, 51, 256, 64, 1, 0, 1, False, True),       # dgrad of a bottleneck's c3 into bn2
+    (2, 51, 51, 64, 64, 3, 1, 1, False, True),        # dgrad of c2 into bn1 (M = 5202: ragged last row group)
+    (2, 26, 26, 128, 512, 1, 0, 1, True, True),       # dgrad of the next block's c1 + residual-branch gradient into bn3
+    (2, 26, 26, 256, 256, 3, 2, 2, False, True),      # dilated
+    (1, 5, 3, 64, 1024, 1, 0, 1, True, False),        # a BatchNorm without ReLU (no mask); M = 15
+]
+
+
+@pytest.mark.parametrize("case", BNBWD_CASES)
+def test_input_gradient_conv_with_batchnorm_backward_in_the_epilogue(hip_lib, dev, case):
+    """pemp_bn_apply_mask_f32 + pemp_conv2d_bnbwd_nhwc_f32 + pemp_bn_bwd_partials_f32 against the unfused chain
+    (pemp_conv2d_nhwc_f32 -> pemp_bn_bwd_f32): the sign bits are exactly y > 0, the masked gradient g is bit-identical
+    (every tile), the partial sums are those of g and g * xhat (fp32 sums of 32 terms), and dz / dgamma / dbeta agree to
+    fp32 rounding of the reductions."""
+    from pemp_amd import ops, train_ops as T
+    N, H, W, Cin, Cout, k, p, d, with_res, relu = case
+    M = N * H * W
+    # forward of the BatchNorm this gradient belongs to
+    z = _nhwc(_rand(N, Cout, H, W, seed=11) * 2 + 0.3).to(dev)
+    res_f = _nhwc(_rand(N, Cout, H, W, seed=12)).to(dev)
+    gamma, beta = _rand(Cout, seed=13, lo=0.5, hi=1.5).to(dev), _rand(Cout, seed=14).to(dev)
+    mean, invstd = T.bn_stats(z.view(M, Cout))
+    mask = torch.empty((M, Cout // 32), dtype=torch.int32, device=dev) if relu else None
+    y = T.bn_apply(z, mean, invstd, gamma, beta, torch.empty_like(z), residual=res_f, relu=relu, mask=mask)
+    y_plain = T.bn_apply(z, mean, invstd, gamma, beta, torch.empty_like(z), residual=res_f, relu=relu)
+    assert torch.equal(y, y_plain)
+    if relu:
+        bits = (y.view(M, Cout // 32, 32) > 0).to(torch.int64) << torch.arange(32, device=dev)
+        want = bits.sum(-1)
+        want = torch.where(want >= 2 ** 31, want - 2 ** 32, want).to(torch.int32)
+        assert torch.equal(mask, want)
+    # the conv that produces the gradient at the BatchNorm's output
+    x = _nhwc(_rand(N, Cin, H, W, seed=1)).to(dev)
+    w = _rand(Cout, Cin, k, k, seed=2, lo=-0.1, hi=0.1)
+    packed, kpad = ops.pack_conv_weight(w.to(dev))
+    prm = ops.ConvParams(packed, None, None, Cin, Cout, k, k, 1, p, d, kpad, False, False)
+    add = _nhwc(_rand(N, Cout, H, W, seed=3)).to(dev) if with_res else None
+    dy = ops.conv2d(x, prm, residual=add, tile=13)
+    g_ref = torch.where(y > 0, dy, torch.zeros_like(dy)) if relu else dy
+    bn = dict(z=z, mean=mean, invstd=invstd, mask=mask)
+    xhat = ((z.view(M, Cout) - mean) * invstd).double().cpu()
+    gd = g_ref.view(M, Cout).double().cpu()
+    pad = (-M) % 32
+    zp = lambda t: torch.cat([t, torch.zeros(pad, Cout, dtype=torch.float64)]).view(-1, 32, Cout)
+    first = None
+    for tile in [t for t in range(21, 28) if Cout % ops.TILE_VARIANTS[t][1] == 0]:
+        g, part = ops.conv2d_bnbwd(x, prm, bn, residual=add, tile=tile)
+        assert torch.equal(g, g_ref), tile
+        pc = part.double().cpu()
+        assert ((pc[:, 0] - zp(gd).sum(1)).abs() <= 1e-6 * zp(gd).abs().sum(1) + 1e-30).all(), tile
+        assert ((pc[:, 1] - zp(gd * xhat).sum(1)).abs() <= 2e-6 * zp(gd * xhat).abs().sum(1) + 1e-30).all(), tile
+        if first is None:
+            first = part.clone()
+        assert torch.equal(part, first), tile
+    dz = torch.empty_like(z)
+    dgamma, dbeta = T.bn_bwd_partials(g_ref, z, mean, invstd, gamma, first, dz)
+    dz0, gout0 = torch.empty_like(z), torch.empty_like(z)
+    dgamma0, dbeta0 = T.bn_bwd(dy, y, z, mean, invstd, gamma, dz0, gout=gout0, relu=relu)
+    assert torch.equal(gout0, g_ref)
+    scale = gd.abs().sum(0).float().to(dev)
+    assert ((dbeta - dbeta0).abs() <= 1e-6 * scale + 1e-30).all() and ((dgamma - dgamma0).abs() <= 4e-6 * scale + 1e-30).all()
+    assert torch.allclose(dz, dz0, rtol=1e-4, atol=1e-5), (dz - dz0).abs().max()
+
+
 def test_conv_with_batch_statistics_refuses_what_it_cannot_run(hip_lib, dev):
     from pemp_amd import _lib, ops
     x = torch.zeros(1, 8, 8, 64, device=dev)
