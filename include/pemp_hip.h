@@ -214,10 +214,23 @@ int pemp_cm_bwd_add_arg_f32(const float* mask, const float* dstat, const int32_t
  *   stats[r][0][c] = sum y[m][c],  stats[r][1][c] = sum y[m][c]^2        (m in rows 32 r .. 32 r + 31, m < M)
  * i.e. ceil(M/32) x 2 x Cout floats.  pemp_bn_stats_partials_f32 adds them in a fixed order (double) into mean /
  * 1/sqrt(var+eps) and the running-statistics update: the separate pass over y that pemp_bn_stats_f32 makes is gone.
- * Deterministic (no atomics).  Non-stem convs whose operands lie below 2 GiB (the buffer-addressed kernels); returns
- * -2 where that does not hold (use pemp_conv2d_nhwc_f32 + pemp_bn_stats_f32 then).  d->tile: 0 or 21..27.            */
+ * Deterministic.  Non-stem convs whose operands lie below 2 GiB (the buffer-addressed kernels); returns
+ * -2 where that does not hold (use pemp_conv2d_nhwc_f32 + pemp_bn_stats_f32 then).  d->tile: 0 or 21..27, or 31..37
+ * (not 33) = the same tile shapes with the LAST, partly filled round of tiles split along K (8 images of 51 x 51 pixels
+ * give 326 tiles of 128 x 128 for 256 output channels: 256 CUs are busy for two rounds and do the work of 1.27).  The
+ * T mod 256 remainder tiles are computed by up to 256 blocks, each over a slice of the K steps; partial accumulators go
+ * to `ws`, the block that arrives last (an arrival counter per tile) adds the slices in ascending order -- the result
+ * does not depend on arrival order, but differs from the unsplit variants by the rounding of that regrouped sum.
+ * ws: pemp_conv2d_splitk_workspace_bytes(d) bytes of UNCACHED device memory from pemp_uncached_alloc (the blocks of one
+ * tile run on different XCDs, whose L2s do not see each other's lines: in uncached memory the exchange needs no cache
+ * write-back / invalidate -- with agent-scope fences on ordinary memory the variant loses what it gains); its first 1024
+ * bytes (the counters) must be zero on entry and are left zero; not shared by launches that may run concurrently.
+ * NULL / 0 for the other tile ids.                                                                                      */
+size_t pemp_conv2d_splitk_workspace_bytes(const pemp_conv_desc* d);
+void* pemp_uncached_alloc(size_t bytes);       /* zero-filled; NULL on failure (pemp_last_error) */
+int pemp_uncached_free(void* p);
 int pemp_conv2d_stats_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,
-                               void* stream);
+                               void* ws, size_t ws_bytes, void* stream);
 int pemp_bn_stats_partials_f32(const float* stats, int M, int C, float eps, float momentum, float* mean,
                                float* invstd, float* run_mean, float* run_var, void* stream);
 
@@ -229,10 +242,11 @@ int pemp_bn_stats_partials_f32(const float* stats, int M, int C, float eps, floa
  * (z: the BatchNorm's input, d->Cout channels, per-pixel stride ldz).  pemp_bn_bwd_partials_f32 finishes: dbeta / dgamma
  * from the partials (fixed order, double) and dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M): the separate reduction pass
  * over (dy, y, z) of pemp_bn_bwd_f32 and its second read of y are gone, and g doubles as the residual-branch gradient.
- * Same restrictions and return codes as pemp_conv2d_stats_nhwc_f32; d->ldr = per-pixel stride of residual.             */
+ * Same restrictions, tile ids, workspace and return codes as pemp_conv2d_stats_nhwc_f32; d->ldr = per-pixel stride of
+ * residual.                                                                                                            */
 int pemp_conv2d_bnbwd_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* residual,
                                const uint32_t* mask, const float* z, int ldz, const float* mean, const float* invstd,
-                               float* stats, void* stream);
+                               float* stats, void* ws, size_t ws_bytes, void* stream);
 int pemp_bn_bwd_partials_f32(const float* g, int ldg, const float* z, int ldz, const float* mean, const float* invstd,
                              const float* gamma, const float* stats, float* dz, int lddz, float* dgamma, float* dbeta,
                              int M, int C, void* stream);

@@ -76,9 +76,13 @@ SYMBOLS = {
     "pemp_dropout2d_mask_f32": (c_int, [c_fp, c_fp, c_int, c_int, C.c_float, C.c_uint64, C.c_uint64, c_fp, c_fp]),
     "pemp_channel_scale_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "pemp_cm_bwd_add_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
-    "pemp_conv2d_stats_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "pemp_conv2d_splitk_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
+    "pemp_uncached_alloc": (c_fp, [c_size]),
+    "pemp_uncached_free": (c_int, [c_fp]),
+    "pemp_conv2d_stats_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_size, c_fp]),
     "pemp_bn_stats_partials_f32": (c_int, [c_fp, c_int, c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
-    "pemp_conv2d_bnbwd_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "pemp_conv2d_bnbwd_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp,
+                                           c_size, c_fp]),
     "pemp_bn_bwd_partials_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_int,
                                          c_fp]),
     "pemp_bn_apply_mask_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int,

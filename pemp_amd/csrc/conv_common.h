@@ -22,6 +22,11 @@ struct ConvArgs {
     const float* bmean;
     const float* binvstd;
     int ldbz;
+    // split-K of the remainder tiles (conv_dma2.hip, SK kernels): tiles >= sk_full are computed by sk_S blocks each, every block
+    // over 1/sk_S of the K steps; partial accumulators go to sk_ws, the last block to arrive adds them in piece order
+    float* sk_ws;
+    int* sk_cnt;            // one arrival counter per split tile: zero on entry, left zero
+    int sk_full, sk_S;
     int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, KH, KW, stride, pad, dil, ldr, Kpad;
     unsigned flags;
     int M, HoWo, cin_steps, nk, ntaps;
@@ -163,5 +168,10 @@ int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st);
 // conv_dma2.hip
 bool conv_dma2_supported(const ConvArgs& a);
 int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st);
+// split-K plan of tile variant `tile` (1..7) for this geometry: number of unsplit tiles, split tiles, pieces per split tile
+// (pieces == 1: the variant runs unsplit) and the workspace the launch needs (counters first, then the partial tiles)
+struct SplitKPlan { int full, split, pieces; size_t ws_bytes; };
+SplitKPlan conv_dma2_splitk_plan(int tile, const ConvArgs& a);
+int launch_conv_dma2_splitk(int tile, ConvArgs a, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace pemp

@@ -28,7 +28,7 @@ namespace pemp {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0>
+template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false>
 __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the launch stub (buffer-resource builtins / "s" asm operands are device-only)
     constexpr int WGN = NW / WGM;
@@ -51,7 +51,24 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
     const int lr = lane & 31, lh = lane >> 5;
 
     const int ntn = a.Cout / BN;
-    const int tile_id = xcd_tile_order(blockIdx.x, gridDim.x);
+    // SK: blocks [0, sk_full) compute whole tiles; behind them, sk_S consecutive blocks share one of the remaining tiles,
+    // block `piece` of them running K steps [kt0, kt0 + nkl)
+    int tile_id, kt0 = 0, nkl = a.nk, sk_r = -1, piece = 0;
+    if constexpr (SK) {
+        const int b = blockIdx.x;
+        if (b < a.sk_full) {
+            tile_id = xcd_tile_order(b, a.sk_full);
+        } else {
+            const int rb = b - a.sk_full;
+            sk_r = rb / a.sk_S;
+            piece = rb - sk_r * a.sk_S;
+            tile_id = a.sk_full + sk_r;
+            kt0 = (int)((long long)piece * a.nk / a.sk_S);
+            nkl = (int)((long long)(piece + 1) * a.nk / a.sk_S) - kt0;
+        }
+    } else {
+        tile_id = xcd_tile_order(blockIdx.x, gridDim.x);
+    }
     const int bm = tile_id / ntn;
     const int bn = tile_id % ntn;
     const int m0 = bm * BM, n0 = bn * BN;
@@ -102,6 +119,17 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
     // wave-uniform K-step state.  Multi-tap convs: channel chunk OUTER, tap INNER (same order as every other conv
     // kernel of the library: variants stay bit-identical); 1x1: chunks in sequence.
     int tap = 0, cb = 0, kh_i = 0, kw_i = 0;
+    if constexpr (SK) {
+        if (kt0 > 0) {
+            const int cb0 = a.ntaps > 1 ? kt0 / a.ntaps : kt0;
+            const int tap0 = a.ntaps > 1 ? kt0 - cb0 * a.ntaps : 0;
+            const int kh0 = tap0 / a.KW;
+            cb = __builtin_amdgcn_readfirstlane(cb0);
+            tap = __builtin_amdgcn_readfirstlane(tap0);
+            kh_i = __builtin_amdgcn_readfirstlane(kh0);
+            kw_i = __builtin_amdgcn_readfirstlane(tap0 - kh0 * a.KW);
+        }
+    }
     const int tapw = a.dil * a.ldx * 4, taph = a.dil * a.W * a.ldx * 4;     // byte displacement of one tap step
 
 #define PEMP_DMA2(buf_)                                                                                           \
@@ -161,7 +189,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
     PEMP_DMA2(0);
-    if (a.nk > 1) {
+    if (nkl > 1) {
         PEMP_ADVANCE2();
         PEMP_DMA2(1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");         // step 0 has landed, step 1 may still fly
@@ -239,11 +267,11 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 
     PEMP_READ(0, 0, 0);
     int kt = 0;
-    for (; kt + 2 < a.nk; ++kt) {
+    for (; kt + 2 < nkl; ++kt) {
         const int buf = kt & 1;
         PEMP_STEP(buf, true, true);
     }
-    if (kt + 1 < a.nk) {
+    if (kt + 1 < nkl) {
         const int buf = kt & 1;
         PEMP_STEP(buf, false, true);
         ++kt;
@@ -278,6 +306,53 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 #undef PEMP_READ
 #undef PEMP_MMA
 
+    if constexpr (SK) {
+        if (sk_r >= 0) {
+            // partial accumulators in register order: float4 q of tile (mi, ni) of every lane, 1 KB per wave-instruction
+            v4f* part = (v4f*)a.sk_ws + ((size_t)(sk_r * a.sk_S + piece) * NW + wave) * (TM * TN * 4 * 64) + lane;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        part[((mi * TN + ni) * 4 + q) * 64] = v4f{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+            // sk_ws is UNCACHED device memory (pemp_uncached_alloc): stores complete in memory, loads come from memory,
+            // whichever XCD issues them -- no L2 write-back / invalidate (measured: agent-scope fences here cost the
+            // 128 x 128 variant 118 -> 94 TFLOP/s, every fence flushing and emptying an XCD's L2 under the other tiles)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's partial stores have been acknowledged
+            __syncthreads();                                               // ... everybody's
+            int* flag = (int*)smem;
+            if (tid == 0) *flag = atomicAdd(a.sk_cnt + sk_r, 1);       // only now this block counts as arrived
+            __syncthreads();
+            const int arrived = *flag;
+            __syncthreads();
+            if (arrived != a.sk_S - 1) return;        // not the last piece of this tile: done
+            if (tid == 0) a.sk_cnt[sk_r] = 0;         // the counter is ready for the next launch
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+            for (int pc = 0; pc < a.sk_S; ++pc) {     // pieces in ascending order, whichever arrived last: deterministic
+                const v4f* src = (const v4f*)a.sk_ws + ((size_t)(sk_r * a.sk_S + pc) * NW + wave) * (TM * TN * 4 * 64) + lane;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const v4f v = __builtin_nontemporal_load(src + ((mi * TN + ni) * 4 + q) * 64);
+                            acc[mi][ni][4 * q] += v.x;
+                            acc[mi][ni][4 * q + 1] += v.y;
+                            acc[mi][ni][4 * q + 2] += v.z;
+                            acc[mi][ni][4 * q + 3] += v.w;
+                        }
+            }
+        }
+    }
+
     // ---- epilogue: transpose through LDS.  No LDS read and no DMA is outstanding after the loop's last barrier. ----
     if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre);
     else if constexpr (EPI != 0) {
@@ -302,6 +377,72 @@ static int launch_dma2(const ConvArgs& a, hipStream_t st) {
     const int grid = cdiv(a.M, BM) * (a.Cout / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
     return launch_status("conv_dma2");
+}
+
+static void tile_shape(int tile, int& bm, int& bn) {
+    static const int shapes[8][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 128}, {128, 64}, {256, 128}, {256, 256}};
+    bm = shapes[tile][0];
+    bn = shapes[tile][1];
+}
+
+// The tiles of a launch are dealt to the 256 CUs in rounds; T mod 256 tiles are left for a last, partly filled round (8 images
+// of 51 x 51 pixels: 326 tiles of 128 x 128 for 256 output channels -- the chip is busy for two rounds and does the work
+// of 1.27).  Those remainder tiles are split along K into as many pieces as keep the piece count <= 256, so that the last
+// round is short instead of partly filled.
+SplitKPlan conv_dma2_splitk_plan(int tile, const ConvArgs& a) {
+    SplitKPlan p = {0, 0, 1, 0};
+    if (tile < 1 || tile > 7 || tile == 3) return p;
+    int bm, bn;
+    tile_shape(tile, bm, bn);
+    const int T = cdiv(a.M, bm) * (a.Cout / bn);
+    const int rem = T % 256;
+    p.full = T;
+    if (rem == 0 || rem > 128) return p;
+    int pieces = 256 / rem;
+    if (pieces > a.nk / 4) pieces = a.nk / 4;
+    if (pieces > 16) pieces = 16;
+    if (pieces < 2) return p;
+    p.full = T - rem;
+    p.split = rem;
+    p.pieces = pieces;
+    p.ws_bytes = 1024 + (size_t)rem * pieces * bm * bn * sizeof(float);     // counters (<= 128 ints), then the partial tiles
+    return p;
+}
+
+template <int BM, int BN, int WGM, int NW>
+static int launch_dma2_sk(const ConvArgs& a, int grid, hipStream_t st) {
+    const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
+    auto kern = a.stats ? (a.bz ? conv_dma2_kernel<BM, BN, WGM, NW, false, 2, true> : conv_dma2_kernel<BM, BN, WGM, NW, false, 1, true>)
+                        : conv_dma2_kernel<BM, BN, WGM, NW, false, 0, true>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    return launch_status("conv_dma2/splitk");
+}
+
+int launch_conv_dma2_splitk(int tile, ConvArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
+    const SplitKPlan p = conv_dma2_splitk_plan(tile, a);
+    if (p.pieces < 2 || a.padv) return launch_conv_dma2(tile, a, st);       // nothing to split: the plain variant
+    if (!ws || ws_bytes < p.ws_bytes || ((uintptr_t)ws & 15)) {
+        set_error("conv split-K: workspace of %zu bytes needed (16-byte aligned), got %zu", p.ws_bytes, ws_bytes);
+        return -1;
+    }
+    a.sk_cnt = (int*)ws;
+    a.sk_ws = (float*)((char*)ws + 1024);
+    a.sk_full = p.full;
+    a.sk_S = p.pieces;
+    const int grid = p.full + p.split * p.pieces;
+    if (tile == 7) return launch_dma2_sk<256, 256, 4, 8>(a, grid, st);
+    if (tile == 6) return launch_dma2_sk<256, 128, 4, 8>(a, grid, st);
+    if (tile == 4) return launch_dma2_sk<128, 128, 4, 8>(a, grid, st);
+    if (tile == 5) return launch_dma2_sk<128, 64, 4, 8>(a, grid, st);
+    if (tile == 1) return launch_dma2_sk<128, 128, 2, 4>(a, grid, st);
+    return launch_dma2_sk<128, 64, 2, 4>(a, grid, st);
 }
 
 // true when the geometry / operands fit this variant (the caller falls back to conv_dma.hip otherwise)

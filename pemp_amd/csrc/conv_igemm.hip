@@ -334,7 +334,7 @@ extern "C" int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x
 }
 
 
-static int conv_stats_common(const char* what, const pemp_conv_desc* d, ConvArgs& a, hipStream_t st) {
+static int conv_stats_fill(const char* what, const pemp_conv_desc* d, ConvArgs& a) {
     PEMP_REQUIRE(!(d->flags & (PEMP_CONV_STEM4 | PEMP_CONV_RELU | PEMP_CONV_SHIFT_PER_IMAGE)), "%s: plain conv only (no stem / ReLU / per-image shift)", what);
     PEMP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0,
                  "%s: bad geometry", what);
@@ -353,30 +353,47 @@ static int conv_stats_common(const char* what, const pemp_conv_desc* d, ConvArgs
     a.ntaps = d->KH * d->KW;
     a.cin_steps = d->Cin / 32;
     a.nk = d->Kpad / 32;
+    a.sk_ws = nullptr; a.sk_cnt = nullptr; a.sk_full = 0; a.sk_S = 1;
     if (!conv_dma2_supported(a)) {
         set_error("%s: geometry / operand size outside the buffer-addressed kernels", what);
         return -2;
     }
-    int t = d->tile == 0 ? 3 : d->tile - 20;
-    PEMP_REQUIRE(t >= 1 && t <= 7, "%s: tile must be 0 or 21..27", what);
+    const int t = d->tile == 0 ? 3 : (d->tile > 30 ? d->tile - 30 : d->tile - 20);
+    PEMP_REQUIRE(t >= 1 && t <= 7 && d->tile != 33, "%s: tile must be 0, 21..27 or 31..37 (no 33)", what);
     PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || a.Cout % 128 == 0, "%s: tile N=128 needs Cout %% 128 == 0", what);
     PEMP_REQUIRE(t != 7 || a.Cout % 256 == 0, "%s: tile 256x256 needs Cout %% 256 == 0", what);
-    return launch_conv_dma2(t, a, st);
+    return 0;
+}
+
+static int conv_stats_common(const char* what, const pemp_conv_desc* d, ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int rc = conv_stats_fill(what, d, a);
+    if (rc) return rc;
+    if (d->tile > 30) return launch_conv_dma2_splitk(d->tile - 30, a, ws, ws_bytes, st);
+    return launch_conv_dma2(d->tile == 0 ? 3 : d->tile - 20, a, st);
+}
+
+extern "C" size_t pemp_conv2d_splitk_workspace_bytes(const pemp_conv_desc* d) {
+    if (!d || d->tile < 31 || d->tile > 37) return 0;
+    ConvArgs a;
+    a.x = a.w = nullptr; a.y = nullptr; a.res = nullptr; a.stats = nullptr;
+    a.bmask = nullptr; a.bz = nullptr; a.bmean = nullptr; a.binvstd = nullptr; a.ldbz = 0;
+    if (conv_stats_fill("conv2d_splitk_workspace_bytes", d, a)) return 0;
+    return conv_dma2_splitk_plan(d->tile - 30, a).ws_bytes;
 }
 
 extern "C" int pemp_conv2d_stats_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,
-                                          void* stream) {
+                                          void* ws, size_t ws_bytes, void* stream) {
     PEMP_REQUIRE(d && x && w && y && stats, "conv2d_stats: null pointer");
     PEMP_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats) & 15) == 0, "conv2d_stats: pointers must be 16-byte aligned");
     ConvArgs a;
     a.x = x; a.w = w; a.y = y; a.res = nullptr; a.stats = stats;
     a.bmask = nullptr; a.bz = nullptr; a.bmean = nullptr; a.binvstd = nullptr; a.ldbz = 0;
-    return conv_stats_common("conv2d_stats", d, a, (hipStream_t)stream);
+    return conv_stats_common("conv2d_stats", d, a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int pemp_conv2d_bnbwd_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* residual,
                                           const uint32_t* mask, const float* z, int ldz, const float* mean, const float* invstd,
-                                          float* stats, void* stream) {
+                                          float* stats, void* ws, size_t ws_bytes, void* stream) {
     PEMP_REQUIRE(d && x && w && y && z && mean && invstd && stats, "conv2d_bnbwd: null pointer");
     PEMP_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats | (uintptr_t)z | (uintptr_t)residual | (uintptr_t)mean |
                    (uintptr_t)invstd) & 15) == 0 && ((uintptr_t)mask & 3) == 0, "conv2d_bnbwd: pointers must be 16-byte aligned");
@@ -384,5 +401,5 @@ extern "C" int pemp_conv2d_bnbwd_nhwc_f32(const pemp_conv_desc* d, const float* 
     ConvArgs a;
     a.x = x; a.w = w; a.y = y; a.res = residual; a.stats = stats;
     a.bmask = mask; a.bz = z; a.bmean = mean; a.binvstd = invstd; a.ldbz = ldz;
-    return conv_stats_common("conv2d_bnbwd", d, a, (hipStream_t)stream);
+    return conv_stats_common("conv2d_bnbwd", d, a, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -460,11 +460,23 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 #endif
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int nsplit,
-                                    int accumulate) {
+// dw = sum over the K-splits of the partial weight gradients, split 0 first (fixed order).  Eight partials are loaded before
+// they are added: the loop is latency-bound otherwise (one L2 / HBM round trip per split).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n,
+                                                           int nsplit, int accumulate) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n / 4; i += (long long)gridDim.x * blockDim.x) {
         float4 s = ((const float4*)ws)[i];
-        for (int k = 1; k < nsplit; ++k) {
+        int k = 1;
+        for (; k + 8 <= nsplit; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ((const float4*)(ws + (size_t)(k + u) * n))[i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+            }
+        }
+        for (; k < nsplit; ++k) {
             const float4 v = ((const float4*)(ws + (size_t)k * n))[i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -570,7 +582,7 @@ extern "C" int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* 
     int e = launch_status("conv_wgrad");
     if (e || direct) return e;
     const long long n = (long long)d->Cout * d->Kpad;
-    int rg = (int)std::min<long long>((n / 4 + 255) / 256, 2048);
+    int rg = (int)std::min<long long>((n / 4 + 255) / 256, 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, st, (const float*)ws, dw, n, a.nsplit, accumulate);
     return launch_status("conv_wgrad/reduce");
 }

@@ -455,6 +455,26 @@ using namespace pemp;
 extern "C" const char* pemp_last_error(void) { return g_err; }
 extern "C" int pemp_abi_version(void) { return PEMP_ABI_VERSION; }
 
+// Device memory that no XCD's L2 caches (MTYPE UC): what one XCD writes, another reads without cache write-back /
+// invalidate -- the split-K convs exchange partial tiles and arrival counters through it.  Zero-filled.
+extern "C" void* pemp_uncached_alloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+    if (e != hipSuccess) {
+        pemp::set_error("pemp_uncached_alloc(%zu): %s", bytes, hipGetErrorString(e));
+        if (p) (void)hipFree(p);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" int pemp_uncached_free(void* p) {
+    const hipError_t e = hipFree(p);
+    if (e != hipSuccess) pemp::set_error("pemp_uncached_free: %s", hipGetErrorString(e));
+    return (int)e;
+}
+
 extern "C" int pemp_pack_input_nhwc4_f32(const float* img, const float* prior, float* out, int N, int H, int W,
                                          void* stream) {
     PEMP_REQUIRE(img && out && N > 0 && H > 0 && W > 0, "pack_input: bad arguments");

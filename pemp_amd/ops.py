@@ -68,6 +68,7 @@ TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15
                  # 2x: the same shapes on conv_dma2.hip (buffer-addressed LDS-DMA, barrier inside the MFMA stream)
                  23: (64, 64), 24: (128, 128), 22: (128, 64), 21: (128, 128), 25: (128, 64), 27: (256, 256), 26: (256, 128)}
 AUTOTUNE = True
+SPLITK = os.environ.get("PEMP_CONV_SPLITK", "1") != "0"     # the training convs may pick the split-K variants (A/B switch)
 DEFAULT_TILE = 13
 _TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared by every ConvParams object
 #: optional JSON file the picks are loaded from / saved to (PEMP_TILE_CACHE=path): a profiling run can then replay a
@@ -82,7 +83,10 @@ def _pick_tile(launch, p, key, cout, only=None):
     """Time the candidate variants for this (layer, input shape) and remember the fastest: two rounds over all
     candidates (the minimum of a variant's two timings counts: a round can be disturbed by whatever else the GPU is
     finishing), then a run-off between the best three with more repetitions."""
-    cands = [t for t, (bm, bn) in TILE_VARIANTS.items() if cout % bn == 0 and (only is None or t in only)]
+    if only is None:
+        cands = [t for t, (bm, bn) in TILE_VARIANTS.items() if cout % bn == 0]
+    else:
+        cands = [t for t in only if cout % TILE_VARIANTS[t - 10 if t > 30 else t][1] == 0]
 
     def timed(t, reps):
         launch(t)                                   # warm
@@ -179,6 +183,38 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
     return out
 
 
+#: split-K variants of the training convs (ids 31..37 = the shapes of 21..27; pemp_hip.h): NOT bit-identical to the others
+SPLITK_TILES = (31, 32, 34, 35, 36, 37)
+_SK_WS = {}      # device index -> (pointer, bytes) of the uncached split-K workspace; the training convs of a device run on one
+                 # stream at a time (main chain), never beside each other
+
+
+def _splitk_ws(lib, desc, device):
+    """-> (pointer, bytes) of this device's uncached workspace (pemp_uncached_alloc), large enough for ``desc``."""
+    need = lib.pemp_conv2d_splitk_workspace_bytes(C.byref(desc))
+    if need == 0:
+        return None, 0
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ptr, size = _SK_WS.get(idx, (None, 0))
+    if size < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the conv split-K workspace must exist before a hipGraph is recorded: run the step eagerly once")
+        torch.cuda.synchronize(device)
+        with torch.cuda.device(device):
+            if ptr:
+                _lib.check(lib.pemp_uncached_free(C.c_void_p(ptr)), "pemp_uncached_free")
+            size = max(need, 72 << 20)            # 256 partial tiles of 256 x 256 floats + counters: every variant fits
+            ptr = lib.pemp_uncached_alloc(size)
+        if not ptr:
+            _lib.check(-1, "pemp_uncached_alloc")
+        _SK_WS[idx] = (ptr, size)
+    return ptr, size
+
+
+def _train_tiles(cout):
+    return [t for t in list(range(21, 28)) + list(SPLITK_TILES) if cout % TILE_VARIANTS[t - 10 if t > 30 else t][1] == 0]
+
+
 def conv2d_stats(x, p, out=None, tile=0):
     """z = conv(x, w) with the per-32-row partial sums of z and z^2 left by the epilogue (pemp_conv2d_stats_nhwc_f32):
     -> (z, partials [ceil(M/32), 2, Cout]).  Raises PempHipError where the buffer-addressed kernels do not apply
@@ -201,15 +237,16 @@ def conv2d_stats(x, p, out=None, tile=0):
 
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, 0, p.kpad, 0, t)
-        _lib.check(lib.pemp_conv2d_stats_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(part), _stream()),
-                   "pemp_conv2d_stats_nhwc_f32")
+        ws, ws_bytes = _splitk_ws(lib, d, x.device) if t > 30 else (None, 0)
+        _lib.check(lib.pemp_conv2d_stats_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(part), C.c_void_p(ws), ws_bytes,
+                                                  _stream()), "pemp_conv2d_stats_nhwc_f32")
 
     if tile == 0:
         key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 2, n, h, w, 0, 0)     # 2: the stats epilogue
         tile = _TILE_CACHE.get(key)
         if tile is None:
             if AUTOTUNE and m >= 1024 and not torch.cuda.is_current_stream_capturing():
-                tile = _pick_tile(launch, p, key, p.cout, only=range(21, 28))
+                tile = _pick_tile(launch, p, key, p.cout, only=_train_tiles(p.cout) if SPLITK else range(21, 28))
             else:
                 tile = DEFAULT_TILE + 10
     launch(tile)
@@ -251,16 +288,17 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
 
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, 0, t)
+        ws, ws_bytes = _splitk_ws(lib, d, x.device) if t > 30 else (None, 0)
         _lib.check(lib.pemp_conv2d_bnbwd_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(residual), _p(mask), _p(z), ldz,
-                                                  _p(bn["mean"]), _p(bn["invstd"]), _p(part), _stream()),
-                   "pemp_conv2d_bnbwd_nhwc_f32")
+                                                  _p(bn["mean"]), _p(bn["invstd"]), _p(part), C.c_void_p(ws), ws_bytes,
+                                                  _stream()), "pemp_conv2d_bnbwd_nhwc_f32")
 
     if tile == 0:
         key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 3, n, h, w, int(residual is not None), 0)   # 3: this epilogue
         tile = _TILE_CACHE.get(key)
         if tile is None:
             if AUTOTUNE and m >= 1024 and not torch.cuda.is_current_stream_capturing():
-                tile = _pick_tile(launch, p, key, p.cout, only=range(21, 28))
+                tile = _pick_tile(launch, p, key, p.cout, only=_train_tiles(p.cout) if SPLITK else range(21, 28))
             else:
                 tile = DEFAULT_TILE + 10
     launch(tile)

@@ -124,6 +124,8 @@ STATS_CASES = [  # N, H, W, Cin, Cout, k, s, p, d
     (3, 26, 26, 256, 512, 1, 2, 0, 1),
     (2, 26, 26, 128, 128, 3, 1, 2, 2),
     (1, 5, 3, 64, 64, 1, 1, 0, 1),          # M = 15 < one row group
+    (8, 51, 51, 256, 256, 3, 1, 2, 2),      # a layer-3 conv of the training step: 326 tiles of 128 x 128 -> 70 split 3 ways
+    (8, 51, 51, 256, 1024, 1, 1, 0, 1),     # 1304 tiles of 128 x 128 -> 24 split into 2 (8 K steps)
 ]
 
 
@@ -155,6 +157,17 @@ def test_conv_with_batch_statistics_in_the_epilogue(hip_lib, dev, case):
         if first is None:
             first = part.clone()
         assert torch.equal(part, first), tile
+    # split-K variants: the remainder tiles add K slices in a different grouping -> fp32 rounding of the regrouped sum
+    # (|d| <= 1e-5 max|z| at K <= 2304); reproducible from launch to launch; the partial sums are those of the stored values
+    for tile in [t for t in ops.SPLITK_TILES if Cout % ops.TILE_VARIANTS[t - 10][1] == 0]:
+        z, part = ops.conv2d_stats(x, prm, tile=tile)
+        assert (z - z_ref).abs().max() <= 1e-5 * z_ref.abs().max(), tile
+        z2, part2 = ops.conv2d_stats(x, prm, tile=tile)
+        assert torch.equal(z, z2) and torch.equal(part, part2), tile
+        zs = torch.cat([z.reshape(M, Cout).double().cpu(), torch.zeros(pad, Cout, dtype=torch.float64)]).view(-1, 32, Cout)
+        pc = part.double().cpu()
+        assert ((pc[:, 0] - zs.sum(1)).abs() <= 1e-6 * zs.abs().sum(1) + 1e-30).all(), tile
+        assert ((pc[:, 1] - (zs * zs).sum(1)).abs() <= 1e-6 * (zs * zs).sum(1) + 1e-30).all(), tile
     rm, rv = _rand(Cout, seed=5), _rand(Cout, seed=6, lo=0.5, hi=1.5)
     rm1, rv1, rm2, rv2 = rm.to(dev), rv.to(dev), rm.to(dev), rv.to(dev)
     mean, invstd = T.bn_stats_partials(first, M, 1e-5, 0.1, rm1, rv1)
@@ -172,6 +185,8 @@ BNBWD_CASES = [  # N, H, W, Cin, Cout, k, p, d, residual, relu
     (2, 26, 26, 128, 512, 1, 0, 1, True, True),       # dgrad of the next block's c1 + residual-branch gradient into bn3
     (2, 26, 26, 256, 256, 3, 2, 2, False, True),      # dilated
     (1, 5, 3, 64, 1024, 1, 0, 1, True, False),        # a BatchNorm without ReLU (no mask); M = 15
+    (8, 51, 51, 256, 256, 3, 2, 2, False, True),      # training shape: remainder tiles split along K
+    (8, 51, 51, 1024, 256, 1, 0, 1, True, True),
 ]
 
 
@@ -221,6 +236,13 @@ def test_input_gradient_conv_with_batchnorm_backward_in_the_epilogue(hip_lib, de
         if first is None:
             first = part.clone()
         assert torch.equal(part, first), tile
+    for tile in [t for t in ops.SPLITK_TILES if Cout % ops.TILE_VARIANTS[t - 10][1] == 0]:      # split-K variants (see above)
+        g, part = ops.conv2d_bnbwd(x, prm, bn, residual=add, tile=tile)
+        assert (g - g_ref).abs().max() <= 1e-5 * dy.abs().max(), tile
+        gs = g.view(M, Cout).double().cpu()
+        pc = part.double().cpu()
+        assert ((pc[:, 0] - zp(gs).sum(1)).abs() <= 1e-6 * zp(gs).abs().sum(1) + 1e-30).all(), tile
+        assert ((pc[:, 1] - zp(gs * xhat).sum(1)).abs() <= 2e-6 * zp(gs * xhat).abs().sum(1) + 1e-30).all(), tile
     dz = torch.empty_like(z)
     dgamma, dbeta = T.bn_bwd_partials(g_ref, z, mean, invstd, gamma, first, dz)
     dz0, gout0 = torch.empty_like(z), torch.empty_like(z)
@@ -237,7 +259,7 @@ def test_conv_with_batch_statistics_refuses_what_it_cannot_run(hip_lib, dev):
     w = torch.zeros(64, 64, 1, 1, device=dev)
     packed, kpad = ops.pack_conv_weight(w)
     prm = ops.ConvParams(packed, None, None, 64, 64, 1, 1, 1, 0, 1, kpad, False, False)
-    with pytest.raises(_lib.PempHipError, match="tile must be 0 or 21..27"):
+    with pytest.raises(_lib.PempHipError, match="tile must be 0, 21..27 or 31..37"):
         ops.conv2d_stats(x, prm, tile=13)
 
 
