@@ -227,6 +227,10 @@ int pemp_cm_bwd_add_arg_f32(const float* mask, const float* dstat, const int32_t
  * bytes (the counters) must be zero on entry and are left zero; not shared by launches that may run concurrently.
  * NULL / 0 for the other tile ids.                                                                                      */
 size_t pemp_conv2d_splitk_workspace_bytes(const pemp_conv_desc* d);
+/* pemp_conv2d_nhwc_f32 with the split-K tile ids (31..37) allowed; other ids behave as there (ws unused).  Training only:
+ * the evaluation path keeps the variants that are bit-identical to each other.                                            */
+int pemp_conv2d_splitk_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale,
+                                const float* shift, const float* residual, void* ws, size_t ws_bytes, void* stream);
 void* pemp_uncached_alloc(size_t bytes);       /* zero-filled; NULL on failure (pemp_last_error) */
 int pemp_uncached_free(void* p);
 int pemp_conv2d_stats_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,

@@ -77,6 +77,7 @@ SYMBOLS = {
     "pemp_channel_scale_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "pemp_cm_bwd_add_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "pemp_conv2d_splitk_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
+    "pemp_conv2d_splitk_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size, c_fp]),
     "pemp_uncached_alloc": (c_fp, [c_size]),
     "pemp_uncached_free": (c_int, [c_fp]),
     "pemp_conv2d_stats_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_size, c_fp]),

@@ -259,9 +259,24 @@ extern "C" int pemp_conv2d_nhwc_f32(const pemp_conv_desc* d, const float* x, con
     return pemp_conv2d_padv_nhwc_f32(d, x, w, y, scale, shift, residual, nullptr, stream);
 }
 
+static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale, const float* shift,
+                       const float* residual, const float* pad_value, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y,
                                          const float* scale, const float* shift, const float* residual,
                                          const float* pad_value, void* stream) {
+    PEMP_REQUIRE(!d || d->tile < 31 || d->tile > 37, "conv2d: the split-K tile ids 31..37 need pemp_conv2d_splitk_nhwc_f32 (workspace)");
+    return conv2d_impl(d, x, w, y, scale, shift, residual, pad_value, nullptr, 0, stream);
+}
+
+extern "C" int pemp_conv2d_splitk_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y,
+                                           const float* scale, const float* shift, const float* residual, void* ws,
+                                           size_t ws_bytes, void* stream) {
+    return conv2d_impl(d, x, w, y, scale, shift, residual, nullptr, ws, ws_bytes, stream);
+}
+
+static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale, const float* shift,
+                       const float* residual, const float* pad_value, void* ws, size_t ws_bytes, void* stream) {
     PEMP_REQUIRE(d && x && w && y, "conv2d: null pointer");
     PEMP_REQUIRE(!pad_value || (!(d->flags & PEMP_CONV_STEM4) && d->KH * d->KW > 1 && ((uintptr_t)pad_value & 15) == 0),
                  "conv2d: pad_value needs a multi-tap non-stem conv and a 16-byte aligned [Cin] vector");
@@ -309,6 +324,17 @@ extern "C" int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x
         tile = 3;
     }
     hipStream_t st = (hipStream_t)stream;
+    a.sk_ws = nullptr; a.sk_cnt = nullptr; a.sk_full = 0; a.sk_S = 1;
+    if (tile >= 31 && tile <= 37) {      // conv_dma2.hip with the last round of tiles split along K (pemp_hip.h)
+        PEMP_REQUIRE(tile != 33, "conv2d: no split-K variant of the 64 x 64 tile");
+        if (conv_dma2_supported(a)) {
+            const int t = tile - 30;
+            PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || a.Cout % 128 == 0, "conv2d: tile N=128 needs Cout %% 128 == 0");
+            PEMP_REQUIRE(t != 7 || a.Cout % 256 == 0, "conv2d: tile 256x256 needs Cout %% 256 == 0");
+            return launch_conv_dma2_splitk(t, a, ws, ws_bytes, st);
+        }
+        tile -= 20;
+    }
     if (tile >= 21 && tile <= 27) {      // conv_dma2.hip: buffer-addressed LDS-DMA + barrier inside the MFMA stream (same tile shapes as 11..17)
         if (conv_dma2_supported(a)) {
             const int t = tile - 20;
@@ -373,11 +399,11 @@ static int conv_stats_common(const char* what, const pemp_conv_desc* d, ConvArgs
 }
 
 extern "C" size_t pemp_conv2d_splitk_workspace_bytes(const pemp_conv_desc* d) {
-    if (!d || d->tile < 31 || d->tile > 37) return 0;
+    if (!d || d->tile < 31 || d->tile > 37 || d->tile == 33 || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 || d->Kpad < 32) return 0;
     ConvArgs a;
-    a.x = a.w = nullptr; a.y = nullptr; a.res = nullptr; a.stats = nullptr;
-    a.bmask = nullptr; a.bz = nullptr; a.bmean = nullptr; a.binvstd = nullptr; a.ldbz = 0;
-    if (conv_stats_fill("conv2d_splitk_workspace_bytes", d, a)) return 0;
+    a.M = d->N * d->Ho * d->Wo;
+    a.Cout = d->Cout;
+    a.nk = d->Kpad / 32;
     return conv_dma2_splitk_plan(d->tile - 30, a).ws_bytes;
 }
 

@@ -129,9 +129,10 @@ def pack_conv_weight(w_oihw, stem4=False):
 
 
 def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=False, relu=None, tile=0,
-           pad_value=None):
+           pad_value=None, splitk=False):
     """y = act(scale * conv(x, w) + shift (+ residual)).  x: NHWC view, returns NHWC tensor/view ``out``.
-    ``pad_value`` [Cin]: what out-of-image taps read instead of zero (multi-tap convs; see fold_input_affine)."""
+    ``pad_value`` [Cin]: what out-of-image taps read instead of zero (multi-tap convs; see fold_input_affine).
+    ``splitk``: the autotuner may also pick the split-K variants (training path: they are not bit-identical to the rest)."""
     lib = _lib.load()
     _chk_dev(x, p.w, out, residual)
     ldx = _nhwc(x, "x")
@@ -162,9 +163,15 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
         flags |= CONV_SHIFT_PER_IMAGE
     if p.stem:
         flags |= CONV_STEM4
+    splitk = splitk and SPLITK and pad_value is None and not p.stem
+
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, flags, t)
-        if pad_value is None:
+        if t > 30:
+            ws, ws_bytes = _splitk_ws(lib, d, x.device)
+            _lib.check(lib.pemp_conv2d_splitk_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift), _p(residual),
+                                                       C.c_void_p(ws), ws_bytes, _stream()), "pemp_conv2d_splitk_nhwc_f32")
+        elif pad_value is None:
             _lib.check(lib.pemp_conv2d_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift),
                                                 _p(residual), _stream()), "pemp_conv2d_nhwc_f32")
         else:
@@ -172,11 +179,12 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
                                                      _p(residual), _p(pad_value), _stream()), "pemp_conv2d_padv_nhwc_f32")
 
     if tile == 0:
-        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, p.stem, n, h, w, int(residual is not None), int(pad_value is not None))
+        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 4 if splitk else int(p.stem), n, h, w, int(residual is not None),
+               int(pad_value is not None))
         tile = _TILE_CACHE.get(key)
         if tile is None:
             if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():
-                tile = _pick_tile(launch, p, key, p.cout)
+                tile = _pick_tile(launch, p, key, p.cout, only=list(TILE_VARIANTS) + list(SPLITK_TILES) if splitk else None)
             else:
                 tile = DEFAULT_TILE
     launch(tile)

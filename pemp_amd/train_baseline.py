@@ -7,7 +7,7 @@ pooling over bilinearly up-sampled features, done through its adjoint) differ.
 import torch
 
 from . import ops, train_ops as T
-from .train_engine import Stage1TrainEngine, Stage1Trainer, _Conv
+from .train_engine import Stage1TrainEngine, Stage1Trainer, _Conv, conv2d
 
 
 class _ResNetProjectionEngine(Stage1TrainEngine):
@@ -18,14 +18,14 @@ class _ResNetProjectionEngine(Stage1TrainEngine):
 
     def _tail_forward(self, x, tape):
         tape["proj_in"] = x
-        return ops.conv2d(x, self.proj.fwd_params(relu=False))
+        return conv2d(x, self.proj.fwd_params(relu=False))
 
-    def _tail_backward(self, dfeat):
+    def _tail_backward(self, dfeat, up=None):
         x = self.tape["proj_in"]
         g = torch.empty_like(dfeat)
         self.proj.conv.bias.grad.copy_(T.relu_bias_bwd(dfeat, None, g, relu=False, ws_cache=self.ws))
         self.proj.wgrad(x, g, self.ws)
-        return ops.conv2d(g, self.proj.dgrad_params())
+        return conv2d(g, self.proj.dgrad_params())
 
 
 class _VGGEngine(Stage1TrainEngine):
@@ -49,7 +49,7 @@ class _VGGEngine(Stage1TrainEngine):
         recs = []
         for kind, obj, relu in self.steps:
             if kind == "conv":
-                y = ops.conv2d(x, obj.fwd_params(relu=relu))
+                y = conv2d(x, obj.fwd_params(relu=relu))
                 recs.append((kind, obj, relu, x, y))
             else:
                 y, idx = T.maxpool_idx(x.contiguous(), 3, obj, 1)
@@ -61,7 +61,7 @@ class _VGGEngine(Stage1TrainEngine):
     def _tail_forward(self, x, tape):
         return x
 
-    def _tail_backward(self, dfeat):
+    def _tail_backward(self, dfeat, up=None):
         return dfeat
 
     def _trunk_backward(self, dx):
@@ -73,7 +73,7 @@ class _VGGEngine(Stage1TrainEngine):
             g = torch.empty_like(y)
             obj.conv.bias.grad.copy_(T.relu_bias_bwd(dx, y, g, relu=relu, ws_cache=self.ws))
             obj.wgrad(x, g, self.ws)
-            dx = ops.conv2d(g, obj.dgrad_params()) if not obj.stem else None
+            dx = conv2d(g, obj.dgrad_params()) if not obj.stem else None
 
 
 class BaselineTrainer(Stage1Trainer):

@@ -27,6 +27,12 @@ import torch.nn as nn
 from . import ops, train_ops as T
 from .ops import ConvParams
 
+
+def conv2d(x, p, **kw):
+    """ops.conv2d for the training step: the autotuner may also pick the split-K variants (not bit-identical to the
+    others, which the evaluation path relies on)."""
+    return ops.conv2d(x, p, splitk=True, **kw)
+
 BN_MOM = 0.1
 FUSE_BN_STATS = os.environ.get("PEMP_FUSE_BN_STATS", "1") != "0"   # conv epilogue starts the batch statistics (A/B switch)
 FUSE_BN_BWD = os.environ.get("PEMP_FUSE_BN_BWD", "1") != "0"       # input-gradient epilogue starts the BatchNorm backward
@@ -373,7 +379,7 @@ class Stage1TrainEngine:
             z, part = ops.conv2d_stats(x, prm)         # batch statistics started in the conv epilogue
             mean, invstd = bn.stats_from(part, z.shape[0] * z.shape[1] * z.shape[2])
         else:
-            z = ops.conv2d(x, prm) if img_bias is None else ops.conv2d(x, prm, shift_override=img_bias, per_image_shift=True)
+            z = conv2d(x, prm) if img_bias is None else conv2d(x, prm, shift_override=img_bias, per_image_shift=True)
             mean, invstd = bn.stats(z, self.ws)
         mask = None
         if FUSE_BN_BWD and relu and T.mask_supported(z.shape[-1]):       # sign bits of y: what the backward needs of it
@@ -405,7 +411,7 @@ class Stage1TrainEngine:
                 and ops.stats_supported(dz, prm)):
             dx, up["gpart"] = ops.conv2d_bnbwd(dz, prm, up, residual=add_to)
         else:
-            dx = ops.conv2d(dz, prm, residual=add_to)
+            dx = conv2d(dz, prm, residual=add_to)
         return dx, gout
 
     def _block_fwd(self, x, b, bias_c1=None, bias_ds=None):
@@ -451,7 +457,7 @@ class Stage1TrainEngine:
         if self.flat.side_stream is not None and not recording:      # the side stream must not start before this step's gradients were zeroed
             torch.cuda.current_stream().wait_stream(self.flat.side_stream)     # the dgrad weight mirror is in place
             self.flat.side_stream.wait_stream(torch.cuda.current_stream())
-        dx = self._tail_backward(dfeat)
+        dx = self._tail_backward(dfeat, up=self.tape["blocks"][-1]["r3"] if self.tape.get("blocks") else None)
         self.flat.cut()                            # segment 0: forward + head + purifier / ASPP backward
         if self.tail_off:
             self.buckets.ready_from(self.tail_off)       # purifier / ASPP gradients are final: all-reduce under layer3's backward
@@ -482,9 +488,9 @@ class Stage1TrainEngine:
     def _tail_forward(self, x, tape):
         # purifier: conv+bias+ReLU (+DropBlock) twice
         nimg, h, w, _ = x.shape
-        ya = ops.conv2d(x, self.p0.fwd_params(relu=True))
+        ya = conv2d(x, self.p0.fwd_params(relu=True))
         xa, da = self._dropblock(ya, nimg, h, w)
-        yb = ops.conv2d(xa, self.p3.fwd_params(relu=True))
+        yb = conv2d(xa, self.p3.fwd_params(relu=True))
         xb, db = self._dropblock(yb, nimg, h, w)
         tape.update(p0_in=x, ya=ya, da=da, xa=xa, yb=yb, db=db, xb=xb)
         # ASPPV2: five BNs share the statistics of xb (branch 0: of its global average)
@@ -493,11 +499,11 @@ class Stage1TrainEngine:
         m0, i0 = self.aspp_bn[0].stats(gap, self.ws)
         t0 = T.bn_apply(gap, m0, i0, self.aspp_bn[0].bn.weight.data, self.aspp_bn[0].bn.bias.data, torch.empty_like(gap), relu=False)
         t0d, d0 = self._dropblock(t0, nimg, 1, 1)
-        g0 = ops.conv2d(t0d.view(nimg, 1, 1, -1), self.aspp_conv[0].fwd_params(relu=True))
+        g0 = conv2d(t0d.view(nimg, 1, 1, -1), self.aspp_conv[0].fwd_params(relu=True))
         l6w = self.l6.weight
         w6 = self.flat.krsc(l6w)                                   # [512, 1280]
         w6g = ConvParams(w6[:, :midc].contiguous(), None, self.l6.bias.data, midc, l6w.shape[0], 1, 1, 1, 0, 1, midc, False, False)
-        bias6 = ops.conv2d(g0, w6g)
+        bias6 = conv2d(g0, w6g)
         cat = self._new(nimg, h, w, 4 * midc)
         ts, ds_ = [], []
         mean_x = invstd_x = None
@@ -508,17 +514,19 @@ class Stage1TrainEngine:
             mean_x, invstd_x = bn.stats(xb, self.ws)
             t = T.bn_apply(xb, mean_x, invstd_x, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(xb), relu=False)
             td, d = self._dropblock(t, nimg, h, w)
-            ops.conv2d(td, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
+            conv2d(td, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
             ts.append(td)
             ds_.append(d)
         w6m = ConvParams(w6[:, midc:].contiguous(), None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False)
-        feat = ops.conv2d(cat, w6m, shift_override=bias6.view(nimg, -1), per_image_shift=True)
+        feat = conv2d(cat, w6m, shift_override=bias6.view(nimg, -1), per_image_shift=True)
         tape.update(gap=gap, m0=m0, i0=i0, t0d=t0d, d0=d0, g0=g0, cat=cat, ts=ts, ds=ds_, mean_x=mean_x, invstd_x=invstd_x,
                     w6=w6, hw=(nimg, h, w))
         return feat
 
     # -- backward -----------------------------------------------------------------------------
-    def _tail_backward(self, dfeat):
+    def _tail_backward(self, dfeat, up=None):
+        """``up``: tape record of the last residual block's bn3 (the BatchNorm + ReLU whose output the tail consumes): the
+        purifier's input-gradient conv then starts that BatchNorm's backward in its epilogue (see _cbn_bwd)."""
         tp, midc = self.tape, self.midc
         nimg, h, w = tp["hw"]
         hw = h * w
@@ -530,7 +538,7 @@ class Stage1TrainEngine:
         T.conv_wgrad(tp["cat"], dfeat, ConvParams(None, None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False),
                      dw6m, ws_cache=self.ws)
         dw6[:, midc:].copy_(dw6m)
-        dcat = ops.conv2d(dfeat, ConvParams(T.dgrad_weight(w6[:, midc:].contiguous(), 1, 1), None, None, l6w.shape[0], 4 * midc,
+        dcat = conv2d(dfeat, ConvParams(T.dgrad_weight(w6[:, midc:].contiguous(), 1, 1), None, None, l6w.shape[0], 4 * midc,
                                             1, 1, 1, 0, 1, l6w.shape[0], False, False))
         s = ops.global_avgpool(dfeat) * float(hw)                   # per-image column sums [N, 512]
         self.l6.bias.grad.copy_(s.sum(dim=0))
@@ -538,7 +546,7 @@ class Stage1TrainEngine:
         T.conv_wgrad(tp["g0"], s.view(nimg, 1, 1, -1), ConvParams(None, None, None, midc, l6w.shape[0], 1, 1, 1, 0, 1, midc, False, False),
                      dw6g, ws_cache=self.ws)
         dw6[:, :midc].copy_(dw6g)
-        dg0 = ops.conv2d(s.view(nimg, 1, 1, -1), ConvParams(T.dgrad_weight(w6[:, :midc].contiguous(), 1, 1), None, None, l6w.shape[0],
+        dg0 = conv2d(s.view(nimg, 1, 1, -1), ConvParams(T.dgrad_weight(w6[:, :midc].contiguous(), 1, 1), None, None, l6w.shape[0],
                                                             midc, 1, 1, 1, 0, 1, l6w.shape[0], False, False))
         # branches 1..4
         dxb = None
@@ -549,7 +557,7 @@ class Stage1TrainEngine:
             db = T.relu_bias_bwd(dcat[..., (i - 1) * midc:i * midc], u, g, relu=True, ws_cache=self.ws)
             conv.conv.bias.grad.copy_(db)
             conv.wgrad(tp["ts"][i - 1], g, self.ws)
-            dt = ops.conv2d(g, conv.dgrad_params())
+            dt = conv2d(g, conv.dgrad_params())
             dt = self._dropblock_bwd(dt, tp["ds"][i - 1])
             dz = self._new(nimg, h, w, dt.shape[-1])
             dgamma, dbeta = T.bn_bwd(dt, None, tp["xb"], tp["mean_x"], tp["invstd_x"], bn.bn.weight.data, dz, relu=False, ws_cache=self.ws)
@@ -564,7 +572,7 @@ class Stage1TrainEngine:
         db = T.relu_bias_bwd(dg0, tp["g0"], g, relu=True, ws_cache=self.ws)
         conv0.conv.bias.grad.copy_(db)
         conv0.wgrad(tp["t0d"].view(nimg, 1, 1, -1), g, self.ws)
-        dt0 = ops.conv2d(g, conv0.dgrad_params()).view(nimg, -1)
+        dt0 = conv2d(g, conv0.dgrad_params()).view(nimg, -1)
         dt0 = self._dropblock_bwd(dt0, tp["d0"])
         dgap = self._new(nimg, dt0.shape[1])
         dgamma, dbeta = T.bn_bwd(dt0, None, tp["gap"], tp["m0"], tp["i0"], bn0.bn.weight.data, dgap, relu=False, ws_cache=self.ws)
@@ -575,12 +583,16 @@ class Stage1TrainEngine:
         g = torch.empty_like(tp["yb"])
         self.p3.conv.bias.grad.copy_(T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws))
         self.p3.wgrad(tp["xa"], g, self.ws)
-        dxa = ops.conv2d(g, self.p3.dgrad_params())
+        dxa = conv2d(g, self.p3.dgrad_params())
         dxa = self._dropblock_bwd(dxa, tp["da"])
         g = torch.empty_like(tp["ya"])
         self.p0.conv.bias.grad.copy_(T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws))
         self.p0.wgrad(tp["p0_in"], g, self.ws)
-        return ops.conv2d(g, self.p0.dgrad_params())
+        prm = self.p0.dgrad_params()
+        if up is not None and FUSE_BN_BWD and up["mask"] is not None and prm.shift is None and ops.stats_supported(g, prm):
+            dx, up["gpart"] = ops.conv2d_bnbwd(g, prm, up)
+            return dx
+        return conv2d(g, prm)
 
     def _trunk_backward(self, dx):
         tp = self.tape

@@ -21,7 +21,7 @@ import torch
 
 from . import ops, train_ops as T
 from .ops import ConvParams
-from .train_engine import Stage1TrainEngine, Stage1Trainer, _BN, _Conv
+from .train_engine import Stage1TrainEngine, Stage1Trainer, _BN, _Conv, conv2d
 
 _CM_STRIDES = (2, 1, 2)          # backbones.py:230,235,240
 
@@ -154,28 +154,28 @@ class Stage2TrainEngine(Stage1TrainEngine):
     def _tail_forward(self, x, tape):
         nimg, h, w, _ = x.shape
         midc = self.midc
-        ya = ops.conv2d(x, self.p0.fwd_params(relu=True))
+        ya = conv2d(x, self.p0.fwd_params(relu=True))
         xa, ma = self._drop(ya, nimg, ya.shape[-1])
-        yb = ops.conv2d(xa, self.p3.fwd_params(relu=True))
+        yb = conv2d(xa, self.p3.fwd_params(relu=True))
         xb, mb = self._drop(yb, nimg, yb.shape[-1])
         gap = ops.global_avgpool(xb)
-        g0 = ops.conv2d(gap.view(nimg, 1, 1, -1), self.aspp_conv[0].fwd_params(relu=True))
+        g0 = conv2d(gap.view(nimg, 1, 1, -1), self.aspp_conv[0].fwd_params(relu=True))
         g0d, m0 = self._drop(g0, nimg, midc)
         l6w = self.l6.weight
         w6 = self.flat.krsc(l6w)                                              # [512, 1280]
         w6g = ConvParams(w6[:, :midc].contiguous(), None, self.l6.bias.data, midc, l6w.shape[0], 1, 1, 1, 0, 1, midc, False, False)
-        bias6 = ops.conv2d(g0d, w6g)
+        bias6 = conv2d(g0d, w6g)
         cat = self._new(nimg, h, w, 4 * midc)                                 # post-ReLU branch outputs u_i
         for i in range(1, 5):
-            ops.conv2d(xb, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
+            conv2d(xb, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
         catd, ms = self._drop(cat, nimg, 4 * midc)                            # the four branch Dropout2d layers at once
         w6m = ConvParams(w6[:, midc:].contiguous(), None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False)
-        feat = ops.conv2d(catd, w6m, shift_override=bias6.view(nimg, -1), per_image_shift=True)
+        feat = conv2d(catd, w6m, shift_override=bias6.view(nimg, -1), per_image_shift=True)
         tape.update(p0_in=x, ya=ya, ma=ma, xa=xa, yb=yb, mb=mb, xb=xb, gap=gap, g0=g0, m0=m0, g0d=g0d, cat=cat, catd=catd,
                     ms=ms, w6=w6, hw=(nimg, h, w))
         return feat
 
-    def _tail_backward(self, dfeat):
+    def _tail_backward(self, dfeat, up=None):
         tp, midc = self.tape, self.midc
         nimg, h, w = tp["hw"]
         l6w = self.l6.weight
@@ -186,7 +186,7 @@ class Stage2TrainEngine(Stage1TrainEngine):
         T.conv_wgrad(tp["catd"], dfeat, ConvParams(None, None, None, 4 * midc, cout, 1, 1, 1, 0, 1, 4 * midc, False, False),
                      dw6m, ws_cache=self.ws)
         dw6[:, midc:].copy_(dw6m)
-        dcat = ops.conv2d(dfeat, ConvParams(T.dgrad_weight(w6[:, midc:].contiguous(), 1, 1), None, None, cout, 4 * midc,
+        dcat = conv2d(dfeat, ConvParams(T.dgrad_weight(w6[:, midc:].contiguous(), 1, 1), None, None, cout, 4 * midc,
                                             1, 1, 1, 0, 1, cout, False, False))
         s = ops.global_avgpool(dfeat) * float(h * w)                          # per-image column sums [N, 512]
         self.l6.bias.grad.copy_(s.sum(dim=0))
@@ -194,7 +194,7 @@ class Stage2TrainEngine(Stage1TrainEngine):
         T.conv_wgrad(tp["g0d"], s.view(nimg, 1, 1, -1), ConvParams(None, None, None, midc, cout, 1, 1, 1, 0, 1, midc, False, False),
                      dw6g, ws_cache=self.ws)
         dw6[:, :midc].copy_(dw6g)
-        dg0 = ops.conv2d(s.view(nimg, 1, 1, -1), ConvParams(T.dgrad_weight(w6[:, :midc].contiguous(), 1, 1), None, None, cout,
+        dg0 = conv2d(s.view(nimg, 1, 1, -1), ConvParams(T.dgrad_weight(w6[:, :midc].contiguous(), 1, 1), None, None, cout,
                                                             midc, 1, 1, 1, 0, 1, cout, False, False))
         dcat = self._drop_bwd(dcat, tp["ms"])
         dxb = None
@@ -204,23 +204,23 @@ class Stage2TrainEngine(Stage1TrainEngine):
             sl = slice((i - 1) * midc, i * midc)
             conv.conv.bias.grad.copy_(T.relu_bias_bwd(dcat[..., sl], tp["cat"][..., sl], g, relu=True, ws_cache=self.ws))
             conv.wgrad(tp["xb"], g, self.ws)
-            dxb = ops.conv2d(g, conv.dgrad_params(), residual=dxb)            # branch gradients accumulate in the epilogue
+            dxb = conv2d(g, conv.dgrad_params(), residual=dxb)            # branch gradients accumulate in the epilogue
         conv0 = self.aspp_conv[0]
         dg0 = self._drop_bwd(dg0, tp["m0"])
         g = self._new(nimg, 1, 1, midc)
         conv0.conv.bias.grad.copy_(T.relu_bias_bwd(dg0, tp["g0"], g, relu=True, ws_cache=self.ws))
         conv0.wgrad(tp["gap"].view(nimg, 1, 1, -1), g, self.ws)
-        T.gap_bwd_add(ops.conv2d(g, conv0.dgrad_params()).view(nimg, -1), dxb)
+        T.gap_bwd_add(conv2d(g, conv0.dgrad_params()).view(nimg, -1), dxb)
         dxb = self._drop_bwd(dxb, tp["mb"])
         g = torch.empty_like(tp["yb"])
         self.p3.conv.bias.grad.copy_(T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws))
         self.p3.wgrad(tp["xa"], g, self.ws)
-        dxa = ops.conv2d(g, self.p3.dgrad_params())
+        dxa = conv2d(g, self.p3.dgrad_params())
         dxa = self._drop_bwd(dxa, tp["ma"])
         g = torch.empty_like(tp["ya"])
         self.p0.conv.bias.grad.copy_(T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws))
         self.p0.wgrad(tp["p0_in"], g, self.ws)
-        return ops.conv2d(g, self.p0.dgrad_params())
+        return conv2d(g, self.p0.dgrad_params())
 
 
 class Stage2Trainer(Stage1Trainer):

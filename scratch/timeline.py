@@ -37,5 +37,21 @@ for q, rs in queues.items():
 rec = {"window_ms_per_step": round((t1 - t0) / steps / 1e6, 3), "busy_ms_per_step": round(busy / steps / 1e6, 3),
        "idle_ms_per_step": round((t1 - t0 - busy) / steps / 1e6, 3), "two_or_more_kernels_ms_per_step": round(multi / steps / 1e6, 3),
        "queues": qs}
+# the largest idle intervals (no kernel on any queue) of the last step, with the kernels either side
+last = [r for r in rows if is_gemm(r["Kernel_Name"])][-per_step:]
+tl0 = int(last[0]["Start_Timestamp"])
+lastrows = [r for r in rows if int(r["Start_Timestamp"]) >= tl0 - 3_000_000]
+lastrows.sort(key=lambda r: int(r["Start_Timestamp"]))
+gaps = []
+end = int(lastrows[0]["End_Timestamp"]); prev = lastrows[0]
+for r in lastrows[1:]:
+    st = int(r["Start_Timestamp"])
+    if st > end:
+        gaps.append((st - end, prev["Kernel_Name"].split("(")[0][:70], r["Kernel_Name"][:110]))
+    if int(r["End_Timestamp"]) > end:
+        end = int(r["End_Timestamp"]); prev = r
+gaps.sort(reverse=True)
+rec["largest_idle_intervals_us_last_step"] = [(round(g / 1e3, 1), a, b) for g, a, b in gaps[:25]]
+rec["idle_total_us_last_window"] = round(sum(g for g, _, _ in gaps) / 1e3, 1)
 json.dump(rec, open(out, "w"), indent=1)
 print(json.dumps(rec, indent=1))
