@@ -185,6 +185,7 @@ CLASS_OF = {
     "pemp_conv2d_nhwc_f32": "conv", "pemp_conv2d_padv_nhwc_f32": "conv", "pemp_conv2d_wgrad_nhwc_f32": "wgrad",
     "pemp_conv2d_stats_nhwc_f32": "conv", "pemp_bn_stats_partials_f32": "batchnorm", "pemp_conv2d_splitk_nhwc_f32": "conv",
     "pemp_conv2d_bnbwd_nhwc_f32": "conv", "pemp_bn_bwd_partials_f32": "batchnorm", "pemp_bn_apply_mask_f32": "batchnorm",
+    "pemp_bn_fwd_partials_f32": "batchnorm", "pemp_bn_bwd_mask_f32": "batchnorm",
     "pemp_bn_stats_f32": "batchnorm", "pemp_bn_apply_f32": "batchnorm", "pemp_bn_bwd_f32": "batchnorm",
     "pemp_relu_bias_bwd_f32": "batchnorm",
     "pemp_mpm_protos_f32": "head", "pemp_masked_avg_pool_f32": "head", "pemp_cosine_proto_max_f32": "head",

@@ -211,9 +211,11 @@ int pemp_cm_bwd_add_arg_f32(const float* mask, const float* dstat, const int32_t
 /* The conv in front of a train-mode BatchNorm with the BatchNorm's batch statistics started in its epilogue
  * (networks/backbones.py:48-52,66-75 with the model in train(), core/base_trainer.py:189): y = conv(x, w) (no affine,
  * no residual, no ReLU) and, for every group of 32 consecutive output rows r, the per-channel partial sums
- *   stats[r][0][c] = sum y[m][c],  stats[r][1][c] = sum y[m][c]^2        (m in rows 32 r .. 32 r + 31, m < M)
- * i.e. ceil(M/32) x 2 x Cout floats.  pemp_bn_stats_partials_f32 adds them in a fixed order (double) into mean /
- * 1/sqrt(var+eps) and the running-statistics update: the separate pass over y that pemp_bn_stats_f32 makes is gone.
+ *   stats[r][0][c] = sum y[m][c],  stats[r][1][c] = sum y[m][c]^2        (m in the rows of row tile r, m < M)
+ * i.e. pemp_conv2d_stats_rows(d) x 2 x Cout floats (one row per row tile of the chosen variant: ceil(M / 64 .. 256)).
+ * pemp_bn_stats_partials_f32 adds them in a fixed order (double) into mean / 1/sqrt(var+eps) and the running-statistics
+ * update: the separate pass over y that pemp_bn_stats_f32 makes is gone.  pemp_bn_fwd_partials_f32 = that followed by the
+ * normalisation (pemp_bn_apply_mask_f32), one call for the pair.
  * Deterministic.  Non-stem convs whose operands lie below 2 GiB (the buffer-addressed kernels); returns
  * -2 where that does not hold (use pemp_conv2d_nhwc_f32 + pemp_bn_stats_f32 then).  d->tile: 0 or 21..27, or 31..37
  * (not 33) = the same tile shapes with the LAST, partly filled round of tiles split along K (8 images of 51 x 51 pixels
@@ -235,13 +237,18 @@ void* pemp_uncached_alloc(size_t bytes);       /* zero-filled; NULL on failure (
 int pemp_uncached_free(void* p);
 int pemp_conv2d_stats_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,
                                void* ws, size_t ws_bytes, void* stream);
-int pemp_bn_stats_partials_f32(const float* stats, int M, int C, float eps, float momentum, float* mean,
+int pemp_conv2d_stats_rows(const pemp_conv_desc* d);
+int pemp_bn_stats_partials_f32(const float* stats, int nrows, int M, int C, float eps, float momentum, float* mean,
                                float* invstd, float* run_mean, float* run_var, void* stream);
+int pemp_bn_fwd_partials_f32(const float* z, int ldz, const float* stats, int nrows, int M, int C, float eps, float momentum,
+                             const float* gamma, const float* beta, const float* residual, int ldr, float* y, int ldy,
+                             int relu, uint32_t* mask, float* mean, float* invstd, float* run_mean, float* run_var,
+                             void* stream);
 
 /* The input-gradient conv whose result is the gradient at the OUTPUT of a train-mode BatchNorm(+ReLU) (autograd of
  * BottleNeck.forward, networks/backbones.py:66-75: conv -> bn -> relu chains), with the first half of that BatchNorm's
  * backward in its epilogue:  o = conv(x, w) (+ residual);  g = o where the BatchNorm's ReLU let the value through
- * (bit c % 32 of mask[m][c / 32], from pemp_bn_apply_mask_f32; mask NULL: no ReLU, g = o);  y = g;  and per 32-row group
+ * (bit c % 32 of mask[m][c / 32], from pemp_bn_apply_mask_f32; mask NULL: no ReLU, g = o);  y = g;  and per row tile
  *   stats[r][0][c] = sum g[m][c],   stats[r][1][c] = sum g[m][c] * (z[m][c] - mean[c]) * invstd[c]
  * (z: the BatchNorm's input, d->Cout channels, per-pixel stride ldz).  pemp_bn_bwd_partials_f32 finishes: dbeta / dgamma
  * from the partials (fixed order, double) and dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M): the separate reduction pass
@@ -252,12 +259,14 @@ int pemp_conv2d_bnbwd_nhwc_f32(const pemp_conv_desc* d, const float* x, const fl
                                const uint32_t* mask, const float* z, int ldz, const float* mean, const float* invstd,
                                float* stats, void* ws, size_t ws_bytes, void* stream);
 int pemp_bn_bwd_partials_f32(const float* g, int ldg, const float* z, int ldz, const float* mean, const float* invstd,
-                             const float* gamma, const float* stats, float* dz, int lddz, float* dgamma, float* dbeta,
-                             int M, int C, void* stream);
+                             const float* gamma, const float* stats, int nrows, float* dz, int lddz, float* dgamma,
+                             float* dbeta, int M, int C, void* stream);
 
 /* Weight gradient of pemp_conv2d_nhwc_f32 (autograd of nn.Conv2d, same call sites):
  *   dw[co][kh][kw][ci] (+)= sum_m g[m][co] * x[pix(m,kh,kw)][ci]      dw is KRSC with row length d->Kpad
- * `d` describes the FORWARD conv (d->ldy = per-pixel stride of g).  STEM4 needs Kpad % 64 == 0. */
+ * `d` describes the FORWARD conv (d->ldy = per-pixel stride of g).  STEM4 needs Kpad % 64 == 0.  d->tile: bits 0..7 = kernel generation
+ * (0: library's choice, 1: first generation), bits 8.. = number of blocks to aim for when the pixel rows are split over
+ * blocks (0: 768; the partial sums of different splits round differently -- same value for workspace query and launch). */
 size_t pemp_conv2d_wgrad_workspace_bytes(const pemp_conv_desc* d);
 int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* g, float* dw,
                                int accumulate, void* ws, size_t ws_bytes, void* stream);
@@ -280,6 +289,11 @@ int pemp_bn_apply_mask_f32(const float* z, int ldz, const float* mean, const flo
 /* backward of the above: g = dy*(y>0 if relu) [optionally stored to gout = gradient of the residual
  * branch]; dgamma = sum g*xhat, dbeta = sum g, dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).     */
 int pemp_bn_bwd_f32(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,
+                    const float* mean, const float* invstd, const float* gamma,
+                    float* dz, int lddz, float* gout, int ldg, float* dgamma, float* dbeta,
+                    int M, int C, int relu, void* ws, size_t ws_bytes, void* stream);
+/* The same with the sign bits of y (pemp_bn_apply_mask_f32) standing in for y where mask is given: y is then not read. */
+int pemp_bn_bwd_mask_f32(const float* dy, int lddy, const float* y, int ldy, const uint32_t* mask, const float* z, int ldz,
                     const float* mean, const float* invstd, const float* gamma,
                     float* dz, int lddz, float* gout, int ldg, float* dgamma, float* dbeta,
                     int M, int C, int relu, void* ws, size_t ws_bytes, void* stream);

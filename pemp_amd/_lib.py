@@ -81,11 +81,14 @@ SYMBOLS = {
     "pemp_uncached_alloc": (c_fp, [c_size]),
     "pemp_uncached_free": (c_int, [c_fp]),
     "pemp_conv2d_stats_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_size, c_fp]),
-    "pemp_bn_stats_partials_f32": (c_int, [c_fp, c_int, c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "pemp_conv2d_stats_rows": (c_int, [C.POINTER(ConvDesc)]),
+    "pemp_bn_stats_partials_f32": (c_int, [c_fp, c_int, c_int, c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "pemp_bn_fwd_partials_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_int,
+                                         c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "pemp_conv2d_bnbwd_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp,
                                            c_size, c_fp]),
-    "pemp_bn_bwd_partials_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_int,
-                                         c_fp]),
+    "pemp_bn_bwd_partials_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int,
+                                         c_int, c_fp]),
     "pemp_bn_apply_mask_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int,
                                        c_int, c_fp, c_fp]),
     "pemp_conv2d_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),
@@ -97,6 +100,8 @@ SYMBOLS = {
                                   c_int, c_fp]),
     "pemp_bn_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int,
                                 c_fp, c_fp, c_int, c_int, c_int, c_fp, c_size, c_fp]),
+    "pemp_bn_bwd_mask_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int,
+                                     c_fp, c_fp, c_int, c_int, c_int, c_fp, c_size, c_fp]),
     "pemp_relu_bias_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int,
                                        c_int, c_fp, c_size, c_fp]),
     "pemp_maxpool2d_bwd_nhwc_f32": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp]),

@@ -15,7 +15,7 @@ struct ConvArgs {
     const float* shift;
     const float* res;
     const float* padv;      // per-input-channel value of out-of-image taps (NULL: zero padding)
-    float* stats;           // [ceil(M/32)][2][Cout] per-32-row partial sums (NULL: none; conv_dma2.hip only): of y and y^2, or,
+    float* stats;           // [ceil(M/BM)][2][Cout] per-row-tile partial sums (NULL: none; conv_dma2.hip only): of y and y^2, or,
                             // with bz set, of g and g*xhat (BatchNorm backward; see pemp_conv2d_bnbwd_nhwc_f32)
     const uint32_t* bmask;  // sign bits of the BatchNorm's output (NULL: no ReLU)
     const float* bz;        // the BatchNorm's input, per-pixel stride ldbz
@@ -51,13 +51,14 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int nblk) {
 // ``pre`` (optional): the residual quads of the wave's tiles, loaded by the caller ahead of time in the order
 // [mi][ni][i] (row = (lane >> 3) + 8 i of tile (mi, ni), channels (lane & 7) * 4 ..) -- conv_dma2.hip issues those loads
 // under its last K step so that their latency is not exposed here.
-// EPI 1: per-channel sums of the stored values and of their squares over each 32-row tile, written to a.stats (the batch
+// EPI 1: per-channel sums of the stored values and of their squares over the wave's rows, left in R ([TN][2][32] floats of
+// LDS per wave; the kernel adds the waves of a block in a fixed order and writes one partial row per row tile: the batch
 // statistics of the BatchNorm behind the conv; fixed layout, fixed order -> deterministic).
 // EPI 2: the stored value is g = o masked by the sign bits of the BatchNorm output this gradient belongs to, the sums are
 // those of g and g * xhat (first half of that BatchNorm's backward; the expression of colsum_kernel<1> in train_ops.hip).
 template <int TM, int TN, int NPRE, int EPI = 0>
 __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
-                                                      int n_base, int lane, const v4f (&pre)[NPRE]) {
+                                                      int n_base, int lane, const v4f (&pre)[NPRE], float* R = nullptr) {
     constexpr bool PRE = NPRE == TM * TN * 4;       // (an array of 1 = "no prefetched residual": registers, never scratch)
     const bool relu = a.flags & PEMP_CONV_RELU;
     const bool per_img = a.flags & PEMP_CONV_SHIFT_PER_IMAGE;
@@ -74,6 +75,7 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
             bmu = *(const v4f*)(a.bmean + n);
             bis = *(const v4f*)(a.binvstd + n);
         }
+        v4f t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};      // EPI: sums over the wave's TM row groups, ascending
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
             v4f zt[4];
@@ -144,14 +146,33 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
                     s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64);
                     s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
                 }
-                const int r32 = (m_base + mi * 32) >> 5;
-                if (lane < 8 && m_base + mi * 32 < a.M) {
-                    *(v4f*)(a.stats + ((size_t)r32 * 2 + 0) * a.Cout + n) = s1;
-                    *(v4f*)(a.stats + ((size_t)r32 * 2 + 1) * a.Cout + n) = s2;
-                }
+                t1 += s1;
+                t2 += s2;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the patch is rewritten
         }
+        if constexpr (EPI != 0) {
+            if (lane < 8) {
+                *(v4f*)(R + (ni * 2 + 0) * 32 + c4) = t1;
+                *(v4f*)(R + (ni * 2 + 1) * 32 + c4) = t2;
+            }
+        }
+    }
+}
+
+// Block-level finish of the EPI sums: the waves that cover the same columns (WGM of them, one per row band of the tile) are
+// added in ascending row order and the tile's partial row goes to a.stats[bm].  Rall: the R areas of all waves
+// ([NW][TN][2][32]); call after a block barrier.
+template <int BN, int WGM, int NW, int TN>
+__device__ __forceinline__ void conv_stats_store(const ConvArgs& a, const float* Rall, int bm, int n0, int tid) {
+    constexpr int WGN = NW / WGM, WN = BN / WGN;
+    if (tid < 2 * BN) {
+        const int st = tid / BN, col = tid - st * BN;
+        const int wni = col / WN, ni = (col - wni * WN) >> 5, c = col & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int wmi = 0; wmi < WGM; ++wmi) s += Rall[(((wmi * WGN + wni) * TN + ni) * 2 + st) * 32 + c];
+        a.stats[((size_t)bm * 2 + st) * a.Cout + n0 + col] = s;
     }
 }
 
@@ -168,6 +189,7 @@ int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st);
 // conv_dma2.hip
 bool conv_dma2_supported(const ConvArgs& a);
 int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st);
+int conv_dma2_tile_rows(int tile);
 // split-K plan of tile variant `tile` (1..7) for this geometry: number of unsplit tiles, split tiles, pieces per split tile
 // (pieces == 1: the variant runs unsplit) and the workspace the launch needs (counters first, then the partial tiles)
 struct SplitKPlan { int full, split, pieces; size_t ws_bytes; };

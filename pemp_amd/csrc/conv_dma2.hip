@@ -354,11 +354,17 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: transpose through LDS.  No LDS read and no DMA is outstanding after the loop's last barrier. ----
-    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre);
+    float* Rall = (float*)smem + NW * 1024;          // EPI: [NW][TN][2][32] sums of the waves, behind their transpose patches
+    static_assert(EPI == 0 || NW * 1024 + NW * TN * 64 <= 64 * (BM + BN), "LDS: statistics area");
+    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre, Rall + wave * TN * 64);
     else if constexpr (EPI != 0) {
         const v4f none[1] = {{0.f, 0.f, 0.f, 0.f}};
-        conv_epilogue_lds_pre<TM, TN, 1, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, none);
+        conv_epilogue_lds_pre<TM, TN, 1, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, none, Rall + wave * TN * 64);
     } else conv_epilogue_lds<TM, TN>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
+    if constexpr (EPI != 0) {
+        __syncthreads();
+        conv_stats_store<BN, WGM, NW, TN>(a, Rall, bm, n0, tid);
+    }
 #endif
 }
 
@@ -377,6 +383,11 @@ static int launch_dma2(const ConvArgs& a, hipStream_t st) {
     const int grid = cdiv(a.M, BM) * (a.Cout / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
     return launch_status("conv_dma2");
+}
+
+int conv_dma2_tile_rows(int tile) {        // BM of tile variant 1..7
+    static const int bm[8] = {0, 128, 128, 64, 128, 128, 256, 256};
+    return tile >= 1 && tile <= 7 ? bm[tile] : 0;
 }
 
 static void tile_shape(int tile, int& bm, int& bn) {

@@ -398,6 +398,13 @@ static int conv_stats_common(const char* what, const pemp_conv_desc* d, ConvArgs
     return launch_conv_dma2(d->tile == 0 ? 3 : d->tile - 20, a, st);
 }
 
+extern "C" int pemp_conv2d_stats_rows(const pemp_conv_desc* d) {
+    if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+    const int t = d->tile == 0 ? 3 : (d->tile > 30 ? d->tile - 30 : d->tile - 20);
+    const int bm = conv_dma2_tile_rows(t);
+    return bm ? cdiv(d->N * d->Ho * d->Wo, bm) : 0;
+}
+
 extern "C" size_t pemp_conv2d_splitk_workspace_bytes(const pemp_conv_desc* d) {
     if (!d || d->tile < 31 || d->tile > 37 || d->tile == 33 || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 || d->Kpad < 32) return 0;
     ConvArgs a;

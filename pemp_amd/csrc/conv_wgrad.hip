@@ -492,13 +492,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 using namespace pemp;
 
-static int pick_split(int tiles, int steps) {
+static int pick_split(int tiles, int steps, int want = 0) {
     // aim for ~768 blocks (3 per CU) with at least 8 reduction steps each.  The kernel shares the chip with the
     // input-gradient chain on the other stream, so it need not fill it alone, and every split costs a [Cout][K] partial
     // that the reduce pass has to read again: 1536 / 1024 / 768 / 512 / 384 blocks -> 20.88 / 20.78 / 20.53 / 20.59 /
     // 20.76 ms per training step.
     static const int target = getenv("PEMP_WGRAD_BLOCKS") ? atoi(getenv("PEMP_WGRAD_BLOCKS")) : 768;      // tuning knob
-    int s = cdiv(target, tiles);
+    int s = cdiv(want > 0 ? want : target, tiles);     // want: the caller's block count (desc.tile >> 8; the Python side times a few)
     if (s > steps / 8) s = steps / 8;
     if (s < 1) s = 1;
     if (s > 512) s = 512;
@@ -519,7 +519,7 @@ extern "C" size_t pemp_conv2d_wgrad_workspace_bytes(const pemp_conv_desc* d) {
     const bool big = wgrad_big_tiles(d);
     const int tw = big ? 128 : 64;
     const int tiles = cdiv(d->Cout, tw) * (d->Kpad / tw > 0 ? cdiv(d->Kpad, tw) : 1);
-    const int split = pick_split(tiles, cdiv(M, 32));
+    const int split = pick_split(tiles, cdiv(M, 32), d->tile >> 8);
     return (size_t)split * d->Cout * d->Kpad * sizeof(float) + 256;
 }
 
@@ -554,7 +554,7 @@ extern "C" int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* 
     const int tw = big ? 128 : 64;
     const int tiles_k = d->Kpad / tw;
     const int tiles = (d->Cout / tw) * tiles_k;
-    a.nsplit = pick_split(tiles, a.steps_total);
+    a.nsplit = pick_split(tiles, a.steps_total, d->tile >> 8);
     a.steps_per_split = cdiv(a.steps_total, a.nsplit);
     a.nsplit = cdiv(a.steps_total, a.steps_per_split);
     const bool direct = a.nsplit == 1 && !accumulate;
@@ -567,7 +567,7 @@ extern "C" int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* 
     dim3 grid(d->Cout / tw, tiles_k, a.nsplit);
     // second-generation kernels: one wrap of wo per 32-pixel step, buffer offsets below 2 GiB (desc.tile = 1 asks for the
     // first generation: the parity tests compare the two bit for bit)
-    const bool v2 = d->tile != 1 && !stem && d->Wo >= 32 && d->Cin % tw == 0 &&
+    const bool v2 = (d->tile & 255) != 1 && !stem && d->Wo >= 32 && d->Cin % tw == 0 &&
                     (long long)d->N * d->H * d->W * d->ldx * 4 < (1ll << 31) && (long long)a.M * d->ldy * 4 < (1ll << 31);
     if (v2) {
         if (big) hipLaunchKernelGGL(conv_wgrad2_kernel<128>, grid, dim3(256), 2 * 2 * 32 * 32 * sizeof(v4f), st, a);

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
                                                      const float* __restrict__ p2, int ld2,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, double* __restrict__ part,
-                                                     int M, int C, int relu) {
+                                                     int M, int C, int relu, const uint32_t* __restrict__ mask = nullptr) {
     __shared__ double red[2][16][64];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cl * 4;
@@ -48,6 +48,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
             A[k] = Y[k] = Z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < r1) {
                 A[k] = *(const float4*)(p0 + (size_t)r * ld0 + c);
+                if (MODE == 1 && relu && mask) {        // the sign bits of y stand in for y (1/32 of the bytes)
+                    const uint32_t b = mask[(size_t)r * (C >> 5) + (c >> 5)] >> (c & 31);
+                    Y[k] = make_float4((b & 1u) ? 1.f : 0.f, (b & 2u) ? 1.f : 0.f, (b & 4u) ? 1.f : 0.f, (b & 8u) ? 1.f : 0.f);
+                } else
                 if (MODE != 0 && relu) Y[k] = *(const float4*)(p1 + (size_t)r * ld1 + c);
                 if (MODE == 1) Z[k] = *(const float4*)(p2 + (size_t)r * ld2 + c);
             }
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
     }
 }
 
-// Totals of the per-32-row partial sums a conv epilogue left ([n32][2][C] floats; conv_common.h): a block owns 32 channels,
+// Totals of the per-row-tile partial sums a conv epilogue left ([n32][2][C] floats; conv_common.h): a block owns 32 channels,
 // thread (rl = tid / 8, q = tid % 8) adds the partial rows rl, rl+32, ... of channel quad q in ascending order (double), the
 // 32 row-lanes are then added in ascending order: fixed order, independent of launch geometry.  Returns, in threads 0..31,
 // the two totals of channel blockIdx.x*32 + tid.
@@ -379,7 +383,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ sum_g,
                                                                 const float* __restrict__ sum_gx, float* __restrict__ dz, int lddz,
-                                                                float* __restrict__ gout, int ldg, int M, int C4, int relu) {
+                                                                float* __restrict__ gout, int ldg, int M, int C4, int relu,
+                                                                const uint32_t* __restrict__ mask = nullptr) {
     const int c = (threadIdx.x % C4) * 4, rpb = 256 / C4;
     const float invM = 1.f / (float)M;
     float is[4], mu[4], sg[4], sgx[4], isg[4];
@@ -398,7 +403,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const float* __r
         const int m = r0 + k * rpb;
         if (m < M) {
             d4[k] = *(const float4*)(dy + (size_t)m * lddy + c);
-            if (relu) y4[k] = *(const float4*)(y + (size_t)m * ldy + c);
+            if (relu && mask) {
+                const uint32_t b = mask[(size_t)m * (C4 >> 3) + (c >> 5)] >> (c & 31);
+                y4[k] = make_float4((b & 1u) ? 1.f : 0.f, (b & 2u) ? 1.f : 0.f, (b & 4u) ? 1.f : 0.f, (b & 8u) ? 1.f : 0.f);
+            } else if (relu) y4[k] = *(const float4*)(y + (size_t)m * ldy + c);
             z4[k] = *(const float4*)(z + (size_t)m * ldz + c);
         }
     }
@@ -628,11 +636,11 @@ extern "C" int pemp_bn_stats_f32(const float* z, int ldz, int M, int C, float ep
     return launch_status("bn_stats");
 }
 
-extern "C" int pemp_bn_stats_partials_f32(const float* stats, int M, int C, float eps, float momentum, float* mean,
+extern "C" int pemp_bn_stats_partials_f32(const float* stats, int nrows, int M, int C, float eps, float momentum, float* mean,
                                           float* invstd, float* run_mean, float* run_var, void* stream) {
-    PEMP_REQUIRE(stats && mean && invstd && M > 0 && C > 0 && C % 32 == 0, "bn_stats_partials: bad arguments (C %% 32)");
+    PEMP_REQUIRE(stats && mean && invstd && M > 0 && C > 0 && C % 32 == 0 && nrows > 0, "bn_stats_partials: bad arguments (C %% 32)");
     PEMP_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "bn_stats_partials: running stats must both be given or both NULL");
-    hipLaunchKernelGGL(bn_stats_partials_kernel, dim3(C / 32), dim3(256), 0, (hipStream_t)stream, stats, cdiv(M, 32), M, C, eps,
+    hipLaunchKernelGGL(bn_stats_partials_kernel, dim3(C / 32), dim3(256), 0, (hipStream_t)stream, stats, nrows, M, C, eps,
                        momentum, mean, invstd, run_mean, run_var);
     return launch_status("bn_stats_partials");
 }
@@ -665,38 +673,64 @@ extern "C" int pemp_bn_bwd_f32(const float* dy, int lddy, const float* y, int ld
                                const float* mean, const float* invstd, const float* gamma, float* dz, int lddz,
                                float* gout, int ldg, float* dgamma, float* dbeta, int M, int C, int relu, void* ws,
                                size_t ws_bytes, void* stream) {
+    return pemp_bn_bwd_mask_f32(dy, lddy, y, ldy, nullptr, z, ldz, mean, invstd, gamma, dz, lddz, gout, ldg, dgamma, dbeta, M, C, relu,
+                                ws, ws_bytes, stream);
+}
+
+extern "C" int pemp_bn_bwd_mask_f32(const float* dy, int lddy, const float* y, int ldy, const uint32_t* mask, const float* z,
+                                    int ldz, const float* mean, const float* invstd, const float* gamma, float* dz, int lddz,
+                                    float* gout, int ldg, float* dgamma, float* dbeta, int M, int C, int relu, void* ws,
+                                    size_t ws_bytes, void* stream) {
     CHK_VEC(dy, lddy, C, "bn_bwd");
     CHK_VEC(z, ldz, C, "bn_bwd");
     CHK_VEC(dz, lddz, C, "bn_bwd");
-    if (relu) CHK_VEC(y, ldy, C, "bn_bwd");
+    PEMP_REQUIRE(!mask || (C % 32 == 0 && rows_form(C)), "bn_bwd: the sign mask needs C in {32, 64, 128, 256, 512, 1024}");
+    if (relu && !mask) CHK_VEC(y, ldy, C, "bn_bwd");
     if (gout) CHK_VEC(gout, ldg, C, "bn_bwd");
     PEMP_REQUIRE(M > 0 && mean && invstd && gamma && dgamma && dbeta && ws, "bn_bwd: null pointer");
     PEMP_REQUIRE(ws_bytes >= pemp_colsum_workspace_bytes(M, C), "bn_bwd: workspace too small");
     const int nck = nchunks_rows(M);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_kernel<1>, dim3(nck, cdiv(C, 64)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean, invstd,
-                       (double*)ws, M, C, relu);
+                       (double*)ws, M, C, relu, mask);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const double*)ws, nck, C, dbeta, dgamma);
     const long long total = (long long)M * (C / 4);
     if (rows_form(C))
         hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3(rows_grid(M, C)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean,
-                           invstd, gamma, dbeta, dgamma, dz, lddz, gout, ldg, M, C / 4, relu);
+                           invstd, gamma, dbeta, dgamma, dz, lddz, gout, ldg, M, C / 4, relu, mask);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, mean,
                            invstd, gamma, dbeta, dgamma, dz, lddz, gout, ldg, (long long)M, C / 4, relu);
     return launch_status("bn_bwd");
 }
 
+extern "C" int pemp_bn_fwd_partials_f32(const float* z, int ldz, const float* stats, int nrows, int M, int C, float eps,
+                                        float momentum, const float* gamma, const float* beta, const float* residual, int ldr,
+                                        float* y, int ldy, int relu, uint32_t* mask, float* mean, float* invstd, float* run_mean,
+                                        float* run_var, void* stream) {
+    CHK_VEC(z, ldz, C, "bn_fwd_partials");
+    CHK_VEC(y, ldy, C, "bn_fwd_partials");
+    if (residual) CHK_VEC(residual, ldr, C, "bn_fwd_partials");
+    PEMP_REQUIRE(stats && nrows > 0 && M > 0 && gamma && beta && mean && invstd, "bn_fwd_partials: null pointer");
+    PEMP_REQUIRE(C % 32 == 0, "bn_fwd_partials: C %% 32");
+    PEMP_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "bn_fwd_partials: running stats must both be given or both NULL");
+    // (one launch -- every block adding the partial rows of its 32 channels itself before it normalises its rows -- was
+    // built and measured slower: 30.7 us against 24 us for the pair, the blocks wait out the partials' latency first)
+    const int rc = pemp_bn_stats_partials_f32(stats, nrows, M, C, eps, momentum, mean, invstd, run_mean, run_var, stream);
+    if (rc) return rc;
+    return pemp_bn_apply_mask_f32(z, ldz, mean, invstd, gamma, beta, residual, ldr, y, ldy, M, C, relu, mask, stream);
+}
+
 extern "C" int pemp_bn_bwd_partials_f32(const float* g, int ldg, const float* z, int ldz, const float* mean,
-                                        const float* invstd, const float* gamma, const float* stats, float* dz, int lddz,
-                                        float* dgamma, float* dbeta, int M, int C, void* stream) {
+                                        const float* invstd, const float* gamma, const float* stats, int nrows, float* dz,
+                                        int lddz, float* dgamma, float* dbeta, int M, int C, void* stream) {
     CHK_VEC(g, ldg, C, "bn_bwd_partials");
     CHK_VEC(z, ldz, C, "bn_bwd_partials");
     CHK_VEC(dz, lddz, C, "bn_bwd_partials");
-    PEMP_REQUIRE(M > 0 && mean && invstd && gamma && dgamma && dbeta && stats, "bn_bwd_partials: null pointer");
+    PEMP_REQUIRE(M > 0 && mean && invstd && gamma && dgamma && dbeta && stats && nrows > 0, "bn_bwd_partials: null pointer");
     PEMP_REQUIRE(C % 32 == 0, "bn_bwd_partials: C %% 32");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3(C / 32), dim3(256), 0, st, stats, cdiv(M, 32), C, dbeta, dgamma);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(C / 32), dim3(256), 0, st, stats, nrows, C, dbeta, dgamma);
     const long long total = (long long)M * (C / 4);
     if (rows_form(C))
         hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3(rows_grid(M, C)), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, z,

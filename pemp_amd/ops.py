@@ -219,13 +219,19 @@ def _splitk_ws(lib, desc, device):
     return ptr, size
 
 
+def _stats_rows(m, tile):
+    """Partial rows the stats / bnbwd epilogues of variant ``tile`` write: one per row tile (pemp_conv2d_stats_rows)."""
+    bm = TILE_VARIANTS[tile - 10 if tile > 30 else tile][0]
+    return (m + bm - 1) // bm
+
+
 def _train_tiles(cout):
     return [t for t in list(range(21, 28)) + list(SPLITK_TILES) if cout % TILE_VARIANTS[t - 10 if t > 30 else t][1] == 0]
 
 
 def conv2d_stats(x, p, out=None, tile=0):
     """z = conv(x, w) with the per-32-row partial sums of z and z^2 left by the epilogue (pemp_conv2d_stats_nhwc_f32):
-    -> (z, partials [ceil(M/32), 2, Cout]).  Raises PempHipError where the buffer-addressed kernels do not apply
+    -> (z, partials [row tiles of the chosen variant, 2, Cout]).  Raises PempHipError where the buffer-addressed kernels do not apply
     (callers then use conv2d + bn_stats); ``stats_supported`` says so beforehand."""
     lib = _lib.load()
     _chk_dev(x, p.w, out)
@@ -241,7 +247,7 @@ def conv2d_stats(x, p, out=None, tile=0):
         out = torch.empty((n, ho, wo, p.cout), dtype=torch.float32, device=x.device)
     ldy = _nhwc(out, "out")
     m = n * ho * wo
-    part = torch.empty(((m + 31) // 32, 2, p.cout), dtype=torch.float32, device=x.device)
+    part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)     # the smallest row tile has 64 rows
 
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, 0, p.kpad, 0, t)
@@ -258,7 +264,7 @@ def conv2d_stats(x, p, out=None, tile=0):
             else:
                 tile = DEFAULT_TILE + 10
     launch(tile)
-    return out, part
+    return out, part[:_stats_rows(m, tile)]
 
 
 def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
@@ -266,7 +272,7 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
     BatchNorm's ReLU -- with the per-32-row partial sums of g and g * xhat left by the epilogue
     (pemp_conv2d_bnbwd_nhwc_f32).  ``bn``: dict with z (the BatchNorm's input, NHWC like the result), mean, invstd and
     mask (int32 [M, C/32] sign bits from train_ops.bn_apply, or None for a BatchNorm without ReLU).
-    -> (g, partials [ceil(M/32), 2, Cout])."""
+    -> (g, partials [row tiles of the chosen variant, 2, Cout])."""
     lib = _lib.load()
     z, mask = bn["z"], bn.get("mask")
     _chk_dev(x, p.w, out, residual, z, mask, bn["mean"], bn["invstd"])
@@ -292,7 +298,7 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
         ldr = _nhwc(residual, "residual")
         if tuple(residual.shape) != tuple(out.shape):
             raise ValueError("conv2d_bnbwd: residual shape mismatch")
-    part = torch.empty(((m + 31) // 32, 2, p.cout), dtype=torch.float32, device=x.device)
+    part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)
 
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, 0, t)
@@ -310,7 +316,7 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
             else:
                 tile = DEFAULT_TILE + 10
     launch(tile)
-    return out, part
+    return out, part[:_stats_rows(m, tile)]
 
 
 def stats_supported(x, p):

@@ -375,15 +375,19 @@ class Stage1TrainEngine:
     def _cbn_fwd(self, x, conv, bn, relu, residual=None, img_bias=None):
         """conv -> (+ per-image bias [N,Cout]) -> batch-stat BN (+residual)(+ReLU); returns (y, tape record)."""
         prm = conv.fwd_params(relu=False, with_bias=False)
+        part = None
         if FUSE_BN_STATS and img_bias is None and ops.stats_supported(x, prm):
             z, part = ops.conv2d_stats(x, prm)         # batch statistics started in the conv epilogue
-            mean, invstd = bn.stats_from(part, z.shape[0] * z.shape[1] * z.shape[2])
         else:
             z = conv2d(x, prm) if img_bias is None else conv2d(x, prm, shift_override=img_bias, per_image_shift=True)
-            mean, invstd = bn.stats(z, self.ws)
         mask = None
         if FUSE_BN_BWD and relu and T.mask_supported(z.shape[-1]):       # sign bits of y: what the backward needs of it
             mask = torch.empty((z.numel() // z.shape[-1], z.shape[-1] // 32), dtype=torch.int32, device=z.device)
+        if part is not None:                           # ... finished and applied by one call
+            y, mean, invstd = T.bn_fwd_partials(z, part, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(z), bn.bn.eps, BN_MOM,
+                                                bn.bn.running_mean, bn.bn.running_var, residual=residual, relu=relu, mask=mask)
+            return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu, mask=mask)
+        mean, invstd = bn.stats(z, self.ws)
         y = T.bn_apply(z, mean, invstd, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(z), residual=residual, relu=relu,
                        mask=mask)
         return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu, mask=mask)
@@ -401,7 +405,8 @@ class Stage1TrainEngine:
         else:
             gout = torch.empty_like(rec["z"]) if want_gout else None
             T.bn_bwd(dy, rec["y"], rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, dz, gout=gout, relu=rec["relu"],
-                     ws_cache=self.ws, out=bn.grad_out())        # dgamma / dbeta go straight into the flat gradient buffer
+                     ws_cache=self.ws, out=bn.grad_out(),        # dgamma / dbeta go straight into the flat gradient buffer
+                     mask=rec.get("mask"))
         conv.wgrad(rec["x"], dz, self.ws)
         rec["dz"] = dz
         if not need_dx:

@@ -37,18 +37,43 @@ def bn_stats(z, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, ws_cache=No
     return mean, invstd
 
 
+def _chk_part(part, what):
+    if part.dtype != torch.float32 or not part.is_contiguous() or part.dim() != 3 or part.shape[1] != 2:
+        raise ValueError(f"{what}: partials must be contiguous fp32 [row tiles, 2, C], got {tuple(part.shape)}")
+
+
 def bn_stats_partials(part, m, eps=1e-5, momentum=0.1, run_mean=None, run_var=None):
-    """bn_stats from the [ceil(M/32), 2, C] partial sums a conv epilogue left (ops.conv2d_stats)."""
+    """bn_stats from the [row tiles, 2, C] partial sums a conv epilogue left (ops.conv2d_stats)."""
     lib = _lib.load()
     _chk_dev(part, run_mean, run_var)
+    _chk_part(part, "bn_stats_partials")
     c = part.shape[2]
-    if part.dtype != torch.float32 or not part.is_contiguous() or part.shape[0] != (m + 31) // 32 or part.shape[1] != 2:
-        raise ValueError(f"bn_stats_partials: partials must be contiguous fp32 [ceil({m}/32), 2, C], got {tuple(part.shape)}")
     mean = torch.empty(c, dtype=torch.float32, device=part.device)
     invstd = torch.empty(c, dtype=torch.float32, device=part.device)
-    _lib.check(lib.pemp_bn_stats_partials_f32(_p(part), m, c, eps, momentum, _p(mean), _p(invstd), _p(run_mean),
+    _lib.check(lib.pemp_bn_stats_partials_f32(_p(part), part.shape[0], m, c, eps, momentum, _p(mean), _p(invstd), _p(run_mean),
                                               _p(run_var), _stream()), "bn_stats_partials")
     return mean, invstd
+
+
+def bn_fwd_partials(z, part, gamma, beta, out, eps=1e-5, momentum=0.1, run_mean=None, run_var=None, residual=None, relu=True,
+                    mask=None):
+    """bn_stats_partials + bn_apply in one call (pemp_bn_fwd_partials_f32): -> (out, mean, invstd)."""
+    lib = _lib.load()
+    _chk_dev(z, part, out, residual, mask, run_mean, run_var)
+    _chk_part(part, "bn_fwd_partials")
+    m, c, ldz = _rows(z, "z")
+    _, _, ldy = _rows(out, "out")
+    ldr = _rows(residual, "residual")[2] if residual is not None else 0
+    if part.shape[2] != c:
+        raise ValueError(f"bn_fwd_partials: partials have {part.shape[2]} channels, z has {c}")
+    if mask is not None and (mask.dtype != torch.int32 or not mask.is_contiguous() or mask.numel() != m * (c // 32) or c % 32):
+        raise ValueError(f"bn_fwd_partials: mask must be a contiguous int32 [{m}, {c}/32] tensor")
+    mean = torch.empty(c, dtype=torch.float32, device=z.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=z.device)
+    _lib.check(lib.pemp_bn_fwd_partials_f32(_p(z), ldz, _p(part), part.shape[0], m, c, eps, momentum, _p(gamma), _p(beta),
+                                            _p(residual), ldr, _p(out), ldy, 1 if relu else 0, _p(mask), _p(mean), _p(invstd),
+                                            _p(run_mean), _p(run_var), _stream()), "bn_fwd_partials")
+    return out, mean, invstd
 
 
 def bn_apply(z, mean, invstd, gamma, beta, out, residual=None, relu=True, mask=None):
@@ -76,23 +101,25 @@ def bn_bwd_partials(g, z, mean, invstd, gamma, part, dz, out=None):
     m, c, ldg = _rows(g, "g")
     ldz = _rows(z, "z")[2]
     lddz = _rows(dz, "dz")[2]
-    if part.dtype != torch.float32 or not part.is_contiguous() or tuple(part.shape) != ((m + 31) // 32, 2, c):
-        raise ValueError(f"bn_bwd_partials: partials must be contiguous fp32 [ceil({m}/32), 2, {c}], got {tuple(part.shape)}")
+    _chk_part(part, "bn_bwd_partials")
+    if part.shape[2] != c:
+        raise ValueError(f"bn_bwd_partials: partials have {part.shape[2]} channels, g has {c}")
     if out is None:
         dgamma = torch.empty(c, dtype=torch.float32, device=g.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=g.device)
     else:
         dgamma, dbeta = out
-    _lib.check(lib.pemp_bn_bwd_partials_f32(_p(g), ldg, _p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(part), _p(dz), lddz,
-                                            _p(dgamma), _p(dbeta), m, c, _stream()), "bn_bwd_partials")
+    _lib.check(lib.pemp_bn_bwd_partials_f32(_p(g), ldg, _p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(part), part.shape[0],
+                                            _p(dz), lddz, _p(dgamma), _p(dbeta), m, c, _stream()), "bn_bwd_partials")
     return dgamma, dbeta
 
 
-def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=None, out=None):
+def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=None, out=None, mask=None):
     """-> (dgamma, dbeta); writes dz (and gout = dy*(y>0), the gradient of the residual branch).
-    ``out=(dgamma, dbeta)``: contiguous [C] tensors to write into (e.g. the flat-buffer gradient views)."""
+    ``out=(dgamma, dbeta)``: contiguous [C] tensors to write into (e.g. the flat-buffer gradient views).
+    ``mask``: the sign bits of y from bn_apply(mask=...); y is then not read."""
     lib = _lib.load()
-    _chk_dev(dy, y, z, dz, gout)
+    _chk_dev(dy, y, z, dz, gout, mask)
     m, c, lddy = _rows(dy, "dy")
     ldy = _rows(y, "y")[2] if y is not None else 0
     ldz = _rows(z, "z")[2]
@@ -106,9 +133,11 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=Non
         dgamma = torch.empty(c, dtype=torch.float32, device=dy.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=dy.device)
     ws = _ws(lib.pemp_colsum_workspace_bytes(m, c), dy.device, ws_cache, ("colsum", m, c))
-    _lib.check(lib.pemp_bn_bwd_f32(_p(dy), lddy, _p(y), ldy, _p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(dz), lddz,
-                                   _p(gout), ldg, _p(dgamma), _p(dbeta), m, c, 1 if relu else 0, _p(ws), ws.numel(),
-                                   _stream()), "bn_bwd")
+    if mask is not None and (mask.dtype != torch.int32 or not mask.is_contiguous() or mask.numel() != m * (c // 32) or c % 32):
+        raise ValueError(f"bn_bwd: mask must be a contiguous int32 [{m}, {c}/32] tensor")
+    _lib.check(lib.pemp_bn_bwd_mask_f32(_p(dy), lddy, _p(y), ldy, _p(mask if relu else None), _p(z), ldz, _p(mean), _p(invstd),
+                                        _p(gamma), _p(dz), lddz, _p(gout), ldg, _p(dgamma), _p(dbeta), m, c, 1 if relu else 0,
+                                        _p(ws), ws.numel(), _stream()), "bn_bwd")
     return dgamma, dbeta
 
 
@@ -131,10 +160,16 @@ def relu_bias_bwd(dy, y, g, add=None, relu=True, want_dbias=True, ws_cache=None,
     return dbias
 
 
-def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0):
+_WGRAD_BLOCKS = {}      # (layer geometry, input shape) -> block count that measured fastest
+WGRAD_BLOCK_CHOICES = (512, 768, 1024, 1536)
+
+
+def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=None):
     """dw (KRSC [Cout, Kpad_w]) (+)= wgrad of the conv described by ConvParams ``p`` (geometry only).
     For the stem ``dw`` has row length ceil(KH*KW*4 / 64) * 64.  ``variant`` = 1: the first-generation kernels
-    (pointer-addressed; the library picks the buffer-addressed second generation where it applies, bit-identical)."""
+    (pointer-addressed; the library picks the buffer-addressed second generation where it applies, bit-identical).
+    ``blocks``: how many blocks the pixel rows are split over (0: the library's 768; None: time WGRAD_BLOCK_CHOICES once
+    per layer shape and keep the fastest -- results of different splits differ by the rounding of the regrouped sum)."""
     lib = _lib.load()
     _chk_dev(x, g, dw)
     from .ops import _nhwc
@@ -148,12 +183,36 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0):
     kpad = dw.shape[1]
     if dw.shape[0] != cout or not dw.is_contiguous():
         raise ValueError("conv_wgrad: dw must be contiguous [Cout, Kpad]")
-    d = ConvDesc(n, h, w, cin, ldx, ho, wo, cout, ldg, p.kh, p.kw, p.stride, p.pad, p.dil, 0, kpad,
-                 CONV_STEM4 if p.stem else 0, int(variant))
-    nbytes = lib.pemp_conv2d_wgrad_workspace_bytes(C.byref(d))
-    ws = _ws(nbytes, x.device, ws_cache, ("wgrad", nbytes))
-    _lib.check(lib.pemp_conv2d_wgrad_nhwc_f32(C.byref(d), _p(x), _p(g), _p(dw), 1 if accumulate else 0, _p(ws),
-                                              ws.numel(), _stream()), "conv_wgrad")
+    def launch(nb):
+        d = ConvDesc(n, h, w, cin, ldx, ho, wo, cout, ldg, p.kh, p.kw, p.stride, p.pad, p.dil, 0, kpad,
+                     CONV_STEM4 if p.stem else 0, int(variant) | (int(nb) << 8))
+        nbytes = lib.pemp_conv2d_wgrad_workspace_bytes(C.byref(d))
+        ws = _ws(nbytes, x.device, ws_cache, ("wgrad", nbytes))
+        _lib.check(lib.pemp_conv2d_wgrad_nhwc_f32(C.byref(d), _p(x), _p(g), _p(dw), 1 if accumulate else 0, _p(ws),
+                                                  ws.numel(), _stream()), "conv_wgrad")
+
+    if blocks is None:
+        from . import ops
+        key = (cin, cout, p.kh, p.kw, p.stride, p.pad, p.dil, bool(p.stem), n, h, w)
+        blocks = _WGRAD_BLOCKS.get(key)
+        if blocks is None:
+            blocks = 0
+            if ops.AUTOTUNE and not accumulate and m >= 4096 and not torch.cuda.is_current_stream_capturing():
+                def timed(nb, reps=3):
+                    launch(nb)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        launch(nb)
+                    e1.record()
+                    e1.synchronize()
+                    return e0.elapsed_time(e1)
+                ms = {nb: timed(nb) for nb in WGRAD_BLOCK_CHOICES}
+                for nb in WGRAD_BLOCK_CHOICES:
+                    ms[nb] = min(ms[nb], timed(nb))
+                blocks = min(ms, key=ms.get)
+            _WGRAD_BLOCKS[key] = blocks
+    launch(blocks)
     return dw
 
 

@@ -132,8 +132,9 @@ STATS_CASES = [  # N, H, W, Cin, Cout, k, s, p, d
 @pytest.mark.parametrize("case", STATS_CASES)
 def test_conv_with_batch_statistics_in_the_epilogue(hip_lib, dev, case):
     """pemp_conv2d_stats_nhwc_f32: z is bit-identical to the plain conv on every tile; the partial sums are the column
-    sums of the stored z over each 32-row group (fp32 sums of 32 values: 1e-6 relative to sum |z|), identical on every
-    tile; mean / invstd / running statistics from them equal pemp_bn_stats_f32 of z to fp32 rounding."""
+    sums of the stored z over each row tile (fp32 sums: 2e-6 relative to sum |z|), reproducible; mean / invstd /
+    running statistics from them equal pemp_bn_stats_f32 of z to fp32 rounding, and pemp_bn_fwd_partials_f32 (statistics
+    + normalisation + sign mask in one call) equals the two separate calls bit for bit."""
     from pemp_amd import ops, train_ops as T
     N, H, W, Cin, Cout, k, s, p, d = case
     x = _nhwc(_rand(N, Cin, H, W, seed=1)).to(dev)
@@ -143,20 +144,28 @@ def test_conv_with_batch_statistics_in_the_epilogue(hip_lib, dev, case):
     assert ops.stats_supported(x, prm)
     z_ref = ops.conv2d(x, prm, tile=13)
     M = z_ref.numel() // Cout
-    zr = z_ref.reshape(M, Cout).double().cpu()
-    pad = (-M) % 32
-    zp = torch.cat([zr, torch.zeros(pad, Cout, dtype=torch.float64)]).view(-1, 32, Cout)
+
+    def tile_sums(t, bm):          # [row tiles of bm rows, Cout] column sums (float64) of an [M, Cout] tensor
+        pad = (-M) % bm
+        return torch.cat([t, torch.zeros(pad, Cout, dtype=torch.float64)]).view(-1, bm, Cout).sum(1)
+
+    def check_partials(z, part, tile):
+        bm = ops.TILE_VARIANTS[tile - 10 if tile > 30 else tile][0]
+        assert part.shape == ((M + bm - 1) // bm, 2, Cout) and part.is_contiguous(), tile     # one row per row tile
+        zd = z.reshape(M, Cout).double().cpu()
+        pc = part.double().cpu()
+        assert ((pc[:, 0] - tile_sums(zd, bm)).abs() <= 2e-6 * tile_sums(zd.abs(), bm) + 1e-30).all(), tile
+        assert ((pc[:, 1] - tile_sums(zd * zd, bm)).abs() <= 2e-6 * tile_sums(zd * zd, bm) + 1e-30).all(), tile
+
     first = None
     for tile in [t for t in range(21, 28) if Cout % ops.TILE_VARIANTS[t][1] == 0]:
         z, part = ops.conv2d_stats(x, prm, tile=tile)
         assert torch.equal(z, z_ref), tile
-        assert part.shape == ((M + 31) // 32, 2, Cout)
-        pc = part.double().cpu()
-        assert ((pc[:, 0] - zp.sum(1)).abs() <= 1e-6 * zp.abs().sum(1) + 1e-30).all(), tile
-        assert ((pc[:, 1] - (zp * zp).sum(1)).abs() <= 1e-6 * (zp * zp).sum(1) + 1e-30).all(), tile
+        check_partials(z, part, tile)
+        z2, part2 = ops.conv2d_stats(x, prm, tile=tile)
+        assert torch.equal(part, part2), tile              # fixed order: reproducible
         if first is None:
             first = part.clone()
-        assert torch.equal(part, first), tile
     # split-K variants: the remainder tiles add K slices in a different grouping -> fp32 rounding of the regrouped sum
     # (|d| <= 1e-5 max|z| at K <= 2304); reproducible from launch to launch; the partial sums are those of the stored values
     for tile in [t for t in ops.SPLITK_TILES if Cout % ops.TILE_VARIANTS[t - 10][1] == 0]:
@@ -164,10 +173,8 @@ def test_conv_with_batch_statistics_in_the_epilogue(hip_lib, dev, case):
         assert (z - z_ref).abs().max() <= 1e-5 * z_ref.abs().max(), tile
         z2, part2 = ops.conv2d_stats(x, prm, tile=tile)
         assert torch.equal(z, z2) and torch.equal(part, part2), tile
-        zs = torch.cat([z.reshape(M, Cout).double().cpu(), torch.zeros(pad, Cout, dtype=torch.float64)]).view(-1, 32, Cout)
-        pc = part.double().cpu()
-        assert ((pc[:, 0] - zs.sum(1)).abs() <= 1e-6 * zs.abs().sum(1) + 1e-30).all(), tile
-        assert ((pc[:, 1] - (zs * zs).sum(1)).abs() <= 1e-6 * (zs * zs).sum(1) + 1e-30).all(), tile
+        check_partials(z, part, tile)
+    zr = z_ref.reshape(M, Cout).double().cpu()
     rm, rv = _rand(Cout, seed=5), _rand(Cout, seed=6, lo=0.5, hi=1.5)
     rm1, rv1, rm2, rv2 = rm.to(dev), rv.to(dev), rm.to(dev), rv.to(dev)
     mean, invstd = T.bn_stats_partials(first, M, 1e-5, 0.1, rm1, rv1)
@@ -177,6 +184,17 @@ def test_conv_with_batch_statistics_in_the_epilogue(hip_lib, dev, case):
     mu = zr.mean(0)
     assert torch.allclose(mean.double().cpu(), mu, rtol=1e-5, atol=1e-6)
     assert torch.allclose(invstd.double().cpu(), 1 / (zr.var(0, unbiased=False) + 1e-5).sqrt(), rtol=1e-5)
+    # one call for statistics + normalisation (+ residual, ReLU, sign mask)
+    gamma, beta = _rand(Cout, seed=7, lo=0.5, hi=1.5).to(dev), _rand(Cout, seed=8).to(dev)
+    res = _rand(M, Cout, seed=9).to(dev).view_as(z_ref)
+    mask1 = torch.empty((M, Cout // 32), dtype=torch.int32, device=dev)
+    mask2 = torch.empty_like(mask1)
+    rm3, rv3 = rm.to(dev), rv.to(dev)
+    y1 = T.bn_apply(z_ref, mean, invstd, gamma, beta, torch.empty_like(z_ref), residual=res, relu=True, mask=mask1)
+    y2, mean2, invstd2 = T.bn_fwd_partials(z_ref, first, gamma, beta, torch.empty_like(z_ref), 1e-5, 0.1, rm3, rv3, residual=res,
+                                           relu=True, mask=mask2)
+    assert torch.equal(y1, y2) and torch.equal(mask1, mask2) and torch.equal(mean, mean2) and torch.equal(invstd, invstd2)
+    assert torch.equal(rm1, rm3) and torch.equal(rv1, rv3)
 
 
 BNBWD_CASES = [  # N, H, W, Cin, Cout, k, p, d, residual, relu
@@ -224,30 +242,38 @@ def test_input_gradient_conv_with_batchnorm_backward_in_the_epilogue(hip_lib, de
     bn = dict(z=z, mean=mean, invstd=invstd, mask=mask)
     xhat = ((z.view(M, Cout) - mean) * invstd).double().cpu()
     gd = g_ref.view(M, Cout).double().cpu()
-    pad = (-M) % 32
-    zp = lambda t: torch.cat([t, torch.zeros(pad, Cout, dtype=torch.float64)]).view(-1, 32, Cout)
+    def tile_sums(t, bm):
+        pad = (-M) % bm
+        return torch.cat([t, torch.zeros(pad, Cout, dtype=torch.float64)]).view(-1, bm, Cout).sum(1)
+
+    def check_partials(gv, part, tile):
+        bm = ops.TILE_VARIANTS[tile - 10 if tile > 30 else tile][0]
+        assert part.shape == ((M + bm - 1) // bm, 2, Cout), tile
+        gs = gv.view(M, Cout).double().cpu()
+        pc = part.double().cpu()
+        assert ((pc[:, 0] - tile_sums(gs, bm)).abs() <= 2e-6 * tile_sums(gs.abs(), bm) + 1e-30).all(), tile
+        assert ((pc[:, 1] - tile_sums(gs * xhat, bm)).abs() <= 4e-6 * tile_sums((gs * xhat).abs(), bm) + 1e-30).all(), tile
+
     first = None
     for tile in [t for t in range(21, 28) if Cout % ops.TILE_VARIANTS[t][1] == 0]:
         g, part = ops.conv2d_bnbwd(x, prm, bn, residual=add, tile=tile)
         assert torch.equal(g, g_ref), tile
-        pc = part.double().cpu()
-        assert ((pc[:, 0] - zp(gd).sum(1)).abs() <= 1e-6 * zp(gd).abs().sum(1) + 1e-30).all(), tile
-        assert ((pc[:, 1] - zp(gd * xhat).sum(1)).abs() <= 2e-6 * zp(gd * xhat).abs().sum(1) + 1e-30).all(), tile
+        check_partials(g, part, tile)
         if first is None:
             first = part.clone()
-        assert torch.equal(part, first), tile
     for tile in [t for t in ops.SPLITK_TILES if Cout % ops.TILE_VARIANTS[t - 10][1] == 0]:      # split-K variants (see above)
         g, part = ops.conv2d_bnbwd(x, prm, bn, residual=add, tile=tile)
         assert (g - g_ref).abs().max() <= 1e-5 * dy.abs().max(), tile
-        gs = g.view(M, Cout).double().cpu()
-        pc = part.double().cpu()
-        assert ((pc[:, 0] - zp(gs).sum(1)).abs() <= 1e-6 * zp(gs).abs().sum(1) + 1e-30).all(), tile
-        assert ((pc[:, 1] - zp(gs * xhat).sum(1)).abs() <= 2e-6 * zp(gs * xhat).abs().sum(1) + 1e-30).all(), tile
+        check_partials(g, part, tile)
     dz = torch.empty_like(z)
     dgamma, dbeta = T.bn_bwd_partials(g_ref, z, mean, invstd, gamma, first, dz)
     dz0, gout0 = torch.empty_like(z), torch.empty_like(z)
     dgamma0, dbeta0 = T.bn_bwd(dy, y, z, mean, invstd, gamma, dz0, gout=gout0, relu=relu)
     assert torch.equal(gout0, g_ref)
+    if relu:                                    # the sign bits standing in for y: the same results, y never read
+        dz1, gout1 = torch.empty_like(z), torch.empty_like(z)
+        dgamma1, dbeta1 = T.bn_bwd(dy, None, z, mean, invstd, gamma, dz1, gout=gout1, relu=True, mask=mask)
+        assert torch.equal(dz1, dz0) and torch.equal(gout1, gout0) and torch.equal(dgamma1, dgamma0) and torch.equal(dbeta1, dbeta0)
     scale = gd.abs().sum(0).float().to(dev)
     assert ((dbeta - dbeta0).abs() <= 1e-6 * scale + 1e-30).all() and ((dgamma - dgamma0).abs() <= 4e-6 * scale + 1e-30).all()
     assert torch.allclose(dz, dz0, rtol=1e-4, atol=1e-5), (dz - dz0).abs().max()
