@@ -570,8 +570,18 @@ extern "C" int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* 
     const bool v2 = (d->tile & 255) != 1 && !stem && d->Wo >= 32 && d->Cin % tw == 0 &&
                     (long long)d->N * d->H * d->W * d->ldx * 4 < (1ll << 31) && (long long)a.M * d->ldy * 4 < (1ll << 31);
     if (v2) {
-        if (big) hipLaunchKernelGGL(conv_wgrad2_kernel<128>, grid, dim3(256), 2 * 2 * 32 * 32 * sizeof(v4f), st, a);
-        else hipLaunchKernelGGL(conv_wgrad2_kernel<64>, grid, dim3(256), 2 * 2 * 32 * 16 * sizeof(v4f), st, a);
+        // Every block asks for at least 64 KB of LDS, i.e. at most two weight-gradient blocks per CU: the 64 x 64 kernel
+        // (32 KB) would otherwise fill a CU's 160 KB five deep and the input-gradient convs on the other stream (64 KB
+        // tiles) would wait for a block to retire.  Training step 17.13 -> 17.01 ms; 96 KB (one block per CU): 17.67.
+        static const size_t lds_min = getenv("PEMP_WGRAD_LDS") ? (size_t)atol(getenv("PEMP_WGRAD_LDS")) : 64 * 1024;
+        size_t lds = big ? 2 * 2 * 32 * 32 * sizeof(v4f) : 2 * 2 * 32 * 16 * sizeof(v4f);
+        if (lds < lds_min) lds = lds_min;
+        if (lds > 64 * 1024) {
+            if (big) (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            else (void)hipFuncSetAttribute((const void*)conv_wgrad2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        if (big) hipLaunchKernelGGL(conv_wgrad2_kernel<128>, grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(conv_wgrad2_kernel<64>, grid, dim3(256), lds, st, a);
     } else if (big) {
         hipLaunchKernelGGL(conv_wgrad128_kernel, grid, dim3(256), 2 * 2 * 32 * 32 * sizeof(v4f), st, a);
     } else {
