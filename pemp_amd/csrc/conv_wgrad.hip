@@ -498,7 +498,9 @@ static int pick_split(int tiles, int steps, int want = 0) {
     // that the reduce pass has to read again: 1536 / 1024 / 768 / 512 / 384 blocks -> 20.88 / 20.78 / 20.53 / 20.59 /
     // 20.76 ms per training step.
     static const int target = getenv("PEMP_WGRAD_BLOCKS") ? atoi(getenv("PEMP_WGRAD_BLOCKS")) : 768;      // tuning knob
-    int s = cdiv(want > 0 ? want : target, tiles);     // want: the caller's block count (desc.tile >> 8; the Python side times a few)
+    int s = (want > 0 ? want : target) / tiles;        // want: the caller's block count (desc.tile >> 8; the Python side times a
+                                                       // few).  Rounded DOWN: two 64 KB blocks fit a CU, so 512 / 1024 blocks
+                                                       // are whole rounds of the chip and a few blocks more would start another
     if (s > steps / 8) s = steps / 8;
     if (s < 1) s = 1;
     if (s > 512) s = 512;

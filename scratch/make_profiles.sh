@@ -34,6 +34,11 @@ done
 python3 scratch/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MfmaUtil $O 25
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MfmaUtil
 unset PEMP_TILE_CACHE
+# 3b. MfmaUtil of the training step's implicit-GEMM kernels
+rm -rf $O/pmc_train
+timeout -k 10 600 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/pmc_train -- python3 bench.py --mode train --steps 5 --warmup 3 --cpu-episodes 0 --no-single --no-roofline > $O/pmc_train.log 2>&1 || echo "pmc train failed"
+python3 scratch/pmc_train_summary.py $O/pmc_train $O > /dev/null || echo "pmc train summary failed"
+rm -rf $O/pmc_train
 # 4. prototype-head kernels beyond the Infinity Cache (60 / 100 queries: 320 / 533 MB per launch)
 for q in 25 60 100; do
   rm -rf $O/kt_head

@@ -20,7 +20,7 @@ for hw, cin, cout, k, d in shapes:
     prm = ops.ConvParams(None, None, None, cin, cout, k, k, 1, d * (k // 2), d, k * k * cin, False, False)
     dw = torch.empty(cout, k * k * cin, device=dev)
     ws = {}
-    us = t(lambda: T.conv_wgrad(x, g, prm, dw, ws_cache=ws))
+    us = t(lambda: T.conv_wgrad(x, g, prm, dw, ws_cache=ws, blocks=0))
     fl = 2.0 * 8 * hw * hw * cout * k * k * cin
     out.append(f"{fl/us/1e6:6.1f}")
 print(os.environ.get("PEMP_WGRAD_BLOCKS", "768").rjust(5), " ".join(out), flush=True)
