@@ -264,8 +264,9 @@ int pemp_bn_bwd_partials_f32(const float* g, int ldg, const float* z, int ldz, c
 
 /* Weight gradient of pemp_conv2d_nhwc_f32 (autograd of nn.Conv2d, same call sites):
  *   dw[co][kh][kw][ci] (+)= sum_m g[m][co] * x[pix(m,kh,kw)][ci]      dw is KRSC with row length d->Kpad
- * `d` describes the FORWARD conv (d->ldy = per-pixel stride of g).  STEM4 needs Kpad % 64 == 0.  d->tile: bits 0..7 = kernel generation
- * (0: library's choice, 1: first generation), bits 8.. = number of blocks to aim for when the pixel rows are split over
+ * `d` describes the FORWARD conv (d->ldy = per-pixel stride of g).  STEM4 needs Kpad % 64 == 0.  d->tile: bits 0..7 = kernel choice
+ * (0: library's, 1: first generation, 2 / 3: second generation with 128 x 128 / 64 x 64 tiles where the channel counts allow),
+ * bits 8.. = number of blocks to aim for when the pixel rows are split over
  * blocks (0: 768; the partial sums of different splits round differently -- same value for workspace query and launch). */
 size_t pemp_conv2d_wgrad_workspace_bytes(const pemp_conv_desc* d);
 int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* g, float* dw,

@@ -511,7 +511,10 @@ static int pick_split(int tiles, int steps, int want = 0) {
 // >= 256 output channels (84 -> 93 TFLOP/s) and the large 1x1 layers; the small-output 1x1 layers keep the 64 x 64
 // kernel, whose 4x more blocks per weight matrix fill the chip better.
 static bool wgrad_big_tiles(const pemp_conv_desc* d) {
-    if ((d->flags & PEMP_CONV_STEM4) || d->Cin % 128 || d->Cout % 128 || d->Cout < 256) return false;
+    if ((d->flags & PEMP_CONV_STEM4) || d->Cin % 128 || d->Cout % 128) return false;
+    if ((d->tile & 255) == 2) return true;          // the caller's choice (it timed both): 2 = 128 x 128, 3 = 64 x 64
+    if ((d->tile & 255) == 3) return false;
+    if (d->Cout < 256) return false;
     return d->KH * d->KW > 1 || (long long)d->Cin * d->Cout >= 512ll * 1024;
 }
 

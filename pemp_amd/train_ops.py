@@ -168,8 +168,9 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=N
     """dw (KRSC [Cout, Kpad_w]) (+)= wgrad of the conv described by ConvParams ``p`` (geometry only).
     For the stem ``dw`` has row length ceil(KH*KW*4 / 64) * 64.  ``variant`` = 1: the first-generation kernels
     (pointer-addressed; the library picks the buffer-addressed second generation where it applies, bit-identical).
-    ``blocks``: how many blocks the pixel rows are split over (0: the library's 768; None: time WGRAD_BLOCK_CHOICES once
-    per layer shape and keep the fastest -- results of different splits differ by the rounding of the regrouped sum)."""
+    ``blocks``: how many blocks the pixel rows are split over (0: the library's 768; None: time WGRAD_BLOCK_CHOICES -- and,
+    where both apply, the 128 x 128 and 64 x 64 tile kernels -- once per layer shape and keep the fastest; results of
+    different splits differ by the rounding of the regrouped sum)."""
     lib = _lib.load()
     _chk_dev(x, g, dw)
     from .ops import _nhwc
@@ -183,9 +184,12 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=N
     kpad = dw.shape[1]
     if dw.shape[0] != cout or not dw.is_contiguous():
         raise ValueError("conv_wgrad: dw must be contiguous [Cout, Kpad]")
-    def launch(nb):
+    def launch(nb):          # nb: block count, or (tile kind 2 / 3, block count)
+        kind, nb = nb if isinstance(nb, tuple) else (int(variant), nb)
+        if variant:
+            kind = int(variant)              # an explicit kernel generation wins over a remembered tile kind
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, cout, ldg, p.kh, p.kw, p.stride, p.pad, p.dil, 0, kpad,
-                     CONV_STEM4 if p.stem else 0, int(variant) | (int(nb) << 8))
+                     CONV_STEM4 if p.stem else 0, int(kind) | (int(nb) << 8))
         nbytes = lib.pemp_conv2d_wgrad_workspace_bytes(C.byref(d))
         ws = _ws(nbytes, x.device, ws_cache, ("wgrad", nbytes))
         _lib.check(lib.pemp_conv2d_wgrad_nhwc_f32(C.byref(d), _p(x), _p(g), _p(dw), 1 if accumulate else 0, _p(ws),
@@ -207,8 +211,11 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=N
                     e1.record()
                     e1.synchronize()
                     return e0.elapsed_time(e1)
-                ms = {nb: timed(nb) for nb in WGRAD_BLOCK_CHOICES}
-                for nb in WGRAD_BLOCK_CHOICES:
+                cands = list(WGRAD_BLOCK_CHOICES)
+                if variant == 0 and not p.stem and cin % 128 == 0 and cout % 128 == 0:      # both tile sizes apply
+                    cands = [(k, nb) for k in (2, 3) for nb in WGRAD_BLOCK_CHOICES]
+                ms = {nb: timed(nb) for nb in cands}
+                for nb in cands:
                     ms[nb] = min(ms[nb], timed(nb))
                 blocks = min(ms, key=ms.get)
             _WGRAD_BLOCKS[key] = blocks

@@ -116,11 +116,18 @@ def test_wgrad_generations_bit_identical_and_match_autograd(hip_lib, dev, case):
     outs = []
     for variant in (1, 0):
         dw = torch.full((Cout, k * k * Cin), float("nan"), device=dev)
-        T.conv_wgrad(xd, gd, prm, dw, variant=variant)
+        T.conv_wgrad(xd, gd, prm, dw, variant=variant, blocks=0)          # the library's split for both: same reduction order
         outs.append(dw.clone())
-        T.conv_wgrad(xd, gd, prm, dw, accumulate=True, variant=variant)
+        T.conv_wgrad(xd, gd, prm, dw, accumulate=True, variant=variant, blocks=0)
         outs.append(dw.clone())
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
     scale = ref.abs().max().item()
     assert (outs[2].cpu() - ref).abs().max().item() <= 2e-5 * scale * max(1.0, (N * y.shape[2] * y.shape[3] / 4096) ** 0.5)
     assert (outs[3].cpu() - 2 * ref).abs().max().item() <= 4e-5 * scale * max(1.0, (N * y.shape[2] * y.shape[3] / 4096) ** 0.5)
+    # every (tile kind, block count) the autotuner may pick gives the same gradient up to the rounding of the regrouped sum
+    kinds = (2, 3) if Cin % 128 == 0 and Cout % 128 == 0 else (0,)
+    for kind in kinds:
+        for nb in T.WGRAD_BLOCK_CHOICES:
+            dw = torch.full((Cout, k * k * Cin), float("nan"), device=dev)
+            T.conv_wgrad(xd, gd, prm, dw, blocks=(kind, nb) if kind else nb)
+            assert (dw.cpu() - ref).abs().max().item() <= 2e-5 * scale * max(1.0, (N * y.shape[2] * y.shape[3] / 4096) ** 0.5), (kind, nb)
