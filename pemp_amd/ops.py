@@ -74,9 +74,26 @@ _TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared 
 #: optional JSON file the picks are loaded from / saved to (PEMP_TILE_CACHE=path): a profiling run can then replay a
 #: previous process' choices instead of timing the variants again under the profiler
 _TILE_CACHE_FILE = os.environ.get("PEMP_TILE_CACHE")
+WGRAD_PICKS = {}     # train_ops.conv_wgrad's per-shape picks ((tile kind, block count)); persisted in the same file
 if _TILE_CACHE_FILE and os.path.exists(_TILE_CACHE_FILE):
     with open(_TILE_CACHE_FILE) as _f:
-        _TILE_CACHE.update({tuple(json.loads(k)): int(v) for k, v in json.load(_f).items()})
+        for _k, _v in json.load(_f).items():
+            _key = json.loads(_k)
+            if _key and _key[0] == "wgrad":
+                WGRAD_PICKS[tuple(_key[1:])] = tuple(_v) if isinstance(_v, list) else int(_v)
+            else:
+                _TILE_CACHE[tuple(_key)] = int(_v)
+
+
+def save_picks():
+    """Write the conv tile picks and the weight-gradient picks to PEMP_TILE_CACHE (no-op without it): a later process --
+    a profiling run, or a training run that must reproduce this one bit for bit -- replays them instead of timing again."""
+    if not _TILE_CACHE_FILE:
+        return
+    out = {json.dumps([int(v) for v in k]): t for k, t in _TILE_CACHE.items()}
+    out.update({json.dumps(["wgrad"] + [int(v) for v in k]): (list(t) if isinstance(t, tuple) else t) for k, t in WGRAD_PICKS.items()})
+    with open(_TILE_CACHE_FILE, "w") as f:
+        json.dump(out, f)
 
 
 def _pick_tile(launch, p, key, cout, only=None):
@@ -105,9 +122,7 @@ def _pick_tile(launch, p, key, cout, only=None):
     final = {t: min(timed(t, 8), timed(t, 8)) for t in top}
     best = min(top, key=lambda t: final[t])
     _TILE_CACHE[key] = best
-    if _TILE_CACHE_FILE:
-        with open(_TILE_CACHE_FILE, "w") as f:
-            json.dump({json.dumps([int(v) for v in k]): t for k, t in _TILE_CACHE.items()}, f)
+    save_picks()
     return best
 
 

@@ -160,7 +160,7 @@ def relu_bias_bwd(dy, y, g, add=None, relu=True, want_dbias=True, ws_cache=None,
     return dbias
 
 
-_WGRAD_BLOCKS = {}      # (layer geometry, input shape) -> block count that measured fastest
+from .ops import WGRAD_PICKS as _WGRAD_BLOCKS      # (layer geometry, input shape) -> (tile kind, block count) that measured fastest
 WGRAD_BLOCK_CHOICES = (512, 768, 1024, 1536)
 
 
@@ -219,6 +219,7 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=N
                     ms[nb] = min(ms[nb], timed(nb))
                 blocks = min(ms, key=ms.get)
             _WGRAD_BLOCKS[key] = blocks
+            ops.save_picks()
     launch(blocks)
     return dw
 

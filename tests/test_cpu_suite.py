@@ -677,3 +677,23 @@ def test_commands_load_the_checkpoint_they_evaluate(tmp_path):
     from pemp_amd.entry import baseline as eb, panet as ep, pemp_stage1 as e1
     for fn in (e1.test, e1.visualize, e2.test, eb.test, ep.test):
         assert {"exp_id", "ckpt"} <= set(inspect.signature(getattr(fn, "__wrapped__", fn)).parameters), fn
+
+
+def test_autotune_picks_round_trip_through_the_cache_file(tmp_path):
+    """PEMP_TILE_CACHE: conv tile picks and weight-gradient (tile kind, block count) picks written by one process are what
+    the next process starts with (a training run that must repeat another one bit for bit replays its picks)."""
+    import subprocess, sys, json
+    f = tmp_path / "picks.json"
+    code = ("from pemp_amd import ops\n"
+            "print(sorted(ops._TILE_CACHE.items()), sorted(ops.WGRAD_PICKS.items(), key=str))\n"
+            "ops._TILE_CACHE[(256, 256, 3, 3, 1, 2, 2, 2, 8, 51, 51, 0, 0)] = 34\n"
+            "ops.WGRAD_PICKS[(256, 256, 3, 3, 1, 2, 2, False, 8, 51, 51)] = (2, 1024)\n"
+            "ops.WGRAD_PICKS[(64, 64, 1, 1, 1, 0, 1, False, 8, 101, 101)] = 512\n"
+            "ops.save_picks()\n")
+    env = dict(os.environ, PEMP_TILE_CACHE=str(f), PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    first = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert first.strip() == "[] []"
+    assert len(json.load(open(f))) == 3
+    second = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert "((256, 256, 3, 3, 1, 2, 2, 2, 8, 51, 51, 0, 0), 34)" in second
+    assert "(2, 1024)" in second and "512" in second
