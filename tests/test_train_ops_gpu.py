@@ -426,3 +426,35 @@ def test_cm_linear_bias_and_backward_match_autograd(hip_lib, dev):
     dfi2 = dfi.clone()
     T.cm_bias_bwd(colsum, feat, group, wext, dwfull[:, C:], dfi2, accumulate=True)
     assert torch.allclose(dfi2, 2 * dfi, rtol=1e-6)
+
+
+@pytest.mark.parametrize("case", [  # N, H, W, Cin, Cout, k, p, d, residual, relu
+    (8, 51, 51, 256, 256, 3, 2, 2, False, True), (8, 51, 51, 256, 1024, 1, 0, 1, True, True), (8, 51, 51, 1024, 256, 1, 0, 1, False, False),
+    (2, 51, 51, 128, 128, 3, 1, 1, True, False), (1, 9, 7, 64, 64, 1, 0, 1, False, True)])
+def test_split_k_conv_variants_match_the_unsplit_conv(hip_lib, dev, case):
+    """pemp_conv2d_splitk_nhwc_f32 (tile ids 31..37: the last round of tiles split along K, partial tiles through the
+    uncached workspace, fixed-order fix-up by the last block to arrive) against the unsplit variants: scale / shift /
+    residual / ReLU epilogue included; |d| <= 1e-5 max|y| (regrouped fp32 sum), bit-identical from launch to launch, and
+    bit-identical to the unsplit variant where the geometry leaves nothing to split."""
+    from pemp_amd import ops
+    N, H, W, Cin, Cout, k, p, d, with_res, relu = case
+    x = _nhwc(_rand(N, Cin, H, W, seed=1)).to(dev)
+    w = _rand(Cout, Cin, k, k, seed=2, lo=-0.1, hi=0.1)
+    packed, kpad = ops.pack_conv_weight(w.to(dev))
+    prm = ops.ConvParams(packed, _rand(Cout, seed=3, lo=0.5, hi=1.5).to(dev), _rand(Cout, seed=4).to(dev), Cin, Cout, k, k, 1, p, d,
+                         kpad, False, relu)
+    res = _nhwc(_rand(N, Cout, H, W, seed=5)).to(dev) if with_res else None
+    ref = ops.conv2d(x, prm, residual=res, tile=13)
+    lib = hip_lib
+    M = N * H * W
+    for tile in [t for t in ops.SPLITK_TILES if Cout % ops.TILE_VARIANTS[t - 10][1] == 0]:
+        y1 = ops.conv2d(x, prm, residual=res, tile=tile)
+        y2 = ops.conv2d(x, prm, residual=res, tile=tile)
+        assert torch.equal(y1, y2), tile
+        assert (y1 - ref).abs().max() <= 1e-5 * ref.abs().max(), tile
+        desc = ops.ConvDesc(N, H, W, Cin, Cin, H, W, Cout, Cout, k, k, 1, p, d, 0, kpad, 0, tile)
+        if lib.pemp_conv2d_splitk_workspace_bytes(ops.C.byref(desc)) == 0:       # nothing to split at this geometry
+            assert torch.equal(y1, ref), tile
+    if M >= 8 * 51 * 51:
+        desc = ops.ConvDesc(N, H, W, Cin, Cin, H, W, Cout, Cout, k, k, 1, p, d, 0, kpad, 0, 31)
+        assert lib.pemp_conv2d_splitk_workspace_bytes(ops.C.byref(desc)) > 0       # the training shapes do split
