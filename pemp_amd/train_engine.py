@@ -233,6 +233,35 @@ class SegmentedCapture:
         cur.wait_stream(side)
 
 
+def _enqueue_wgrad(flat, job, x, g, ws):
+    """Run ``job._wgrad_now(x, g, workspace cache)`` where weight gradients run: deferred into the side graph of the current
+    segment while a SegmentedCapture is recording, on the side stream behind an event otherwise, in place without one."""
+    if flat.capture is not None:
+        flat.capture.defer(job, x, g)
+        return
+    if flat.side_stream is None or x.shape[0] * x.shape[1] * x.shape[2] < 64:
+        return job._wgrad_now(x, g, ws)
+    ready = torch.cuda.Event()
+    ready.record()
+    flat.side_keep.append((x, g))                      # operands stay referenced until the join
+    with torch.cuda.stream(flat.side_stream):
+        flat.side_stream.wait_event(ready)
+        job._wgrad_now(x, g, flat.side_ws)
+
+
+class _SliceWgrad:
+    """Weight gradient of a 1x1 conv whose weight is a column slice of a larger matrix (ASPPV2's layer6 sees the global branch
+    and the four concatenated branches as two such slices): computed into a dense temporary, copied into the slice."""
+
+    def __init__(self, dst, cin, cout):
+        self.dst, self.prm = dst, ConvParams(None, None, None, cin, cout, 1, 1, 1, 0, 1, cin, False, False)
+
+    def _wgrad_now(self, x, g, ws):
+        tmp = torch.empty((self.prm.cout, self.prm.cin), dtype=torch.float32, device=x.device)
+        T.conv_wgrad(x, g, self.prm, tmp, ws_cache=ws)
+        self.dst.copy_(tmp)
+
+
 class _Conv:
     """Geometry + parameter handles of one conv; packed views are refreshed every step."""
 
@@ -265,18 +294,7 @@ class _Conv:
         so it is enqueued on the engine's side stream (after the event that says ``g`` is ready) and runs concurrently
         with the input-gradient / BatchNorm chain, filling the CUs those small-M kernels leave idle; the engine joins
         the side stream at the end of ``backward``."""
-        flat = self.flat
-        if flat.capture is not None:                           # recorded into the side graph of the current segment
-            flat.capture.defer(self, x, g)
-            return
-        if flat.side_stream is None or x.shape[0] * x.shape[1] * x.shape[2] < 64:
-            return self._wgrad_now(x, g, ws)
-        ready = torch.cuda.Event()
-        ready.record()
-        flat.side_keep.append((x, g))                      # operands stay referenced until the join
-        with torch.cuda.stream(flat.side_stream):
-            flat.side_stream.wait_event(ready)
-            self._wgrad_now(x, g, flat.side_ws)
+        _enqueue_wgrad(self.flat, self, x, g, ws)
 
     def _wgrad_now(self, x, g, ws):
         w = self.conv.weight
@@ -539,18 +557,12 @@ class Stage1TrainEngine:
         w6 = tp["w6"]
         dw6 = self.flat.krsc_grad(l6w)                              # [512, 1280] view of the gradient
         # layer6: main 1x1 conv over the 4 concatenated branches + per-image bias from the global branch
-        dw6m = self._new(l6w.shape[0], 4 * midc)
-        T.conv_wgrad(tp["cat"], dfeat, ConvParams(None, None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False),
-                     dw6m, ws_cache=self.ws)
-        dw6[:, midc:].copy_(dw6m)
+        _enqueue_wgrad(self.flat, _SliceWgrad(dw6[:, midc:], 4 * midc, l6w.shape[0]), tp["cat"], dfeat, self.ws)   # side stream
         dcat = conv2d(dfeat, ConvParams(T.dgrad_weight(w6[:, midc:].contiguous(), 1, 1), None, None, l6w.shape[0], 4 * midc,
                                             1, 1, 1, 0, 1, l6w.shape[0], False, False))
         s = ops.global_avgpool(dfeat) * float(hw)                   # per-image column sums [N, 512]
         self.l6.bias.grad.copy_(s.sum(dim=0))
-        dw6g = self._new(l6w.shape[0], midc)
-        T.conv_wgrad(tp["g0"], s.view(nimg, 1, 1, -1), ConvParams(None, None, None, midc, l6w.shape[0], 1, 1, 1, 0, 1, midc, False, False),
-                     dw6g, ws_cache=self.ws)
-        dw6[:, :midc].copy_(dw6g)
+        _enqueue_wgrad(self.flat, _SliceWgrad(dw6[:, :midc], midc, l6w.shape[0]), tp["g0"], s.view(nimg, 1, 1, -1), self.ws)
         dg0 = conv2d(s.view(nimg, 1, 1, -1), ConvParams(T.dgrad_weight(w6[:, :midc].contiguous(), 1, 1), None, None, l6w.shape[0],
                                                             midc, 1, 1, 1, 0, 1, l6w.shape[0], False, False))
         # branches 1..4

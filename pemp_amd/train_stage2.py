@@ -21,7 +21,7 @@ import torch
 
 from . import ops, train_ops as T
 from .ops import ConvParams
-from .train_engine import Stage1TrainEngine, Stage1Trainer, _BN, _Conv, conv2d
+from .train_engine import Stage1TrainEngine, Stage1Trainer, _BN, _Conv, _SliceWgrad, _enqueue_wgrad, conv2d
 
 _CM_STRIDES = (2, 1, 2)          # backbones.py:230,235,240
 
@@ -182,18 +182,12 @@ class Stage2TrainEngine(Stage1TrainEngine):
         cout = l6w.shape[0]
         w6 = tp["w6"]
         dw6 = self.flat.krsc_grad(l6w)
-        dw6m = self._new(cout, 4 * midc)
-        T.conv_wgrad(tp["catd"], dfeat, ConvParams(None, None, None, 4 * midc, cout, 1, 1, 1, 0, 1, 4 * midc, False, False),
-                     dw6m, ws_cache=self.ws)
-        dw6[:, midc:].copy_(dw6m)
+        _enqueue_wgrad(self.flat, _SliceWgrad(dw6[:, midc:], 4 * midc, cout), tp["catd"], dfeat, self.ws)      # side stream
         dcat = conv2d(dfeat, ConvParams(T.dgrad_weight(w6[:, midc:].contiguous(), 1, 1), None, None, cout, 4 * midc,
                                             1, 1, 1, 0, 1, cout, False, False))
         s = ops.global_avgpool(dfeat) * float(h * w)                          # per-image column sums [N, 512]
         self.l6.bias.grad.copy_(s.sum(dim=0))
-        dw6g = self._new(cout, midc)
-        T.conv_wgrad(tp["g0d"], s.view(nimg, 1, 1, -1), ConvParams(None, None, None, midc, cout, 1, 1, 1, 0, 1, midc, False, False),
-                     dw6g, ws_cache=self.ws)
-        dw6[:, :midc].copy_(dw6g)
+        _enqueue_wgrad(self.flat, _SliceWgrad(dw6[:, :midc], midc, cout), tp["g0d"], s.view(nimg, 1, 1, -1), self.ws)
         dg0 = conv2d(s.view(nimg, 1, 1, -1), ConvParams(T.dgrad_weight(w6[:, :midc].contiguous(), 1, 1), None, None, cout,
                                                             midc, 1, 1, 1, 0, 1, cout, False, False))
         dcat = self._drop_bwd(dcat, tp["ms"])
