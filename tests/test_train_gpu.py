@@ -399,3 +399,31 @@ def test_full_size_training_steps_are_reproducible(hip_lib, dev):
     assert any(t > 30 for t in ops._TILE_CACHE.values()), "no split-K variant was picked at the training shape"
     assert torch.isfinite(out[0][0]).all()
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_full_size_graph_chain_equals_the_eager_step(hip_lib, dev):
+    """The hipGraph chain against the eager step at BASELINE config 3's real shape (4 episodes of 401 x 401): the split-K
+    variants (arrival counters reset by the kernels themselves, uncached workspace) and the per-shape weight-gradient picks are
+    part of the recorded segments; weights after five steps (two eager warm-ups + three replays) are bit-identical."""
+    from pemp_amd import synth
+    from pemp_amd.networks import pemp_stage1 as m1
+    from pemp_amd.train_engine import Stage1Trainer
+    batches = []
+    for s in range(5):
+        b = synth.make_batch([900 + 4 * s + i for i in range(4)], shot=1, out_hw=(401, 401))
+        t = lambda a: torch.from_numpy(a).to(dev)
+        batches.append((t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0])))
+    warm = Stage1Trainer(m1.ModelClass(None), device=dev, drop_rate=0.0)
+    warm.train_step(*batches[0])                     # fills the autotune caches: both trainers below replay the same picks
+    out = []
+    for use_graph in (False, True):
+        net = m1.ModelClass(None)
+        net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+        tr = Stage1Trainer(net, device=dev, lr=2e-3, drop_rate=0.0, use_graph=use_graph)
+        losses = [tr.train_step(*bt) for bt in batches]
+        torch.cuda.synchronize()
+        if use_graph:
+            cap = next(iter(tr._graphs.values()))["cap"]
+            assert len(cap.main) >= 10 and sum(g is not None for g in cap.side) >= 10
+        out.append((torch.stack(losses).cpu(), tr.eng.flat.data.clone().cpu()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
