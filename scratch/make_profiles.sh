@@ -39,6 +39,12 @@ rm -rf $O/pmc_train
 timeout -k 10 600 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/pmc_train -- python3 bench.py --mode train --steps 5 --warmup 3 --cpu-episodes 0 --no-single --no-roofline > $O/pmc_train.log 2>&1 || echo "pmc train failed"
 python3 scratch/pmc_train_summary.py $O/pmc_train $O > /dev/null || echo "pmc train summary failed"
 rm -rf $O/pmc_train
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/pmct_$c
+  timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmct_$c -- python3 bench.py --mode train --steps 5 --warmup 3 --cpu-episodes 0 --no-single --no-roofline > $O/pmct_$c.log 2>&1 || echo "pmc train $c failed"
+done
+python3 scratch/pmc_train_traffic.py $O/pmct_FETCH_SIZE $O/pmct_WRITE_SIZE $O > /dev/null || echo "pmc train traffic failed"
+rm -rf $O/pmct_FETCH_SIZE $O/pmct_WRITE_SIZE
 # 4. prototype-head kernels beyond the Infinity Cache (60 / 100 queries: 320 / 533 MB per launch)
 for q in 25 60 100; do
   rm -rf $O/kt_head
