@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the staging-inclusive end_to_end figure")
     ap.add_argument("--no-single", action="store_true", help="skip the one-episode-per-step figure")
+    ap.add_argument("--no-sides", action="store_true", help="default line: skip the `train` / `stage2_5shot` objects")
     ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)        # internal: "<threads>" -> run one CPU-baseline leg
     return ap.parse_args()
 
@@ -68,21 +69,39 @@ def parse():
 # ---------------------------------------------------------------------------------------------
 # N > 1 without an external launcher: `python bench.py --gpus N` starts its own ranks
 # ---------------------------------------------------------------------------------------------
+def beat():
+    """Heartbeat of a rank started by ``launch_ranks``: touches the rank's file (PEMP_BENCH_HEARTBEAT) at every phase
+    boundary outside the timed region.  The launcher's silence watchdog reads the modification times."""
+    path = os.environ.get("PEMP_BENCH_HEARTBEAT")
+    if path:
+        with open(path, "a"):
+            os.utime(path, None)
+
+
 def launch_ranks(n):
     """Start ``n`` copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
     as torchrun would), wait for them and return the exit code: 0 only if every rank exited 0.  Runs BEFORE this
     process makes any GPU call (it never makes one): the children are fresh processes, nothing is re-exec'ed.  A rank
-    that dies takes the job down -- the survivors (blocked in a barrier) are terminated by PID."""
+    that dies takes the job down -- the survivors (blocked in a barrier) are terminated by PID.  Silence watchdog: every
+    rank touches a heartbeat file at each phase boundary (``beat``); when NO rank has done so for PEMP_BENCH_SILENCE_S
+    seconds (default 300 -- a rank stuck in a collective keeps the others waiting in theirs) all children are
+    terminated and the job exits 124."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    silence = float(os.environ.get("PEMP_BENCH_SILENCE_S", "300"))
+    hbdir = tempfile.mkdtemp(prefix="pemp_bench_hb_")
+    procs, beats = [], []
     for r in range(n):
+        hb = os.path.join(hbdir, f"rank{r}")
+        open(hb, "w").close()
+        beats.append(hb)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PEMP_BENCH_CHILD="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PEMP_BENCH_CHILD="1", PEMP_BENCH_HEARTBEAT=hb)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -100,9 +119,31 @@ def launch_ranks(n):
                     print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
                     for q in alive:
                         q.terminate()
+            if alive and rc == 0:
+                quiet = time.time() - max(os.path.getmtime(b) for b in beats)
+                if quiet > silence:
+                    rc = 124
+                    print(f"bench.py: no rank has made progress for {quiet:.0f} s (> {silence:.0f} s); stopping all "
+                          f"{len(alive)} rank(s) still running", file=sys.stderr)
+                    for q in alive:
+                        q.terminate()
+                    t_end = time.time() + 10
+                    while time.time() < t_end and any(q.poll() is None for q in alive):
+                        time.sleep(0.1)
+                    break
     finally:
         for q in alive:
-            q.kill()
+            if q.poll() is None:
+                q.kill()
+        for b in beats:
+            try:
+                os.unlink(b)
+            except OSError:
+                pass
+        try:
+            os.rmdir(hbdir)
+        except OSError:
+            pass
     return rc
 
 
@@ -112,6 +153,9 @@ def dry_run(args, world, rank):
     exit non-zero before the first barrier (the launcher must then fail the whole job)."""
     if os.environ.get("PEMP_BENCH_FAIL_RANK") == str(rank):
         raise SystemExit(3)
+    beat()
+    if os.environ.get("PEMP_BENCH_HANG_RANK") == str(rank):       # a rank that never reaches the collective the others wait in
+        time.sleep(3600)
     if world > 1:
         dist.init_process_group(os.environ.get("PEMP_BENCH_BACKEND", "gloo"))
         dist.barrier()
@@ -246,7 +290,8 @@ def instrumented(run, reps=3):
             if r == 1:
                 proxy.rec.clear()
             run(r)
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
     finally:
         _lib._lib = real
     return proxy.rec
@@ -395,6 +440,7 @@ def cpu_leg(args):
         per = B
         what = f"{len(times)} train step(s) of {B} episode(s) (oracle/ref_cpu.py train_step: train-mode forward, CE, autograd backward, clip, SGD)"
     else:
+        rows = []
         with torch.no_grad():
             for i in range(args.cpu_episodes + 1):
                 ep = synth.make_episode(5678 + i, shot=args.shot, index=i, dataset=args.dataset)
@@ -406,17 +452,25 @@ def cpu_leg(args):
                     fwd = lambda a, b, c, hw: ref_cpu.stage2_forward(sd2, a, b, c, prior, hw)
                 else:
                     fwd = lambda a, b, c, hw: ref_cpu.stage1_forward(sd, a, b, c, hw)
-                ref_cpu.test_step(fwd, (sup, msk, qry), gt)
+                pred, loss, _ = ref_cpu.test_step(fwd, (sup, msk, qry), gt)
                 dt = time.time() - t0
                 if i > 0:                      # first episode warms the allocator / oneDNN primitives
                     times.append(dt)
+                # outside the timed region: the episode's tp/fp/fn row (core/metrics.py:9-23) for the mIoU comparison
+                m = ref_cpu.FewShotMetric(80)
+                m.update(pred, gt.numpy(), [int(ep["cls"])])
+                rows.append({"seed": 5678 + i, "index": i, "shot": args.shot, "dataset": args.dataset, "cls": int(ep["cls"]),
+                             "counts": [float(v) for v in np.r_[m.stat[0], m.stat[int(ep["cls"])]]], "loss": loss})
                 if sum(times) > budget:
                     break
         per = 1
         what = f"{len(times)} episodes (seeds 5679..), oracle/ref_cpu.py test_step"
     tot = sum(times)
-    print(json.dumps({"value": round(len(times) * per / tot, 3), "threads": threads,
-                      "sample": f"{what}, torch {torch.__version__} CPU, {threads} thread(s), median {np.median(times) * 1e3:.0f} ms/step"}))
+    res = {"value": round(len(times) * per / tot, 3), "threads": threads,
+           "sample": f"{what}, torch {torch.__version__} CPU, {threads} thread(s), median {np.median(times) * 1e3:.0f} ms/step"}
+    if args.mode != "train":
+        res["episodes"] = rows
+    print(json.dumps(res))
 
 
 def cpu_baseline(args):
@@ -445,6 +499,8 @@ def cpu_baseline(args):
     if "error" in main:
         return main
     out = {"value": main["value"], "unit": "episodes/s", "cores": cores, "kind": "port", "sample": main["sample"]}
+    if "episodes" in main:
+        out["episodes"] = main["episodes"]         # per-episode tp/fp/fn rows: consumed by miou_vs_cpu, not printed
     one = legs.get(1, {})
     out["one_thread"] = {"value": one.get("value"), "cores": 1, "sample": one.get("sample", one.get("error"))}
     return out
@@ -523,60 +579,151 @@ def single_episode(net, dev, args, n=120):
         key = "value" if lanes == 1 else f"value_{lanes}_in_flight"
         out[key] = round(n / dt, 2)
         out["ms_per_episode" if lanes == 1 else f"ms_per_episode_{lanes}_in_flight"] = round(dt / n * 1e3, 4)
+    # The reference's Evaluator.test_step body as written (entry/pemp_stage1.py:48-53): host tensors in, three .cuda()
+    # copies, forward, loss.item() and argmax .cpu().numpy() out -- two host synchronisations per episode.
+    ev = Evaluator(net, device=dev)
+    host = [(tuple(x.cpu() for x in ins), msk.cpu()) for ins, msk in eps]
+    for ins, msk in host:
+        ev.test_step(ins, msk)
+    torch.cuda.synchronize()
+    m = max(20, n // 2)
+    t0 = time.perf_counter()
+    for i in range(m):
+        pred, loss = ev.test_step(*host[i % len(host)])
+    dt = time.perf_counter() - t0
+    assert pred.ndim == 3 and np.isfinite(loss)
+    out["reference_body"] = {"value": round(m / dt, 2), "ms_per_episode": round(dt / m * 1e3, 4),
+                             "what": "Evaluator.test_step as the reference writes it: host tensors -> 3 H2D copies -> forward -> "
+                                     "loss float + argmax numpy on the host, every episode (pageable host memory, no overlap)"}
     out.update(unit="episodes/s", episodes_per_step=1,
                protocol="one episode per test_step (reference data.test_bs = 1), hipGraph replay, statistics fetched once per round")
     return out
 
 
 # ---------------------------------------------------------------------------------------------
-# --mode train
+# training step (--mode train, and the ``train`` object of the default line)
 # ---------------------------------------------------------------------------------------------
-def main_train(args, world, rank, dev):
-    """Trainer.train_step (reference entry/pemp_stage1.py:57-65) on `--batch` episodes per rank (the reference's
-    data.bs = 4), data-parallel: bucketed flat-gradient all-reduce over RCCL, overlapped with backward."""
-    from pemp_amd import synth
+def stub_trainer(rank):
+    """PEMP_BENCH_STUB=1 (tests; CPU, gloo): the REAL ``Stage1Trainer.train_step`` / ``reduce_gradients`` / ``GradBuckets``
+    control flow -- bucket hooks fired during "backward", finished in the optimizer step, the ``collectives`` switch --
+    over a 64 K-float flat buffer, with two lines of arithmetic in place of the HIP kernels."""
+    from pemp_amd.train_engine import GradBuckets, Stage1Trainer
+
+    class _NS:
+        pass
+
+    class Stub(Stage1Trainer):
+        def __init__(self):
+            n = 1 << 16
+            f, e = _NS(), _NS()
+            f.data, f.grad, f.side_stream = torch.zeros(n), torch.zeros(n), None
+            e.flat, e.ws = f, {}
+            e.buckets = GradBuckets(f.grad, [n // 4, n // 2, 3 * n // 4], min_bytes=n)        # four buckets of 64 KB
+            self.eng, self.use_graph, self.optimizer, self.calls, self.device = e, False, None, 0, torch.device("cpu")
+
+        def forward_backward(self, *ins):
+            f, b = self.eng.flat, self.eng.buckets
+            n = f.grad.numel()
+            f.grad.fill_(float(rank + 1))                   # rank r's gradient: r + 1 everywhere
+            for lo in (3 * n // 4, n // 2, n // 4, 0):      # "backward" finishes the buffer from its end
+                b.ready_from(lo)
+            self.calls += 1
+            return torch.tensor(float(self.calls)), None
+
+        def apply_update(self, scale):
+            self.eng.flat.data.add_(self.eng.flat.grad * scale, alpha=-0.1)
+
+    return Stub()
+
+
+def make_trainer(model, shot, dev, rank, use_graph=False):
+    if os.environ.get("PEMP_BENCH_STUB"):
+        return stub_trainer(rank)
     from pemp_amd.train_engine import Stage1Trainer
     net, _ = build_model(None, "stage1", 1)
-    # eager by default: the weight-gradient kernels run on a side stream concurrently with the input-gradient chain
-    use_graph = args.train_graph
-    s2 = args.model == "stage2"
-    if s2:          # frozen stage-1 prior + stage-2 step (entry/pemp_stage2.py:72-83)
+    if model == "stage2":          # frozen stage-1 prior + stage-2 step (entry/pemp_stage2.py:72-83)
         from pemp_amd.train_stage2 import Stage2Trainer
-        net2, _ = build_model(None, "stage2", args.shot)
-        tr = Stage2Trainer(net.to(dev).eval(), net2, device=dev, use_graph=use_graph)
-    else:
-        tr = Stage1Trainer(net, device=dev, use_graph=use_graph)
-    B = args.batch
+        net2, _ = build_model(None, "stage2", shot)
+        return Stage2Trainer(net.to(dev).eval(), net2, device=dev, use_graph=use_graph)
+    # eager by default: the weight-gradient kernels run on a side stream concurrently with the input-gradient chain
+    return Stage1Trainer(net, device=dev, use_graph=use_graph)
+
+
+def train_pool(dev, rank, shot, B, groups=3):
+    from pemp_amd import synth
     pool = []
-    for g in range(3):
-        b = synth.make_batch([1234 + 1000 * rank + g * B + i for i in range(B)], shot=args.shot, out_hw=(401, 401))
+    for g in range(groups):
+        b = synth.make_batch([1234 + 1000 * rank + g * B + i for i in range(B)], shot=shot, out_hw=(401, 401))
         pool.append(tuple(torch.from_numpy(b[k]).to(dev) for k in ("sup_img", "sup_mask", "qry_img")) +
                     (torch.from_numpy(b["qry_mask"][:, 0]).to(dev),))
-    for i in range(args.warmup):
+    return pool
+
+
+def device_sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed_train_steps(tr, pool, steps, warmup, world, dev):
+    """W untimed + K timed ``train_step`` calls between barriers -> (seconds [MAX over ranks], host ms per step, losses)."""
+    for i in range(warmup):
         tr.train_step(*pool[i % len(pool)])
+        beat()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync(dev)
 
     barrier()
     t0 = time.perf_counter()
     losses = []
     host = 0.0
-    for i in range(args.steps):
+    for i in range(steps):
         h0 = time.perf_counter()
         losses.append(tr.train_step(*pool[i % len(pool)]))
         host += time.perf_counter() - h0
     barrier()
     dt = time.perf_counter() - t0
-    host_ms = host / args.steps * 1e3          # host time to enqueue one step (no synchronisation inside)
+    beat()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ls = torch.stack(losses).cpu().numpy()
     assert np.isfinite(ls).all()
+    return dt, host / steps * 1e3, ls
+
+
+def train_roofline(tr, pool, step_ms, reps=2):
+    """Per-kernel durations of the training step: an instrumented eager pass on ONE stream (kernels of the two streams
+    overlap in the timed step) and -- it may run on one rank alone -- with every gradient collective switched off
+    (``collectives`` False: no bucket hook, no all-reduce in the optimizer step)."""
+    flat = tr.eng.flat
+    side, bside, ug, coll = flat.side_stream, tr.eng.buckets.side, tr.use_graph, tr.collectives
+    flat.side_stream = tr.eng.buckets.side = None
+    tr.use_graph, tr.collectives = False, False
+    try:
+        rec = instrumented(lambda r: tr.train_step(*pool[r % len(pool)]), reps=reps)
+    finally:
+        flat.side_stream, tr.eng.buckets.side, tr.use_graph, tr.collectives = side, bside, ug, coll
+    r = summarize(rec, reps, step_ms)
+    r["note"] = ("per-kernel durations from a single-stream, rank-local eager pass; the timed step overlaps the weight-gradient "
+                 "kernels with the input-gradient chain on a side stream%s (step_effective_tflops = conv flops / timed step)"
+                 % (" and replays a chain of hipGraph segments" if ug else ""))
+    return r
+
+
+def main_train(args, world, rank, dev):
+    """Trainer.train_step (reference entry/pemp_stage1.py:57-65) on `--batch` episodes per rank (the reference's
+    data.bs = 4), data-parallel: bucketed flat-gradient all-reduce over RCCL, overlapped with backward."""
+    use_graph = args.train_graph
+    s2 = args.model == "stage2"
+    tr = make_trainer(args.model, args.shot, dev, rank, use_graph)
+    B = args.batch
+    pool = train_pool(dev, rank, args.shot, B)
+    beat()
+    dt, host_ms, ls = timed_train_steps(tr, pool, args.steps, args.warmup, world, dev)
     out = None
     if rank == 0:
         step_ms = dt / args.steps * 1e3
@@ -590,32 +737,21 @@ def main_train(args, world, rank, dev):
                                    "ResNet-50, %d-shot, 401x401, %d episodes/rank/step, synthetic E(seed) episodes + Wgen weights" % (args.shot, B),
                        "episodes_per_step": B, "shot": args.shot, "hipgraph": use_graph, "host_enqueue_ms_per_step": round(host_ms, 2),
                        "first_loss": round(float(ls[0]), 5), "last_loss": round(float(ls[-1]), 5)}}
+        if os.environ.get("PEMP_BENCH_STUB"):
+            out["config"]["stub_weight"] = float(tr.eng.flat.data[0])      # before the rank-local roofline pass
 
         def guarded(key, fn):
             try:
                 out[key] = fn()
             except Exception as exc:  # noqa: BLE001
                 out[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            beat()
 
         if not args.no_roofline:
-            def roof():
-                # kernels of the two streams overlap in the timed step; for per-kernel durations the instrumented pass
-                # keeps everything on one stream (same kernels, same operands)
-                flat = tr.eng.flat
-                side, bside, ug = flat.side_stream, tr.eng.buckets.side, tr.use_graph
-                flat.side_stream = tr.eng.buckets.side = None
-                tr.use_graph = False
-                try:
-                    rec = instrumented(lambda r: tr.train_step(*pool[r % len(pool)]), reps=2)
-                finally:
-                    flat.side_stream, tr.eng.buckets.side, tr.use_graph = side, bside, ug
-                r = summarize(rec, 2, step_ms)
-                r["note"] = ("per-kernel durations from a single-stream eager pass; the timed step overlaps the weight-gradient kernels "
-                             "with the input-gradient chain on a side stream%s (step_effective_tflops = conv flops / timed step)"
-                             % (" and replays a chain of hipGraph segments" if use_graph else ""))
-                return r
-            guarded("roofline", roof)
-        if world == 1 and args.cpu_episodes > 0:
+            # rank 0 alone runs these extra steps while the other ranks wait in the barrier below: the pass is rank-local
+            # by construction (train_roofline switches every collective of the step off)
+            guarded("roofline", lambda: train_roofline(tr, pool, step_ms))
+        if world == 1 and args.cpu_episodes > 0 and not os.environ.get("PEMP_BENCH_STUB"):
             guarded("cpu_baseline", lambda: cpu_baseline(args))
     if world > 1:
         dist.barrier()
@@ -624,9 +760,136 @@ def main_train(args, world, rank, dev):
         print(json.dumps(out))
 
 
+def side_train(dev, model="stage1", shot=1, batch=4, steps=10, warmup=4):
+    """The training step (BASELINE.json configs[2]; the reference's data.bs = 4) measured inside the default run, so that it
+    sits under the driver's clock too: same code as ``--mode train``, compact record."""
+    tr = make_trainer(model, shot, dev, 0)
+    pool = train_pool(dev, 0, shot, batch)
+    dt, host_ms, ls = timed_train_steps(tr, pool, steps, warmup, 1, dev)
+    step_ms = dt / steps * 1e3
+    r = train_roofline(tr, pool, step_ms, reps=1)
+    eff = r.get("step_effective_tflops", 0.0)
+    return {"workload": "pemp_%s train_step, ResNet-50, %d-shot, 401x401, %d episodes/step (see --mode train)" % (model, shot, batch),
+            "episodes_per_step": batch, "steps": steps, "warmup": warmup, "ms_per_step": round(step_ms, 3),
+            "episodes_per_s": round(steps * batch / dt, 2), "host_enqueue_ms_per_step": round(host_ms, 2),
+            "gflop_per_step": r["gflop_per_step"], "step_effective_tflops": eff,
+            "frac": round(eff / PEAK_F32_MFMA_TFLOPS, 4), "kernel_frac": r["frac"],
+            "kernel_ms_by_class": {k: v["ms_per_step"] for k, v in r["by_class"].items()},
+            "last_loss": round(float(ls[-1]), 5),
+            "note": "frac = conv + weight-gradient flops of a step / timed step / fp32 MFMA peak; kernel_frac = the same flops / "
+                    "the summed durations of those kernels in a single-stream pass"}
+
+
 # ---------------------------------------------------------------------------------------------
-# eval (headline)
+# eval
 # ---------------------------------------------------------------------------------------------
+class EvalRunner:
+    """The device work of Evaluator.test_step for ``batch`` resident episodes: hipGraph replay of the shape-static part +
+    the fused tail; ``model`` stage2 = stage-1 prior pass + stage 2 (entry/pemp_stage2.py:53-61)."""
+
+    def __init__(self, dev, rank, model="stage1", shot=1, batch=25, dataset="PASCAL", steps=40):
+        from pemp_amd import ops
+        self.ops, self.model, self.shot, self.batch = ops, model, shot, batch
+        self.vgg = model in ("baseline", "panet")
+        self.net, _ = build_model(dev, model if self.vgg else "stage1", shot)
+        self.stage2 = build_model(dev, "stage2", shot)[0] if model == "stage2" else None
+        self.pool = episode_pool(dev, shot, batch, rank, dataset=dataset)
+        self.ws, self.ws_align, self.aux_log = {}, {}, []
+        self.stats_log = torch.zeros((steps, batch, 8), dtype=torch.float64, device=dev)
+
+    def step(self, i, log=True, graph=True):
+        ops, net, stage2 = self.ops, self.net, self.stage2
+        ep = self.pool[i % len(self.pool)]
+        ins = (ep["sup_img"], ep["sup_mask"], ep["qry_img"])
+        with torch.no_grad():
+            pred, _ = net.lowres_graphed(*ins) if graph else net.lowres(*ins)
+            if stage2 is not None:
+                prior, _, _ = ops.eval_tail(pred, None, out_hw=ins[0].shape[-2:], ws_cache=self.ws)
+                prior = prior.unsqueeze(1).float()
+                pred, _ = stage2.lowres_graphed(*ins, prior) if graph else stage2.lowres(*ins, prior)
+            if self.model == "panet":       # auxiliary prototype-alignment loss of every episode (entry/panet.py:51-57)
+                from pemp_amd.networks.panet import align_forward
+                self.aux_log.append(align_forward(net._last_feats, pred, ins[1], ins[0].shape[0], self.shot, 1, 20, self.ws_align)["loss"])
+            am, stats, _ = ops.eval_tail(pred, ep["qry_mask"], ws_cache=self.ws)
+        if log:
+            self.stats_log[i].copy_(stats)
+        return am
+
+    def timed(self, steps, warmup, world, dev):
+        for i in range(warmup):
+            self.step(i, log=False)
+            beat()
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        beat()
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        # sanity on the logged statistics (the work really happened): finite losses, counts add up
+        st = self.stats_log[:steps].cpu().numpy()
+        assert np.isfinite(st).all() and (st[..., 1] > 0).all(), "eval tail produced invalid statistics"
+        return dt, float((st[..., 0] / st[..., 1]).mean())
+
+
+def side_stage2(dev, shot=5, batch=8, steps=8, warmup=3):
+    """BASELINE.json configs[3] inside the default run: stage-1 prior + stage 2, 5-shot, 8 episodes per step."""
+    run = EvalRunner(dev, 0, "stage2", shot, batch, steps=steps)
+    dt, mean_loss = run.timed(steps, warmup, 1, dev)
+    step_ms = dt / steps * 1e3
+    rec = instrumented(lambda r: run.step(r, log=False, graph=False), reps=1)
+    r = summarize(rec, 1, step_ms)
+    return {"workload": "pemp_stage1 prior + pemp_stage2 eval test_step, ResNet-50, %d-shot, 401x401, %d episodes/step" % (shot, batch),
+            "episodes_per_step": batch, "steps": steps, "warmup": warmup, "ms_per_step": round(step_ms, 3),
+            "episodes_per_s": round(steps * batch / dt, 2), "gflop_per_step": r["gflop_per_step"],
+            "step_effective_tflops": r.get("step_effective_tflops"),
+            "frac": round(r.get("step_effective_tflops", 0.0) / PEAK_F32_MFMA_TFLOPS, 4), "kernel_frac": r["frac"],
+            "mean_ce_loss": round(mean_loss, 6)}
+
+
+def miou_vs_cpu(net, dev, cpu):
+    """mIoU of the episodes the CPU baseline leg evaluated (the reference prints mIoU and speed together,
+    core/base_trainer.py:84-100): the same E(seed) episodes through Evaluator.test_step_device, the tp/fp/fn rows through
+    FewShotMetric on both sides."""
+    from pemp_amd import synth
+    from pemp_amd.core.metrics import FewShotMetric
+    from pemp_amd.entry.pemp_stage1 import Evaluator
+    eps = cpu.get("episodes") or []
+    if not eps:
+        return {"error": "the CPU leg returned no per-episode rows"}
+    ev = Evaluator(net, device=dev)
+    labels = synth.val_labels(0, eps[0].get("dataset", "PASCAL"))
+    nclass = 20 if eps[0].get("dataset", "PASCAL") == "PASCAL" else 80
+    m_gpu, m_cpu = FewShotMetric(nclass), FewShotMetric(nclass)
+    dloss, same = 0.0, 0
+    t = lambda a: torch.from_numpy(a)[None]
+    for e in eps:
+        ep = synth.make_episode(e["seed"], shot=e["shot"], index=e["index"], dataset=e.get("dataset", "PASCAL"))
+        _, stats = ev.test_step_device((t(ep["sup_img"]), t(ep["sup_mask"]), t(ep["qry_img"])), t(ep["qry_mask"]))
+        st = stats.cpu().numpy()
+        m_gpu.update_counts(st[:, 2:], [e["cls"]])
+        m_cpu.update_counts(np.asarray(e["counts"], np.float64)[None], [e["cls"]])
+        dloss = max(dloss, abs(float(st[0, 0] / st[0, 1]) - e["loss"]))
+        same += int(np.array_equal(st[0, 2:], np.asarray(e["counts"], np.float64)))
+    seen = [c for c in labels if m_cpu.stat[c].sum() > 0]
+    mg, mc = float(m_gpu.mIoU(seen)[1]), float(m_cpu.mIoU(seen)[1])
+    bg, bc = float(m_gpu.mIoU(seen, binary=True)[1]), float(m_cpu.mIoU(seen, binary=True)[1])
+    return {"miou": round(mg, 6), "miou_cpu": round(mc, 6), "delta_miou_vs_cpu": round(abs(mg - mc), 8),
+            "biou": round(bg, 6), "delta_biou_vs_cpu": round(abs(bg - bc), 8), "episodes": len(eps), "classes": len(seen),
+            "episodes_with_identical_pixel_counts": same, "max_abs_delta_ce_loss": round(dloss, 8),
+            "note": "synthetic E(seed) episodes + Wgen weights: the value says nothing about PASCAL accuracy, the delta is the parity figure"}
+
+
 def main():
     args = parse()
     if args.cpu_leg:
@@ -642,6 +905,14 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     if os.environ.get("PEMP_BENCH_DRYRUN"):
         return dry_run(args, world, rank)
+    beat()
+    if os.environ.get("PEMP_BENCH_STUB"):          # tests: main_train's real control flow on CPU tensors over gloo
+        if args.mode != "train":
+            raise SystemExit("PEMP_BENCH_STUB drives --mode train only")
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        return main_train(args, world, rank, torch.device("cpu"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # PEMP_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
@@ -657,68 +928,25 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    from pemp_amd import build, ops
+    from pemp_amd import build
     if first_local:
         build.build()                 # normally a no-op: the prebuilt .so travels with the snapshot
     if world > 1:
         dist.barrier()
+    beat()
     if args.mode == "train":
         return main_train(args, world, rank, dev)
     vgg = args.model in ("baseline", "panet")
-    net, _ = build_model(dev, args.model if vgg else "stage1", args.shot)
-    pool = episode_pool(dev, args.shot, args.batch, rank, dataset=args.dataset)
-    ws = {}
-    stats_log = torch.zeros((args.steps, args.batch, 8), dtype=torch.float64, device=dev)
-
-    aux_log, ws_align = [], {}
-    stage2 = build_model(dev, "stage2", args.shot)[0] if args.model == "stage2" else None   # configs[3]: stage-1 prior + stage 2
-
-    def step(i, log=True, graph=not args.no_graph):
-        ep = pool[i % len(pool)]
-        ins = (ep["sup_img"], ep["sup_mask"], ep["qry_img"])
-        with torch.no_grad():
-            pred, _ = net.lowres_graphed(*ins) if graph else net.lowres(*ins)
-            if stage2 is not None:
-                prior, _, _ = ops.eval_tail(pred, None, out_hw=ins[0].shape[-2:], ws_cache=ws)
-                prior = prior.unsqueeze(1).float()
-                pred, _ = stage2.lowres_graphed(*ins, prior) if graph else stage2.lowres(*ins, prior)
-            if args.model == "panet":       # auxiliary prototype-alignment loss of every episode (entry/panet.py:51-57)
-                from pemp_amd.networks.panet import align_forward
-                aux_log.append(align_forward(net._last_feats, pred, ins[1], ins[0].shape[0], args.shot, 1, 20, ws_align)["loss"])
-            am, stats, _ = ops.eval_tail(pred, ep["qry_mask"], ws_cache=ws)
-        if log:
-            stats_log[i].copy_(stats)
-        return am
-
-    for i in range(args.warmup):
-        step(i, log=False)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    # sanity on the logged statistics (the work really happened): finite losses, counts add up
-    st = stats_log.cpu().numpy()
-    assert np.isfinite(st).all() and (st[..., 1] > 0).all(), "eval tail produced invalid statistics"
-    mean_loss = float((st[..., 0] / st[..., 1]).mean())
+    run = EvalRunner(dev, rank, args.model, args.shot, args.batch, args.dataset, args.steps)
+    net, pool = run.net, run.pool
+    beat()
+    dt, mean_loss = run.timed(args.steps, args.warmup, world, dev)
 
     out = None
     if rank == 0:
         eps_total = args.steps * args.batch * world
         name = "Baseline" if args.model == "baseline" else "PANet" if args.model == "panet" else \
-            "PEMP stage-1" if stage2 is None else "PEMP stage-1 prior + stage-2"
+            "PEMP stage-1" if run.stage2 is None else "PEMP stage-1 prior + stage-2"
         dsn = "PASCAL-5i" if args.dataset == "PASCAL" else "COCO-20i"
         step_ms = dt / args.steps * 1e3
         out = {
@@ -727,7 +955,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s eval test_step, %s, %d-shot, 401x401, %d episode(s)/step, %s-shaped "
-                                   "synthetic E(seed) episodes + Wgen(1234) weights" % (
+                                   "synthetic E(seed) episodes + Wgen(1234) weights; episodes resident in HBM when the timed "
+                                   "region starts, statistics fetched once after it (the reference's Timer region also holds the "
+                                   "three H2D copies and the argmax/loss D2H of every episode: that figure is `end_to_end` and "
+                                   "`single_episode.reference_body`)" % (
                                        args.model if vgg else "pemp_" + args.model, "VGG-16" if vgg else "ResNet-50",
                                        args.shot, args.batch, dsn),
                        "episodes_per_step": args.batch, "shot": args.shot, "hipgraph": not args.no_graph,
@@ -739,20 +970,30 @@ def main():
                 out[key] = fn()
             except Exception as exc:  # noqa: BLE001
                 out[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            beat()
 
         if not args.no_roofline:
             def roof():
-                rec = instrumented(lambda r: step(r, log=False, graph=False), reps=3)
+                rec = instrumented(lambda r: run.step(r, log=False, graph=False), reps=3)
                 r = summarize(rec, 3, step_ms)
                 r["cosine_kernel"] = cosine_roofline(net, pool)
                 return attach_pmc(r, f"{args.model}-eval-b{args.batch}-s{args.shot}")
             guarded("roofline", roof)
-        if world == 1 and args.model == "stage1" and not args.no_graph and not args.no_single:
+        headline = world == 1 and args.model == "stage1" and not args.no_graph
+        if headline and not args.no_single:
             guarded("single_episode", lambda: single_episode(net, dev, args))
-        if world == 1 and args.model == "stage1" and not args.no_graph and not args.no_e2e and args.dataset == "PASCAL":
+        if headline and not args.no_e2e and args.dataset == "PASCAL":
             guarded("end_to_end", lambda: end_to_end(net, args, dev))
         if world == 1 and args.cpu_episodes > 0 and not vgg:
             guarded("cpu_baseline", lambda: cpu_baseline(args))
+            if args.model == "stage1" and isinstance(out["cpu_baseline"], dict) and "episodes" in out["cpu_baseline"]:
+                rows = {"episodes": out["cpu_baseline"].pop("episodes")}
+                guarded("miou", lambda: miou_vs_cpu(net, dev, rows))
+        # the other BASELINE.json configurations, measured in this process so that they sit under the driver's clock too
+        if headline and args.dataset == "PASCAL" and args.shot == 1 and not args.no_sides:
+            del run
+            guarded("train", lambda: side_train(dev))
+            guarded("stage2_5shot", lambda: side_stage2(dev))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -220,6 +220,22 @@ class SegmentedCapture:
         self.keep = []                     # all segments recorded: nothing can be handed their memory any more
         self.events = [torch.cuda.Event() for _ in self.main]
 
+    def abort(self):
+        """The recorded step raised: leave capture mode with the trainer usable again (the caller re-raises the original
+        error).  The open graph is ended -- an invalidated capture raises here, which is swallowed: the first error is the
+        one that matters -- nothing recorded so far is kept, weight gradients stop being deferred, the capture stream's
+        context is left."""
+        try:
+            if self.cur is not None:
+                self.cur.capture_end()
+        except Exception:  # noqa: BLE001
+            pass
+        self.cur = None
+        self.main, self.side, self.keep, self.pending = [], [], [], []
+        self.flat.capture = None
+        self._ctx.__exit__(None, None, None)
+        torch.cuda.current_stream().wait_stream(self.cs)
+
     def replay(self):
         cur, side = torch.cuda.current_stream(), self.flat.side_stream
         side.wait_stream(cur)              # the side graphs must not start before this step's inputs / zeroed gradients
@@ -724,6 +740,10 @@ class Stage1Trainer:
         self.loss_obj = losses.get({"loss": loss, "sigma": sigma})
 
     map_full_res = False          # Baseline: masked average pooling over bilinearly up-sampled features
+    #: False = a rank-LOCAL step: no gradient collective at all (bucket hooks off, no all-reduce in the optimizer step).
+    #: For passes that only one rank runs (bench.py's instrumented roofline pass): a collective issued by one rank alone
+    #: would pair with whatever the other ranks issue next.
+    collectives = True
 
     def encode(self, sup_img, sup_mask, qry_img, qry_prior=None):
         """Train-mode encoder forward -> NHWC features [B*S + B*Q, h, w, c] (supports first); tape kept in the engine."""
@@ -772,7 +792,7 @@ class Stage1Trainer:
 
     def train_step(self, sup_img, sup_mask, qry_img, qry_msk=None):
         ins = (sup_img.to(self.device), sup_mask.to(self.device), qry_img.to(self.device), qry_msk.to(self.device))
-        self.eng.buckets.enabled = not self.use_graph      # eager step: gradient buckets are all-reduced during backward
+        self.eng.buckets.enabled = self.collectives and not self.use_graph   # eager step: buckets are all-reduced during backward
         loss = self._graphed_forward_backward(*ins) if self.use_graph else self.forward_backward(*ins)[0]
         self.optimizer_step()                               # finishes / waits for the buckets
         self.eng.buckets.enabled = False
@@ -796,8 +816,11 @@ class Stage1Trainer:
             cap.begin()
             try:
                 loss, _ = self.forward_backward(*static)
-            finally:
-                cap.end()
+            except BaseException:
+                cap.abort()                # keeps the original error; the next call records again
+                ent["calls"] = 0
+                raise
+            cap.end()
             ent.update(cap=cap, static=static, loss=loss)
         for s_, t in zip(ent["static"], ins):
             s_.copy_(t, non_blocking=True)
@@ -809,13 +832,23 @@ class Stage1Trainer:
         ``pemp_amd.core.solver.get`` with its LR scheduler -- as the source of hyper-parameters of every step."""
         self.optimizer = optimizer
 
+    def reduce_gradients(self):
+        """The step's gradient collective: finishes / waits for the buckets launched during backward (or all-reduces the whole
+        flat buffer when none was) and returns the factor that turns the SUM into the mean; 1.0 without touching the
+        process group for a rank-local step (``collectives`` False)."""
+        if not self.collectives:
+            return 1.0
+        return self.eng.buckets.finish() if self.eng.buckets.next else allreduce_gradients(self.eng.flat.grad)
+
     def optimizer_step(self):
-        f = self.eng.flat
         if self.optimizer is not None:
             g = self.optimizer.param_groups[0]
             self.lr, self.momentum, self.wd = g["lr"], g.get("momentum", 0.0), g.get("weight_decay", 0.0)
             self.nesterov = bool(g.get("nesterov", False))
-        scale = self.eng.buckets.finish() if self.eng.buckets.next else allreduce_gradients(f.grad)
+        self.apply_update(self.reduce_gradients())
+
+    def apply_update(self, scale):
+        f = self.eng.flat
         if self.optimizer is not None and not isinstance(self.optimizer, torch.optim.SGD):
             # any other torch optimizer (tr.opt=adam, core/solver.py:92-96) steps on the parameter views itself
             if scale != 1.0:

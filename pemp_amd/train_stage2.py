@@ -277,7 +277,7 @@ class Stage2Trainer(Stage1Trainer):
     def train_step(self, sup_img, sup_mask, qry_img, qry_msk=None, qry_prior=None):
         ins = [t.to(self.device) for t in (sup_img, sup_mask, qry_img, qry_msk)]
         ins.append(self.prior(*ins[:3]) if qry_prior is None else qry_prior.to(self.device))
-        self.eng.buckets.enabled = not self.use_graph      # purifier / ASPP bucket goes out under the trunk's backward
+        self.eng.buckets.enabled = self.collectives and not self.use_graph   # purifier / ASPP bucket goes out under the trunk's backward
         loss = self._graphed_forward_backward(*ins) if self.use_graph else self.forward_backward(*ins)[0]
         self.optimizer_step()
         self.eng.buckets.enabled = False

@@ -168,7 +168,10 @@ def _run_bench(extra_env, *argv):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PEMP_BENCH_DRYRUN="1", PEMP_BENCH_BACKEND="gloo", **extra_env)
+    env = dict(os.environ, PEMP_BENCH_DRYRUN="1", PEMP_BENCH_BACKEND="gloo")
+    env.update(extra_env)
+    if not env.get("PEMP_BENCH_DRYRUN"):
+        env.pop("PEMP_BENCH_DRYRUN")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=240)
@@ -196,6 +199,60 @@ def test_bench_launcher_fails_when_a_rank_fails():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "rank 1 exited" in r.stderr
+
+
+def test_bench_train_control_flow_two_ranks_with_the_rank0_roofline_pass():
+    """`bench.py --mode train --gpus 2` through main_train's REAL control flow (PEMP_BENCH_STUB: the real
+    Stage1Trainer.train_step / reduce_gradients / GradBuckets over a small CPU buffer, gloo): warm-up + timed steps with
+    bucketed all-reduces on both ranks, then the roofline pass that rank 0 runs ALONE -- it must be collective-free
+    (round 2: its bucket all-reduces paired with the other rank's barrier).  The job completes, the line carries
+    `roofline`, and the weights after the timed steps are the data-parallel result."""
+    import json
+    r = _run_bench({"PEMP_BENCH_STUB": "1", "PEMP_BENCH_DRYRUN": "", "PEMP_BENCH_SILENCE_S": "60"},
+                   "--gpus", "2", "--steps", "3", "--warmup", "2", "--mode", "train")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["episodes_per_step"] == 4
+    assert "roofline" in out and "error" not in out["roofline"], out.get("roofline")
+    # 5 steps of lr 0.1 on the MEAN gradient of the ranks ((1 + 2) / 2): every all-reduce of the timed part paired up
+    assert abs(out["config"]["stub_weight"] - (-0.1 * 1.5 * 5)) < 1e-6
+    assert out["config"]["last_loss"] == 5.0          # rank 0 made exactly 5 calls before the roofline pass
+
+
+def test_bench_train_stub_roofline_pass_with_collectives_left_on_would_mismatch():
+    """The guard the test above relies on: a rank-local step issues NO collective (collectives = False), a normal step does."""
+    import bench
+    import torch.distributed as dist
+    calls = []
+    tr = bench.stub_trainer(0)
+    real_active = type(tr.eng.buckets).active
+    try:
+        type(tr.eng.buckets).active = lambda self: self.enabled          # pretend a 2-rank group exists
+        tr.eng.buckets._launch = lambda lo, hi: calls.append((lo, hi))
+        tr.eng.buckets.finish = lambda: calls.append("finish") or 0.5
+        tr.train_step(*[torch.zeros(1)] * 4)
+        assert len([c for c in calls if c != "finish"]) == 4
+        calls.clear()
+        tr.collectives = False
+        tr.train_step(*[torch.zeros(1)] * 4)
+        assert calls == []
+    finally:
+        type(tr.eng.buckets).active = real_active
+    assert not dist.is_initialized()
+
+
+def test_bench_launcher_watchdog_stops_a_silent_job():
+    """A rank that never reaches the collective the others wait in: no heartbeat for PEMP_BENCH_SILENCE_S seconds ->
+    the launcher terminates every rank and exits 124."""
+    import time
+    t0 = time.time()
+    r = _run_bench({"PEMP_BENCH_HANG_RANK": "1", "PEMP_BENCH_SILENCE_S": "4"}, "--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert "no rank has made progress" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 120
 
 
 def test_bench_under_an_external_launcher_uses_its_world_size():
