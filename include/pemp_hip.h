@@ -229,12 +229,16 @@ int pemp_cm_bwd_add_arg_f32(const float* mask, const float* dstat, const int32_t
  * bytes (the counters) must be zero on entry and are left zero; not shared by launches that may run concurrently.
  * NULL / 0 for the other tile ids.                                                                                      */
 size_t pemp_conv2d_splitk_workspace_bytes(const pemp_conv_desc* d);
-/* pemp_conv2d_nhwc_f32 with the split-K tile ids (31..37) allowed; other ids behave as there (ws unused).  Training only:
- * the evaluation path keeps the variants that are bit-identical to each other.                                            */
+/* pemp_conv2d_nhwc_f32 with the split-K tile ids (31..37) allowed; other ids behave as there (ws unused).  Used by the
+ * training step and by evaluation steps of one or two episodes (<= 12000 output rows, where the unsplit variants leave most
+ * CUs idle); larger evaluation steps keep the variants that are bit-identical to each other.                              */
 int pemp_conv2d_splitk_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale,
                                 const float* shift, const float* residual, void* ws, size_t ws_bytes, void* stream);
 void* pemp_uncached_alloc(size_t bytes);       /* zero-filled; NULL on failure (pemp_last_error) */
 int pemp_uncached_free(void* p);
+/* Zero the arrival counters (first 1024 bytes) of a split-K workspace on `stream`: the kernels leave them zero, a launch
+ * that failed may not have -- the host side calls this before it reports the failure.                                     */
+int pemp_splitk_reset(void* ws, void* stream);
 int pemp_conv2d_stats_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,
                                void* ws, size_t ws_bytes, void* stream);
 int pemp_conv2d_stats_rows(const pemp_conv_desc* d);

@@ -469,6 +469,15 @@ extern "C" void* pemp_uncached_alloc(size_t bytes) {
     return p;
 }
 
+// Zero the arrival counters of a split-K workspace (its first 1024 bytes) on `stream`: the kernels leave them zero, a launch
+// that failed or was aborted may not have.
+extern "C" int pemp_splitk_reset(void* ws, void* stream) {
+    PEMP_REQUIRE(ws, "splitk_reset: null workspace");
+    const hipError_t e = hipMemsetAsync(ws, 0, 1024, (hipStream_t)stream);
+    if (e != hipSuccess) pemp::set_error("pemp_splitk_reset: %s", hipGetErrorString(e));
+    return (int)e;
+}
+
 extern "C" int pemp_uncached_free(void* p) {
     const hipError_t e = hipFree(p);
     if (e != hipSuccess) pemp::set_error("pemp_uncached_free: %s", hipGetErrorString(e));

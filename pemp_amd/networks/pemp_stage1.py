@@ -86,11 +86,12 @@ class _HeadMixin:
 
         class _Lane:
             def __enter__(self_inner):
-                self_inner.prev = model.__dict__.get("_lane", 0)
+                self_inner.prev = (model.__dict__.get("_lane", 0), ops.SK_SCOPE)
                 model.__dict__["_lane"] = k
+                ops.SK_SCOPE = k                   # lanes run beside each other: each has its own split-K workspace
 
             def __exit__(self_inner, *exc):
-                model.__dict__["_lane"] = self_inner.prev
+                model.__dict__["_lane"], ops.SK_SCOPE = self_inner.prev
                 return False
         return _Lane()
 

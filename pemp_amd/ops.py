@@ -68,6 +68,9 @@ TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15
                  # 2x: the same shapes on conv_dma2.hip (buffer-addressed LDS-DMA, barrier inside the MFMA stream)
                  23: (64, 64), 24: (128, 128), 22: (128, 64), 21: (128, 128), 25: (128, 64), 27: (256, 256), 26: (256, 128)}
 AUTOTUNE = True
+#: de-phasing of co-resident blocks (units of 64 cycles, 0..127) handed to the conv / weight-gradient kernels in flags bits 24..30
+STAGGER = int(os.environ.get("PEMP_CONV_STAGGER", "0"))
+WGRAD_STAGGER = int(os.environ.get("PEMP_WGRAD_STAGGER", "0"))
 SPLITK = os.environ.get("PEMP_CONV_SPLITK", "1") != "0"     # the training convs may pick the split-K variants (A/B switch)
 DEFAULT_TILE = 13
 _TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared by every ConvParams object
@@ -178,14 +181,15 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
         flags |= CONV_SHIFT_PER_IMAGE
     if p.stem:
         flags |= CONV_STEM4
-    splitk = splitk and SPLITK and pad_value is None and not p.stem
+    flags |= (STAGGER & 127) << 24
+    splitk = ((splitk and SPLITK) or (EVAL_SPLITK and n * ho * wo <= EVAL_SPLITK_MAX_ROWS)) and pad_value is None and not p.stem
 
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, flags, t)
         if t > 30:
             ws, ws_bytes = _splitk_ws(lib, d, x.device)
-            _lib.check(lib.pemp_conv2d_splitk_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift), _p(residual),
-                                                       C.c_void_p(ws), ws_bytes, _stream()), "pemp_conv2d_splitk_nhwc_f32")
+            _check_sk(lib, lib.pemp_conv2d_splitk_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift), _p(residual),
+                                                           C.c_void_p(ws), ws_bytes, _stream()), ws, "pemp_conv2d_splitk_nhwc_f32")
         elif pad_value is None:
             _lib.check(lib.pemp_conv2d_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift),
                                                 _p(residual), _stream()), "pemp_conv2d_nhwc_f32")
@@ -206,32 +210,50 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
     return out
 
 
-#: split-K variants of the training convs (ids 31..37 = the shapes of 21..27; pemp_hip.h): NOT bit-identical to the others
+#: split-K variants (ids 31..37 = the shapes of 21..27; pemp_hip.h): NOT bit-identical to the others.  The training convs may pick
+#: them, and so may the evaluation path for SMALL row counts (one or two episodes per step: 5202 rows leave two thirds of the
+#: chip idle on the 3x3 layers otherwise) -- see EVAL_SPLITK
 SPLITK_TILES = (31, 32, 34, 35, 36, 37)
-_SK_WS = {}      # device index -> (pointer, bytes) of the uncached split-K workspace; the training convs of a device run on one
-                 # stream at a time (main chain), never beside each other
+#: evaluation convs of at most EVAL_SPLITK_MAX_ROWS output rows may use the split-K variants (PEMP_EVAL_SPLITK=0: never --
+#: every evaluation variant is then bit-identical again and a one-episode step equals the batched step bit for bit; with it,
+#: they agree to rounding: tests/test_eval_protocol_gpu.py states the bounds)
+EVAL_SPLITK = os.environ.get("PEMP_EVAL_SPLITK", "1") != "0"
+EVAL_SPLITK_MAX_ROWS = int(os.environ.get("PEMP_EVAL_SPLITK_MAX_ROWS", "12000"))
+#: Uncached split-K workspaces, one per (device, scope).  A workspace must never serve two launches that can run beside each
+#: other, so everything that runs on its own stream has its own SCOPE: 0 = the main chain (training step, evaluation engine),
+#: k = evaluation lane k (networks._HeadMixin.lane sets SK_SCOPE).  The size is fixed (every variant fits) and a workspace is
+#: never freed or moved: captured hipGraphs hold its address.
+_SK_WS = {}
+SK_SCOPE = 0
+_SK_WS_BYTES = 72 << 20            # 256 partial tiles of 256 x 256 floats + counters
 
 
 def _splitk_ws(lib, desc, device):
-    """-> (pointer, bytes) of this device's uncached workspace (pemp_uncached_alloc), large enough for ``desc``."""
+    """-> (pointer, bytes) of the uncached workspace (pemp_uncached_alloc) of this device and the current scope."""
     need = lib.pemp_conv2d_splitk_workspace_bytes(C.byref(desc))
     if need == 0:
         return None, 0
+    if need > _SK_WS_BYTES:
+        raise RuntimeError(f"conv split-K: a launch asks for {need} bytes of workspace, the fixed size is {_SK_WS_BYTES}")
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    ptr, size = _SK_WS.get(idx, (None, 0))
-    if size < need:
+    ent = _SK_WS.get((idx, SK_SCOPE))
+    if ent is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("the conv split-K workspace must exist before a hipGraph is recorded: run the step eagerly once")
-        torch.cuda.synchronize(device)
         with torch.cuda.device(device):
-            if ptr:
-                _lib.check(lib.pemp_uncached_free(C.c_void_p(ptr)), "pemp_uncached_free")
-            size = max(need, 72 << 20)            # 256 partial tiles of 256 x 256 floats + counters: every variant fits
-            ptr = lib.pemp_uncached_alloc(size)
+            ptr = lib.pemp_uncached_alloc(_SK_WS_BYTES)
         if not ptr:
             _lib.check(-1, "pemp_uncached_alloc")
-        _SK_WS[idx] = (ptr, size)
-    return ptr, size
+        ent = _SK_WS[(idx, SK_SCOPE)] = (ptr, _SK_WS_BYTES)
+    return ent
+
+
+def _check_sk(lib, rc, ws, what):
+    """A split-K launch that failed may have left arrival counters non-zero (no block would ever be "last" again): clear
+    them before the failure is raised."""
+    if rc and ws:
+        lib.pemp_splitk_reset(C.c_void_p(ws), _stream())
+    _lib.check(rc, what)
 
 
 def _stats_rows(m, tile):
@@ -265,10 +287,10 @@ def conv2d_stats(x, p, out=None, tile=0):
     part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)     # the smallest row tile has 64 rows
 
     def launch(t):
-        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, 0, p.kpad, 0, t)
+        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, 0, p.kpad, (STAGGER & 127) << 24, t)
         ws, ws_bytes = _splitk_ws(lib, d, x.device) if t > 30 else (None, 0)
-        _lib.check(lib.pemp_conv2d_stats_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(part), C.c_void_p(ws), ws_bytes,
-                                                  _stream()), "pemp_conv2d_stats_nhwc_f32")
+        _check_sk(lib, lib.pemp_conv2d_stats_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(part), C.c_void_p(ws), ws_bytes,
+                                                      _stream()), ws, "pemp_conv2d_stats_nhwc_f32")
 
     if tile == 0:
         key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 2, n, h, w, 0, 0)     # 2: the stats epilogue
@@ -316,11 +338,11 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
     part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)
 
     def launch(t):
-        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, 0, t)
+        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, (STAGGER & 127) << 24, t)
         ws, ws_bytes = _splitk_ws(lib, d, x.device) if t > 30 else (None, 0)
-        _lib.check(lib.pemp_conv2d_bnbwd_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(residual), _p(mask), _p(z), ldz,
-                                                  _p(bn["mean"]), _p(bn["invstd"]), _p(part), C.c_void_p(ws), ws_bytes,
-                                                  _stream()), "pemp_conv2d_bnbwd_nhwc_f32")
+        _check_sk(lib, lib.pemp_conv2d_bnbwd_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(residual), _p(mask), _p(z), ldz,
+                                                      _p(bn["mean"]), _p(bn["invstd"]), _p(part), C.c_void_p(ws), ws_bytes,
+                                                      _stream()), ws, "pemp_conv2d_bnbwd_nhwc_f32")
 
     if tile == 0:
         key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 3, n, h, w, int(residual is not None), 0)   # 3: this epilogue

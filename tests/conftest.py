@@ -26,3 +26,11 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def exact_eval_variants(monkeypatch):
+    """Evaluation convs restricted to the variants that are bit-identical to each other (no split-K for small row counts:
+    pemp_amd.ops.EVAL_SPLITK): what the "one episode per step equals the batched step bit for bit" tests state."""
+    from pemp_amd import ops
+    monkeypatch.setattr(ops, "EVAL_SPLITK", False)

@@ -48,7 +48,7 @@ def test_eval_round_miou_matches_cpu_oracle(hip_lib, dev):
     assert abs(loss - float(np.mean(losses))) <= 1e-4
 
 
-def test_batched_evaluation_gives_identical_metrics(hip_lib, dev):
+def test_batched_evaluation_gives_identical_metrics(hip_lib, dev, exact_eval_variants):
     """start_eval_loop(batch=4) (several episodes per encoder pass, one tail launch per label size, ragged last
     group) returns exactly the metrics of the reference-style one-episode-per-step loop."""
     from pemp_amd.entry import pemp_stage1 as e
@@ -63,7 +63,7 @@ def test_batched_evaluation_gives_identical_metrics(hip_lib, dev):
     assert l0 == l1 and np.array_equal(m0, m1) and np.array_equal(b0, b1)
 
 
-def test_single_episode_steps_in_flight_give_identical_statistics(hip_lib, dev):
+def test_single_episode_steps_in_flight_give_identical_statistics(hip_lib, dev, exact_eval_variants):
     """The reference protocol (one episode per test_step) with 1 and with 4 steps in flight (Evaluator(lanes=4): engine
     replicas on their own HIP streams): the per-episode statistics rows are bit-identical, in order, for ragged label sizes;
     the evaluation loop returns identical metrics; and both equal the batched step."""
@@ -85,7 +85,7 @@ def test_single_episode_steps_in_flight_give_identical_statistics(hip_lib, dev):
     assert l0 == l1 and np.array_equal(m0, m1) and np.array_equal(b0, b1)
 
 
-def test_stage2_batched_evaluation_gives_identical_metrics(hip_lib, dev):
+def test_stage2_batched_evaluation_gives_identical_metrics(hip_lib, dev, exact_eval_variants):
     """The stage-2 evaluator (stage-1 prior -> stage 2) through the same sharded loop: batch 3 == batch 1."""
     from pemp_amd.entry import pemp_stage2 as e2
     s1 = e2.PriorNet(None)
@@ -120,15 +120,22 @@ def test_coco20i_round_matches_cpu_oracle(hip_lib, dev):
     nclass = e1.num_classes("COCO")
     labels = e1.get_val_labels(split, "COCO")
     assert nclass == 80 and labels == list(range(21, 41))
+    from pemp_amd import ops
     res, per_class = [], []
-    for batch in (1, 8):
+    for batch, sk in ((1, False), (8, False), (1, True)):
+        # sk False: every evaluation conv variant is bit-identical, one episode per step == eight per step exactly;
+        # sk True (the default): a one-episode step may run the 3x3 layers split along K -- same metrics to rounding
+        ops.EVAL_SPLITK = sk
         data = e1.SyntheticEpisodes(n_eps, 5678, shot=1, split=split, dataset="COCO")
         ev = e1.Evaluator(net, dev)
         res.append(ev.start_eval_loop(data, nclass, split, te_epochs=1, batch=batch, dataset_name="COCO"))
         per_class.append(ev.round_miou[0])
-    (loss, miou_c, biou_c), (loss8, miou8, biou8) = res
+    ops.EVAL_SPLITK = True
+    (loss, miou_c, biou_c), (loss8, miou8, biou8), (loss_sk, miou_sk, biou_sk) = res
     assert loss == loss8 and np.array_equal(miou_c, miou8) and np.array_equal(biou_c, biou8)
     assert np.array_equal(per_class[0], per_class[1]) and per_class[0].shape == (20,)
+    assert abs(loss_sk - loss) <= 1e-5 and np.abs(np.asarray(miou_sk) - np.asarray(miou_c)).max() <= 1e-4
+    miou_c, biou_c, loss, per_class[0] = miou_sk, biou_sk, loss_sk, per_class[2]      # the default path is the one held to the oracle
     assert np.isfinite(per_class[0]).all() and np.isfinite(miou_c) and np.isfinite(biou_c)
     torch.set_num_threads(16)
     data = e1.SyntheticEpisodes(n_eps, 5678, shot=1, split=split, dataset="COCO")
@@ -156,3 +163,33 @@ def test_coco20i_round_matches_cpu_oracle(hip_lib, dev):
     assert abs(got_miou - ref_miou) <= 1e-4 and abs(got_biou - ref_biou) <= 1e-4
     assert np.abs(per_class[0] - ref_c).max() <= 2e-4
     assert abs(loss - float(np.mean(losses))) <= 1e-4
+
+
+def test_one_episode_step_with_split_k_matches_the_batched_step(hip_lib, dev):
+    """Default evaluation path at the real shape (401 x 401): a one-episode step (5202 feature rows; the autotuner may pick
+    the split-K conv variants, pemp_amd.ops.EVAL_SPLITK) against the same episode inside an 8-episode step (unsplit
+    variants): feature-resolution logits within LOGIT_TOL / 20 (measured ~1e-5: only the summation order of the K slices
+    differs), pixel counts within 0.1 % of the label, loss within 1e-5; and the one-episode result is bit-stable across
+    replays of its hipGraph."""
+    from pemp_amd import ops, synth
+    from pemp_amd.networks import pemp_stage1 as m
+    net = m.ModelClass(None)
+    net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    net = net.to(dev).eval()
+    b = synth.make_batch([5678 + i for i in range(8)], shot=1, out_hw=(366, 500))
+    t = lambda k: torch.from_numpy(b[k]).to(dev)
+    sup, msk, qry, lab = t("sup_img"), t("sup_mask"), t("qry_img"), t("qry_mask")[:, 0]
+    with torch.no_grad():
+        pred8 = net.lowres(sup, msk, qry)[0].clone()
+        _, st8, _ = ops.eval_tail(pred8, lab)
+        st8 = st8.cpu().numpy()
+        for i in (0, 5):
+            p1 = net.lowres_graphed(sup[i:i + 1], msk[i:i + 1], qry[i:i + 1])[0].clone()
+            p1b = net.lowres_graphed(sup[i:i + 1], msk[i:i + 1], qry[i:i + 1])[0].clone()
+            assert torch.equal(p1, p1b)
+            d = (p1 - pred8[i:i + 1]).abs().max().item()
+            assert d <= util.LOGIT_TOL / 20, d
+            _, st1, _ = ops.eval_tail(p1, lab[i:i + 1])
+            st1 = st1.cpu().numpy()[0]
+            assert abs(st1[0] / st1[1] - st8[i, 0] / st8[i, 1]) <= 1e-5
+            assert np.abs(st1[2:] - st8[i, 2:]).max() <= 1e-3 * lab[i].numel()
