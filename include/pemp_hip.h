@@ -334,6 +334,8 @@ int pemp_cedt_weight_f32(const int64_t* target, float* weight, void* ws, size_t 
  *           behind for the same features and masks; protos [B][J][c]; pred [B][2][n];
  *   target int64 [B][Ho][Wo]; stats [B][8] from pemp_eval_tail_f32 (valid-pixel counts).
  * Outputs: dsup [B*S][n][ldd], dqry [B][n][ldd] (feature gradients), dctr [c][2p] (NULL when p == 0). */
+/* The last B * 2 * n int32 words of the workspace receive, per (episode, group, query pixel), the prototype row the cosine
+ * backward routed the gradient to (group 0 = foreground rows [0, p), group 1 = background rows [p, 2p); first maximum).    */
 size_t pemp_head_bwd_workspace_bytes(int B, int S, int n, int c, int p);
 int pemp_head_bwd_f32(const float* sup_feat, const float* qry_feat, int ldf, const float* mask,
                       const float* ctr, const void* fwd_ws, const float* protos, const float* pred,

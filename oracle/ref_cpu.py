@@ -31,6 +31,72 @@ TRAIN = False     # module switch: True = model.train() semantics for BatchNorm 
                   # drop_rate = 0 (their random streams cannot be pinned: dropblock's source is absent)
 
 
+# Decision switches (tests/test_grad_frozen_gpu.py).  The path has three kinds of discrete decisions: the sign of a ReLU's
+# input, the winner of a max-pool window, the prototype that wins a group maximum.  ``SWITCHES = Switches()`` makes a forward
+# pass RECORD them by tag; ``SWITCHES = Switches(decisions)`` makes it TAKE them (y = x * mask, pooled = x[winner],
+# max = x[winner]): a decision-frozen, smooth function.  Evaluated in float64 under autograd it yields the gradient that a
+# backward pass which used the same decisions must reproduce up to rounding -- no arg-max that flips between two
+# float32 evaluations (the noise floor of the end-to-end gradient comparison) is left in the comparison.
+# ``SWITCHES = None`` (default): plain F.relu / F.max_pool2d / Tensor.max, bit for bit.
+SWITCHES = None
+
+
+class Switches:
+    def __init__(self, decisions=None):
+        self.replay = decisions is not None
+        self.d = {} if decisions is None else decisions
+        self.used = set()
+
+    def take(self, tag):
+        self.used.add(tag)
+        return self.d[tag]
+
+
+class _MaxResult:
+    def __init__(self, values, indices):
+        self.values, self.indices = values, indices
+
+    def __getitem__(self, i):
+        return (self.values, self.indices)[i]
+
+
+def _relu(x, tag):
+    s = SWITCHES
+    if s is None:
+        return F.relu(x)
+    if s.replay:
+        m = s.take(tag)
+        if m.shape != x.shape:
+            raise ValueError(f"switch {tag}: mask {tuple(m.shape)} for activation {tuple(x.shape)}")
+        return x * m.to(x.dtype)
+    s.d[tag] = x.detach() > 0
+    return F.relu(x)
+
+
+def _max_pool2d(x, k, stride, pad, tag, ceil_mode=False):
+    s = SWITCHES
+    if s is None:
+        return F.max_pool2d(x, k, stride, pad, ceil_mode=ceil_mode)
+    if s.replay:
+        idx = s.take(tag)                # as F.max_pool2d(return_indices=True): h * W + w inside the input plane
+        return x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+    y, idx = F.max_pool2d(x, k, stride, pad, ceil_mode=ceil_mode, return_indices=True)
+    s.d[tag] = idx
+    return y
+
+
+def _group_max(t, dim, tag):
+    s = SWITCHES
+    if s is None:
+        return t.max(dim=dim)
+    if s.replay:
+        idx = s.take(tag)
+        return _MaxResult(t.gather(dim, idx.unsqueeze(dim)).squeeze(dim), idx)
+    mv = t.max(dim=dim)
+    s.d[tag] = mv.indices
+    return mv
+
+
 def _bn(x, sd, p):
     """nn.BatchNorm2d (networks/backbones.py:48-52,90,111,328): eval -> running statistics;
     train (core/base_trainer.py:189) -> batch statistics, running stats updated in place."""
@@ -44,14 +110,14 @@ def _conv(x, sd, p, stride=1, padding=0, dilation=1):
 
 def bottleneck(x, sd, p, stride, dilation, downsample):
     """BottleNeck.forward, networks/backbones.py:64-77 (stride sits on conv1, :47)."""
-    out = F.relu(_bn(_conv(x, sd, p + ".conv1", stride=stride), sd, p + ".bn1"))
-    out = F.relu(_bn(_conv(out, sd, p + ".conv2", padding=dilation, dilation=dilation), sd, p + ".bn2"))
+    out = _relu(_bn(_conv(x, sd, p + ".conv1", stride=stride), sd, p + ".bn1"), p + ".relu1")
+    out = _relu(_bn(_conv(out, sd, p + ".conv2", padding=dilation, dilation=dilation), sd, p + ".bn2"), p + ".relu2")
     out = _bn(_conv(out, sd, p + ".conv3"), sd, p + ".bn3")
     if downsample:
         res = _bn(_conv(x, sd, p + ".downsample.0", stride=stride), sd, p + ".downsample.1")
     else:
         res = x
-    return F.relu(out + res)
+    return _relu(out + res, p + ".relu3")
 
 
 _LAYER_CFG = {  # name: (stride, dilation) -- networks/backbones.py:97-99
@@ -70,8 +136,8 @@ def _res_layer(x, sd, p, name, blocks):
 
 def resnet_stem(x, sd, p):
     """conv1 7x7 s2 p3 -> bn -> relu -> maxpool 3/2/1 ceil_mode (backbones.py:89-92,125)."""
-    x = F.relu(_bn(_conv(x, sd, p + ".conv1", stride=2, padding=3), sd, p + ".bn1"))
-    return F.max_pool2d(x, 3, 2, 1, ceil_mode=True)
+    x = _relu(_bn(_conv(x, sd, p + ".conv1", stride=2, padding=3), sd, p + ".bn1"), p + ".relu")
+    return _max_pool2d(x, 3, 2, 1, p + ".maxpool", ceil_mode=True)
 
 
 def resnet(x, sd, p, layers=(3, 4, 6)):
@@ -111,12 +177,12 @@ _ASPP_DIL = (None, 0, 6, 12, 18)  # aspp_0 = global branch, aspp_1 = 1x1, then d
 def aspp_v2(x, sd, p):
     """ASPPV2.forward, BN -> (DropBlock) -> conv -> ReLU per branch (backbones.py:324-369)."""
     g = F.adaptive_avg_pool2d(x, (1, 1))
-    g = F.relu(_conv(_bn(g, sd, p + ".aspp_0.0"), sd, p + ".aspp_0.2"))
+    g = _relu(_conv(_bn(g, sd, p + ".aspp_0.0"), sd, p + ".aspp_0.2"), p + ".aspp_0.relu")
     outs = [g.expand(-1, -1, *x.shape[-2:])]
     for i in range(1, 5):
         d = _ASPP_DIL[i]
-        outs.append(F.relu(_conv(_bn(x, sd, f"{p}.aspp_{i}.0"), sd, f"{p}.aspp_{i}.2",
-                                 padding=d, dilation=max(d, 1))))
+        outs.append(_relu(_conv(_bn(x, sd, f"{p}.aspp_{i}.0"), sd, f"{p}.aspp_{i}.2",
+                                padding=d, dilation=max(d, 1)), f"{p}.aspp_{i}.relu"))
     return _conv(torch.cat(outs, 1), sd, p + ".layer6")
 
 
@@ -132,8 +198,8 @@ def aspp(x, sd, p):
 
 def purifier(x, sd, p, v2=True):
     """encoder.purifier (networks/pemp_stage1.py:73-80; pemp_stage2.py:65-72)."""
-    x = F.relu(_conv(x, sd, p + ".0"))
-    x = F.relu(_conv(x, sd, p + ".3", padding=1))
+    x = _relu(_conv(x, sd, p + ".0"), p + ".0.relu")
+    x = _relu(_conv(x, sd, p + ".3", padding=1), p + ".3.relu")
     return aspp_v2(x, sd, p + ".6") if v2 else aspp(x, sd, p + ".6")
 
 
@@ -147,16 +213,16 @@ _VGG = (  # (conv index in nn.Sequential, dilation, relu) / "P2" pool s2 / "P1" 
 
 def vgg16(x, sd, p, last_relu=False):
     """VGG16.forward (networks/backbones.py:372-405)."""
+    npool = 0
     for item in _VGG:
-        if item == "P2":
-            x = F.max_pool2d(x, 3, 2, 1)
-        elif item == "P1":
-            x = F.max_pool2d(x, 3, 1, 1)
+        if item == "P2" or item == "P1":
+            x = _max_pool2d(x, 3, 2 if item == "P2" else 1, 1, f"{p}.pool{npool}")
+            npool += 1
         else:
             idx, d, relu = item
             x = _conv(x, sd, f"{p}.features.{idx}", padding=d, dilation=d)
             if relu or (relu is None and last_relu):
-                x = F.relu(x)
+                x = _relu(x, f"{p}.features.{idx}.relu")
     return x
 
 
@@ -226,7 +292,7 @@ def mpm(sup_fts, qry_fts, sup_fg, sup_bg, ctr, protos, dist_scalar=20, ret_ind=F
         new = new.transpose(3, 4).reshape(B, S, c * protos, 2).mean(dim=1)            # [B,cp,2]
         adaptive_p = new.view(B, c, protos, 2).transpose(2, 3).reshape(B, c, -1)      # stage2 :185
         fg_proto, bg_proto = new.view(B, c, protos, 2).unbind(dim=3)                  # [B,c,p]
-        mv = compute_similarity(fg_proto, bg_proto, qry_fts, dist_scalar).max(dim=2)
+        mv = _group_max(compute_similarity(fg_proto, bg_proto, qry_fts, dist_scalar), 2, "head.proto_max")
         pred = mv.values
         if ret_ind:
             ind = mv.indices
@@ -458,3 +524,33 @@ def train_step(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", qry_prio
         if v.is_floating_point():
             v.requires_grad_(False)
     return float(loss.detach()), grads
+
+
+def frozen_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, decisions, model="stage1", backbone="resnet50",
+                     dtype=torch.float64):
+    """Loss and d loss / d parameter of ONE train-mode forward (batch-statistics BatchNorm, regularisers off, CE) in which
+    every discrete decision -- ReLU sign, max-pool winner, winning prototype -- is TAKEN from ``decisions`` (see Switches),
+    evaluated in ``dtype`` under autograd.  ``sd`` is not modified.  -> (loss float, {name: gradient}, tags used)."""
+    global TRAIN, SWITCHES
+    frozen = lambda k: ("running" in k or "num_batches" in k or k.endswith("backbone.bn1.weight") or k.endswith("backbone.bn1.bias")
+                        or ".downsample.1." in k)
+    w = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
+    leaves = {k: v.requires_grad_(True) for k, v in w.items() if v.is_floating_point() and not frozen(k)}
+    old = (TRAIN, SWITCHES)
+    TRAIN, SWITCHES = True, Switches(decisions)
+    try:
+        H, W = qry_msk.shape[-2:]
+        ins = (sup_img.to(dtype), sup_mask.to(dtype), qry_img.to(dtype))
+        if model == "stage1":
+            logits = stage1_forward(w, *ins, (H, W), backbone=backbone)
+        elif model == "baseline":
+            logits = baseline_forward(w, *ins, (H, W), backbone=backbone)
+        else:
+            raise ValueError(model)
+        loss = ce_loss(logits, qry_msk.view(-1, H, W))
+        names = list(leaves)
+        grads = dict(zip(names, torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)))
+        used = set(SWITCHES.used)
+    finally:
+        TRAIN, SWITCHES = old
+    return float(loss.detach()), {k: g for k, g in grads.items() if g is not None}, used

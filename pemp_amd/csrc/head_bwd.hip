@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ protos,
                                                          const float* __restrict__ dpred, float* __restrict__ dqry,
                                                          int ldd, float* __restrict__ part, int n, int c, int p,
-                                                         float scalar) {
+                                                         float scalar, int* __restrict__ winners) {
     __shared__ float pn[MAXJ][64 * MAXCL];
     __shared__ float nrm[MAXJ];
     const int b = blockIdx.y;
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
                 }
             sel[g] = bj;
             coef[g] = scalar * dpred[((size_t)b * 2 + (g == 0 ? 1 : 0)) * n + i];
+            if (lane == 0) winners[((size_t)b * 2 + g) * n + i] = bj;
         }
         float dy[MAXCL];
 #pragma unroll
@@ -478,11 +479,14 @@ constexpr int HB_BLOCKS = 128;   // pixel-group blocks per image in the two wave
 
 using namespace pemp;
 
-// workspace (fp32): Pps[BS][J][c] | Dps[BS][J] | dpred[B][2][n] | dP[B][J][c] | cpart[B][HB][J][c] | mpart[BS][HB][J][c]
+// workspace (fp32): Pps[BS][J][c] | Dps[BS][J] | dpred[B][2][n] | dP[B][J][c] | cpart[B][HB][J][c] | mpart[BS][HB][J][c] |
+// winners int32 [B][2][n] (the LAST B * 2 * n words: the prototype row the cosine backward routed each (query pixel, group)
+// gradient to -- group 0 = foreground rows [0, p), group 1 = background rows [p, 2p); what a decision-frozen reference
+// evaluation needs to know, tests/test_grad_frozen_gpu.py)
 static size_t head_bwd_floats(int B, int S, int n, int c, int J) {
     const size_t BS = (size_t)B * S;
     return BS * J * c + BS * J + (size_t)B * 2 * n + (size_t)B * J * c + (size_t)B * HB_BLOCKS * J * c +
-           BS * HB_BLOCKS * J * c + 64;
+           BS * HB_BLOCKS * J * c + 64 + (size_t)B * 2 * n;
 }
 
 extern "C" size_t pemp_head_bwd_workspace_bytes(int B, int S, int n, int c, int p) {
@@ -532,7 +536,8 @@ static int head_bwd_impl(const float* sup_feat, const float* qry_feat, int ldf, 
         hipLaunchKernelGGL(upsample_bwd_kernel<true>, dim3(cdiv(n, 4), B), dim3(256), 0, st, pred, target, weight, stats, B,
                            (const float*)nullptr, dpred, h, w, Ho, Wo);
     hipLaunchKernelGGL(cosine_bwd_kernel, dim3(HB_BLOCKS, B), dim3(256), 0, st, qry_feat, ldf, protos, (const float*)dpred,
-                       dqry, ldd, cpart, n, c, p > 0 ? p : 1, dist_scalar);
+                       dqry, ldd, cpart, n, c, p > 0 ? p : 1, dist_scalar,
+                       (int*)((float*)ws + head_bwd_floats(B, S, n, c, J) - (size_t)B * 2 * n));
     hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(J * c, 64), B), dim3(256), 0, st, (const float*)cpart, HB_BLOCKS, J * c,
                        dP, 0);
     int e = launch_status("head_bwd/cosine");

@@ -697,3 +697,44 @@ def test_autotune_picks_round_trip_through_the_cache_file(tmp_path):
     second = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
     assert "((256, 256, 3, 3, 1, 2, 2, 2, 8, 51, 51, 0, 0), 34)" in second
     assert "(2, 1024)" in second and "512" in second
+
+
+def test_oracle_decision_switches_record_and_replay():
+    """oracle/ref_cpu.py Switches: a train-mode forward that RECORDS its discrete decisions, then the decision-frozen
+    forward that TAKES them, give the same loss and the same gradients (float32: the two are the same arithmetic), for the
+    ResNet-50 stage-1 path and the VGG-16 baseline; replaying with one ReLU mask inverted changes the gradient (the switches
+    really steer the pass); a missing tag fails loudly."""
+    import pytest
+    from oracle import ref_cpu
+    from pemp_amd import synth
+    for name, model, backbone in (("stage1_rn50", "stage1", "resnet50"), ("baseline_vgg16", "baseline", "vgg16")):
+        sd = util.wgen_state_dict(name)
+        b = synth.make_batch([31, 32], shot=1, height=65, width=65, out_hw=(65, 65))
+        t = lambda k: torch.from_numpy(b[k])
+        sup, msk, qry, gt = t("sup_img"), t("sup_mask"), t("qry_img"), t("qry_mask")[:, 0]
+        w = {k: v.clone() for k, v in sd.items()}
+        leaves = [k for k, v in w.items() if v.is_floating_point() and "running" not in k]
+        for k in leaves:
+            w[k].requires_grad_(True)
+        rec = ref_cpu.Switches()
+        ref_cpu.TRAIN, ref_cpu.SWITCHES = True, rec
+        try:
+            fwd = ref_cpu.stage1_forward if model == "stage1" else ref_cpu.baseline_forward
+            loss = ref_cpu.ce_loss(fwd(w, sup, msk, qry, (65, 65), backbone=backbone), gt)
+            plain = dict(zip(leaves, torch.autograd.grad(loss, [w[k] for k in leaves], allow_unused=True)))
+        finally:
+            ref_cpu.TRAIN, ref_cpu.SWITCHES = False, None
+        assert any(k.endswith("relu") or "relu" in k for k in rec.d) and any("pool" in k for k in rec.d)
+        l2, g2, used = ref_cpu.frozen_gradients(sd, sup, msk, qry, gt, rec.d, model=model, backbone=backbone, dtype=torch.float32)
+        assert used == set(rec.d)
+        assert abs(l2 - float(loss.detach())) <= 1e-6
+        for k, g in g2.items():
+            assert torch.allclose(g, plain[k], rtol=1e-4, atol=1e-7 + 1e-5 * plain[k].abs().max().item()), k
+        flipped = dict(rec.d)
+        tag = sorted(k for k in rec.d if "relu" in k)[3]
+        flipped[tag] = ~rec.d[tag]
+        _, g3, _ = ref_cpu.frozen_gradients(sd, sup, msk, qry, gt, flipped, model=model, backbone=backbone, dtype=torch.float32)
+        assert max((g3[k] - g2[k]).abs().max().item() for k in g2) > 1e-4
+        broken = {k: v for k, v in rec.d.items() if k != tag}
+        with pytest.raises(KeyError):
+            ref_cpu.frozen_gradients(sd, sup, msk, qry, gt, broken, model=model, backbone=backbone, dtype=torch.float32)

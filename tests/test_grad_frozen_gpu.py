@@ -1,0 +1,183 @@
+"""Gradients of one training step with the discrete decisions FROZEN: a bound that can see a kernel bug.
+
+The end-to-end comparison with the reference's gradients (test_train_gpu.py) has a noise floor of ~1e-3: the step switches
+discretely -- ReLU signs, max-pool winners, the winning prototype -- and two float32 evaluations of the same step do not take
+the same switches (one flipped arg-max of VGG-16's stride-1 pool moves every gradient below it by 1e-3).  Here the switches
+are taken out of the comparison: the decisions the HIP forward pass actually took are read from its tape (ReLU: y > 0 of the
+layer's output; max pool: the winners of the layer's float32 input, first maximum in scan order as the kernel and ATen both
+choose; prototype maximum: the winners the cosine backward recorded in its workspace), and the oracle evaluates the SAME decision-frozen function in float64
+under autograd (oracle/ref_cpu.py: Switches, frozen_gradients).  What is left between the two gradients is rounding only:
+
+    every parameter tensor:  |hip - g64|_2 <= max(1e-5 * |g64|_2,  3 * |cpu32 - g64|_2)
+
+where cpu32 is the same frozen function evaluated in float32 by the oracle on the CPU.  The two Baselines stay under the
+absolute 1e-5 (measured: VGG-16 2e-6 .. 3.3e-6, ResNet-50 3e-6 .. 6.8e-6; their end-to-end bound is 3e-3).  Stage 1's
+meta-prototype head is ill-conditioned in float32 -- a softmax over -|x - c|^2 of 512-dimensional features, |x - c|^2 in the
+hundreds -- and there float32 arithmetic itself, CPU or GPU, sits ~1e-4 from float64; the second term holds the HIP path to
+that floor instead of letting the conditioning of the function pass as slack everywhere
+for stage-1 ResNet-50, Baseline ResNet-50 and Baseline VGG-16 at 97 x 97 (the cases whose end-to-end bound was widened in
+round 2).  The loss agrees to 1e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+BOUND = 1e-5
+FACTOR = 3.0
+
+
+def _nchw(t, perm=None):
+    t = t.detach().permute(0, 3, 1, 2).contiguous().cpu()
+    return t if perm is None else t[perm]
+
+
+def _perm(B, S, Q):
+    """oracle image order (episode-major: s.., q.. of episode 0, then episode 1 ...) -> HIP image order ([all supports | all
+    queries])."""
+    idx = []
+    for b in range(B):
+        idx += [b * S + s for s in range(S)] + [B * S + b * Q + q for q in range(Q)]
+    return torch.tensor(idx)
+
+
+def _resnet_decisions(tape, perm, prefix="encoder.backbone"):
+    d = {f"{prefix}.relu": _nchw(tape["stem"]["y"], perm) > 0}
+    d[f"{prefix}.maxpool"] = F.max_pool2d(_nchw(tape["pool_in"], perm), 3, 2, 1, ceil_mode=True, return_indices=True)[1]
+    names = [(L, i) for L, n in (("layer1", 3), ("layer2", 4), ("layer3", 6)) for i in range(n)]
+    assert len(names) == len(tape["blocks"])
+    for (L, i), rec in zip(names, tape["blocks"]):
+        for r in (1, 2, 3):
+            d[f"{prefix}.{L}.{i}.relu{r}"] = _nchw(rec[f"r{r}"]["y"], perm) > 0
+    return d
+
+
+def _stage1_tail_decisions(tape, perm, midc, prefix="encoder.purifier"):
+    d = {f"{prefix}.0.relu": _nchw(tape["ya"], perm) > 0, f"{prefix}.3.relu": _nchw(tape["yb"], perm) > 0,
+         f"{prefix}.6.aspp_0.relu": _nchw(tape["g0"], perm) > 0}
+    for i in range(1, 5):
+        d[f"{prefix}.6.aspp_{i}.relu"] = _nchw(tape["cat"][..., (i - 1) * midc:i * midc], perm) > 0
+    return d
+
+
+def _vgg_decisions(tape, perm, prefix="encoder.backbone"):
+    from pemp_amd.networks.backbones import VGG_LAYOUT
+    d, npool, prev = {}, 0, None
+    convs = iter([it for it in VGG_LAYOUT if isinstance(it, tuple)])
+    for kind, obj, relu, x, y in tape["vgg"]:
+        if kind == "conv":
+            idx = next(convs)[0]
+            if relu:
+                d[f"{prefix}.features.{idx}.relu"] = _nchw(y, perm) > 0
+            prev = y
+        else:
+            d[f"{prefix}.pool{npool}"] = F.max_pool2d(_nchw(prev, perm), 3, obj, 1, return_indices=True)[1]
+            npool += 1
+            prev = None       # the pooled tensor is the next conv's input; only conv outputs are needed here
+    return d
+
+
+def _run(tr, net, batch, model, backbone, tail):
+    """-> (hip loss, {name: hip gradient}, decisions of the HIP forward pass, oracle-ordered CPU inputs)."""
+    from oracle import ref_cpu
+    sup, msk, qry, gt = batch
+    B, S = sup.shape[:2]
+    Q = qry.shape[1]
+    perm = _perm(B, S, Q)
+    grabbed = {}
+    eng = tr.eng
+    orig_backward, orig_head = eng.backward, tr._head_hip
+
+    def spy_backward(dfeat):
+        grabbed["tape"] = dict(eng.tape)
+        return orig_backward(dfeat)
+
+    def spy_head(feat, *a):
+        grabbed["feat"] = feat.detach().clone()
+        return orig_head(feat, *a)
+
+    eng.backward, tr._head_hip = spy_backward, spy_head
+    try:
+        loss, _ = tr.forward_backward(sup, msk, qry, gt)
+    finally:
+        eng.backward, tr._head_hip = orig_backward, orig_head
+    torch.cuda.synchronize()
+    tape = grabbed["tape"]
+    dec = _vgg_decisions(tape, perm) if backbone == "vgg16" else _resnet_decisions(tape, perm)
+    if tail:
+        dec.update(_stage1_tail_decisions(tape, perm, eng.midc))
+    if model == "stage1":
+        # winning prototypes: what the cosine backward itself routed every (query pixel, group) gradient to -- it leaves them
+        # in the tail of its workspace (pemp_head_bwd_workspace_bytes).  Coinciding meta-prototypes give exact ties over whole
+        # regions, so a recomputation in other arithmetic would not reproduce these choices.
+        from pemp_amd import _lib
+        feat = grabbed["feat"]
+        c, h, w = feat.shape[3], feat.shape[1], feat.shape[2]
+        p = net.ctr.shape[1] // 2
+        n = h * w
+        nbytes = _lib.load().pemp_head_bwd_workspace_bytes(B, S, n, c, p)
+        ws = eng.ws[("head_bwd", B, S, h, w, c, p)]
+        win = ws[nbytes - B * 2 * n * 4:nbytes].view(torch.int32).view(B, 2, h, w).cpu().long()
+        assert int(win[:, 0].min()) >= 0 and int(win[:, 0].max()) < p and int(win[:, 1].min()) >= p and int(win[:, 1].max()) < 2 * p
+        # oracle layout (compute_similarity): channel 0 = background, 1 = foreground, index inside the group
+        dec["head.proto_max"] = torch.stack((win[:, 1] - p, win[:, 0]), dim=1)
+    grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.requires_grad and p.grad is not None}
+    return float(loss.item()), grads, dec
+
+
+def _compare(what, hip_loss, hip, sd, batch, dec, model, backbone):
+    from oracle import ref_cpu
+    sup, msk, qry, gt = (t.cpu() for t in batch)
+    loss64, g64, used = ref_cpu.frozen_gradients(sd, sup, msk, qry, gt, dec, model=model, backbone=backbone)
+    assert used == set(dec), (sorted(set(dec) - used), sorted(used - set(dec)))      # every decision of the pass was frozen
+    # the same frozen function in float32 on the CPU: what float32 arithmetic itself leaves of the float64 gradient
+    _, g32, _ = ref_cpu.frozen_gradients(sd, sup, msk, qry, gt, dec, model=model, backbone=backbone, dtype=torch.float32)
+    assert abs(hip_loss - loss64) <= 2e-6 * max(1.0, abs(loss64)), (hip_loss, loss64)
+    assert set(hip) == set(g64), sorted(set(hip) ^ set(g64))[:10]
+    rows = []
+    for name, g in g64.items():
+        n2 = max(g.norm().item(), 1e-30)
+        rows.append(((hip[name].double() - g).norm().item() / n2, (g32[name].double() - g).norm().item() / n2, name))
+    rows.sort(reverse=True)
+    med = rows[len(rows) // 2]
+    print(f"{what}: {len(rows)} tensors, relative L2 error vs float64: hip max {rows[0][0]:.2e} ({rows[0][2]}), median {med[0]:.2e}; "
+          f"cpu float32 max {max(r[1] for r in rows):.2e}, median {sorted(r[1] for r in rows)[len(rows) // 2]:.2e}")
+    for e_hip, e_32, name in rows[:5]:
+        print(f"   {name:50s} hip {e_hip:.2e}   cpu float32 {e_32:.2e}")
+    bad = [(n, eh, e32) for eh, e32, n in rows if eh > max(BOUND, FACTOR * e32)]
+    assert not bad, (what, bad[:10])
+    return rows
+
+
+def _batch(dev, seeds=(31, 32), H=97):
+    from pemp_amd import synth
+    b = synth.make_batch(list(seeds), shot=1, height=H, width=H, out_hw=(H, H))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0])
+
+
+def test_stage1_rn50_gradients_with_frozen_decisions(hip_lib, dev):
+    from pemp_amd.networks import pemp_stage1 as m
+    from pemp_amd.train_engine import Stage1Trainer
+    sd = util.wgen_state_dict("stage1_rn50")
+    net = m.ModelClass(None)
+    net.load_state_dict(sd)
+    tr = Stage1Trainer(net, device=dev, drop_rate=0.0)
+    batch = _batch(dev)
+    hip_loss, hip, dec = _run(tr, net, batch, "stage1", "resnet50", tail=True)
+    _compare("stage1_rn50", hip_loss, hip, sd, batch, dec, "stage1", "resnet50")
+
+
+@pytest.mark.parametrize("backbone,tag", [("vgg16", "baseline_vgg16"), ("resnet50", "baseline_rn50")])
+def test_baseline_gradients_with_frozen_decisions(hip_lib, dev, backbone, tag):
+    from pemp_amd.networks import baseline as m
+    from pemp_amd.train_baseline import BaselineTrainer
+    sd = util.wgen_state_dict(tag)
+    net = m.Baseline(None, backbone=backbone)
+    net.load_state_dict(sd)
+    tr = BaselineTrainer(net, device=dev)
+    batch = _batch(dev)
+    hip_loss, hip, dec = _run(tr, net, batch, "baseline", backbone, tail=False)
+    _compare(tag, hip_loss, hip, sd, batch, dec, "baseline", backbone)
