@@ -72,7 +72,8 @@ def test_stage1_matches_reference_golden(model, dev, fixture):
         rref = g[f"e{e}_resp_s7"]
         rgot = resp[0, ::7, ::7].cpu().numpy()
         _, margin = util.response_reference(model._last_feats, t["sup_mask"], model.ctr, 1, shot, 3, 20, hw)
-        rmask = util.assert_response_exact(rgot, rref, margin[0, ::7, ::7], what=f"{fixture} e{e}")
+        rmask = util.assert_response_exact(rgot, rref, margin[0, ::7, ::7], what=f"{fixture} e{e}",
+                                           max_masked=0.18 if fixture == "stage1_rn50_small" else 0.12)
         print(f"{fixture} e{e}: |dlogit| {lerr:.2e}  argmax pixels inside the margin {masked:.5f}  response {rmask:.4f}")
 
 

@@ -164,15 +164,18 @@ def response_reference(feats_nhwc, sup_mask, ctr, B, S, protos, dist_scalar, out
     return up(resp).long(), up(margin)
 
 
-def assert_response_exact(resp_got, resp_ref, margin_map, margin=MARGIN, what="", max_masked=0.6):
+def assert_response_exact(resp_got, resp_ref, margin_map, margin=MARGIN, what="", max_masked=0.12):
     """Exact agreement of the response index wherever its decision margin exceeds ``margin``.  Returns the masked
     fraction (coinciding meta-prototypes -- centres that attract no pixel pool to the same vector -- give exact ties
-    over whole regions; those are the masked pixels)."""
+    over whole regions; those are the masked pixels).  ``max_masked``: measured share + 0.05 -- every fixture but one has at
+    most 6.0 % of its pixels inside the margin (default bound 0.12); stage1_rn50_small's first episode has 12.2 % (its caller
+    passes 0.18)."""
     resp_got = torch.as_tensor(np.asarray(resp_got.cpu() if hasattr(resp_got, "cpu") else resp_got)).long()
     resp_ref = torch.as_tensor(np.asarray(resp_ref)).long()
     keep = margin_map > margin
     wrong = int(((resp_got != resp_ref) & keep).sum())
     masked = 1.0 - keep.float().mean().item()
+    print(f"response index {what}: {masked:.4f} of the pixels inside the {margin:g} margin (bound {max_masked:.4f}), {wrong} mismatches outside")
     assert wrong == 0, f"{what}: {wrong} response-index mismatches outside the {margin:g} margin"
     assert masked <= max_masked, f"{what}: {masked:.4f} of the response pixels inside the margin"
     return masked
