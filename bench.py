@@ -666,6 +666,20 @@ def device_sync(dev):
 
 def timed_train_steps(tr, pool, steps, warmup, world, dev):
     """W untimed + K timed ``train_step`` calls between barriers -> (seconds [MAX over ranks], host ms per step, losses)."""
+    if world > 1:
+        # kernel variants are timed by rank 0 only and broadcast (pemp_amd.ops.tuned_by_rank0); that extra step is rank-local
+        # (no gradient collective: the ranks do not run it at the same time)
+        from pemp_amd import ops
+
+        def local_step():
+            tr.collectives = False
+            try:
+                tr.train_step(*pool[0])
+                device_sync(dev)
+            finally:
+                tr.collectives = True
+        ops.tuned_by_rank0(local_step)
+        beat()
     for i in range(warmup):
         tr.train_step(*pool[i % len(pool)])
         beat()
@@ -816,6 +830,12 @@ class EvalRunner:
         return am
 
     def timed(self, steps, warmup, world, dev):
+        if world > 1:                   # kernel variants are timed by rank 0 only and broadcast
+            def first():
+                self.step(0, log=False)
+                torch.cuda.synchronize()
+            self.ops.tuned_by_rank0(first)
+            beat()
         for i in range(warmup):
             self.step(i, log=False)
             beat()

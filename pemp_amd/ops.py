@@ -99,6 +99,36 @@ def save_picks():
         json.dump(out, f)
 
 
+def export_picks():
+    """Everything the autotuners have decided so far, as one picklable object (see ``tuned_by_rank0``)."""
+    return {"tiles": dict(_TILE_CACHE), "wgrad": dict(WGRAD_PICKS)}
+
+
+def import_picks(picks):
+    _TILE_CACHE.update(picks["tiles"])
+    WGRAD_PICKS.update(picks["wgrad"])
+
+
+def tuned_by_rank0(warm):
+    """Run ``warm()`` -- one untimed step that meets every conv / weight-gradient shape of the job -- so that only RANK 0
+    times kernel variants: it warms first, its picks are broadcast (one ``broadcast_object_list`` of a few KB), the other
+    ranks then warm with every shape already in the cache.  All ranks run the same variants afterwards (the split-K and
+    weight-gradient split choices change the rounding: data-parallel replicas should not differ in them), and N - 1 ranks do
+    not spend their warm-up on timing runs.  One process / no process group: just ``warm()``."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        warm()
+        return
+    rank = dist.get_rank()
+    if rank == 0:
+        warm()
+    box = [export_picks() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    if rank != 0:
+        import_picks(box[0])
+        warm()
+
+
 def _pick_tile(launch, p, key, cout, only=None):
     """Time the candidate variants for this (layer, input shape) and remember the fastest: two rounds over all
     candidates (the minimum of a variant's two timings counts: a round can be disturbed by whatever else the GPU is

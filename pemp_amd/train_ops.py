@@ -198,7 +198,9 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=N
 
     if blocks is None:
         from . import ops
-        key = (cin, cout, p.kh, p.kw, p.stride, p.pad, p.dil, bool(p.stem), n, h, w)
+        # the pick depends on which kernel generation runs: the explicit ``variant`` and what decides the library's own choice
+        # (geometry, strides) are part of the key -- a pick made for variant 1 must never be replayed for variant 0
+        key = (cin, cout, p.kh, p.kw, p.stride, p.pad, p.dil, bool(p.stem), n, h, w, int(variant), ldx, ldg)
         blocks = _WGRAD_BLOCKS.get(key)
         if blocks is None:
             blocks = 0

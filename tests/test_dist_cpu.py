@@ -216,9 +216,11 @@ def test_bench_train_control_flow_two_ranks_with_the_rank0_roofline_pass():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["episodes_per_step"] == 4
     assert "roofline" in out and "error" not in out["roofline"], out.get("roofline")
-    # 5 steps of lr 0.1 on the MEAN gradient of the ranks ((1 + 2) / 2): every all-reduce of the timed part paired up
-    assert abs(out["config"]["stub_weight"] - (-0.1 * 1.5 * 5)) < 1e-6
-    assert out["config"]["last_loss"] == 5.0          # rank 0 made exactly 5 calls before the roofline pass
+    # rank 0: one rank-local step first (kernel variants are timed by rank 0 alone and broadcast, ops.tuned_by_rank0: its own
+    # gradient 1, no collective), then 5 steps of lr 0.1 on the MEAN gradient of the ranks ((1 + 2) / 2): every all-reduce
+    # of the warm-up and of the timed part paired up
+    assert abs(out["config"]["stub_weight"] - (-0.1 * 1.0 - 0.1 * 1.5 * 5)) < 1e-6
+    assert out["config"]["last_loss"] == 6.0          # rank 0 made exactly 1 + 5 calls before the roofline pass
 
 
 def test_bench_train_stub_roofline_pass_with_collectives_left_on_would_mismatch():
@@ -316,3 +318,89 @@ def test_two_rank_buffers_and_prior_network_are_synchronised():
     assert not np.allclose(b0, b1)                          # they had drifted apart ...
     assert np.array_equal(a0, b0) and np.array_equal(a1, b0) and n0 == n1     # ... and both hold rank 0's afterwards
     assert all(np.array_equal(x, y) for x, y in zip(pr0, pr1))
+
+
+# ---------------------------------------------------------------------------------------------
+# eight ranks (the node BASELINE.json's configs run on): ragged episode shards, ranks without an episode in the last batch,
+# the gradient buckets, the rank-0 autotune broadcast
+# ---------------------------------------------------------------------------------------------
+def _eight_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pemp_amd import ops
+        from pemp_amd.entry.pemp_stage1 import shard_indices
+        from pemp_amd.train_engine import GradBuckets, allreduce_gradients
+        res = {"round": _round(n, rank, world), "mine": list(shard_indices(n, rank, world))}
+        # gradient buckets: the flat buffer finished from its end, four buckets, every rank the same schedule
+        nfl = 1 << 14
+        flat = torch.full((nfl,), float(rank + 1))
+        b = GradBuckets(flat, [nfl // 4, nfl // 2, 3 * nfl // 4], min_bytes=nfl)
+        b.enabled = True
+        for lo in (3 * nfl // 4, nfl // 2, nfl // 4, 0):
+            b.ready_from(lo)
+        res["scale"] = b.finish()
+        res["bucket_sum"] = (float(flat.min()), float(flat.max()), len(b.buckets))
+        whole = torch.full((1000,), float(rank + 1))
+        res["whole_scale"] = allreduce_gradients(whole)
+        res["whole_sum"] = float(whole[0])
+        # kernel picks: only rank 0 "times", everybody ends up with its choices
+        calls = []
+
+        def warm():
+            calls.append(len(ops._TILE_CACHE))
+            if rank == 0:
+                ops._TILE_CACHE[("test-shape", 1)] = 34
+                ops.WGRAD_PICKS[("test-wgrad", 2)] = (2, 512)
+        ops.tuned_by_rank0(warm)
+        res["picks"] = (ops._TILE_CACHE.get(("test-shape", 1)), ops.WGRAD_PICKS.get(("test-wgrad", 2)), calls)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_eval_round_buckets_and_autotune_broadcast():
+    n, world = 37, 8                            # ranks 0..4 evaluate 5 episodes, ranks 5..7 four: the last "batch" is ragged
+    single = _round(n, 0, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = sorted(i for r in range(world) for i in got[r]["mine"])
+    assert seen == list(range(n)) and [len(got[r]["mine"]) for r in range(world)] == [5, 5, 5, 5, 5, 4, 4, 4]
+    for r in range(world):
+        miou, biou, stat, loss, cnt = got[r]["round"]
+        assert miou == single[0] and biou == single[1] and np.array_equal(stat, single[2]) and cnt == n
+        assert abs(loss - single[3]) < 1e-9
+        assert got[r]["scale"] == 1.0 / world and got[r]["bucket_sum"] == (36.0, 36.0, 4)          # 1 + 2 + ... + 8
+        assert got[r]["whole_scale"] == 1.0 / world and got[r]["whole_sum"] == 36.0
+        tile, wg, calls = got[r]["picks"]
+        assert tile == 34 and tuple(wg) == (2, 512) and len(calls) == 1
+    # the seven other ranks warmed AFTER the broadcast: rank 0's pick was already in their cache when warm() ran
+    assert all(got[r]["picks"][2][0] >= 1 for r in range(1, world))
+
+
+def test_eight_rank_eval_with_fewer_episodes_than_ranks():
+    """5 episodes on 8 ranks: three ranks have nothing to evaluate and still take part in the round's all-reduce."""
+    n, world = 5, 8
+    single = _round(n, 0, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        miou, biou, stat, loss, cnt = got[r]
+        assert cnt == n and np.array_equal(stat, single[2]) and (miou == single[0] or (np.isnan(miou) and np.isnan(single[0])))
