@@ -325,9 +325,19 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         part[((mi * TN + ni) * 4 + q) * 64] = v4f{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-            // sk_ws is UNCACHED device memory (pemp_uncached_alloc): stores complete in memory, loads come from memory,
-            // whichever XCD issues them -- no L2 write-back / invalidate (measured: agent-scope fences here cost the
-            // 128 x 128 variant 118 -> 94 TFLOP/s, every fence flushing and emptying an XCD's L2 under the other tiles)
+            // sk_ws is UNCACHED device memory (pemp_uncached_alloc: hipDeviceMallocUncached, MTYPE UC): stores complete in memory,
+            // loads come from memory, whichever XCD issues them -- no L2 write-back / invalidate (measured: agent-scope fences here
+            // cost the 128 x 128 variant 118 -> 94 TFLOP/s, every fence flushing and emptying an XCD's L2 under the other tiles).
+            // What the hand-off relies on, stated: (1) UC lines are never allocated in an XCD's L2 or a CU's L1, so there is no
+            // stale copy for the reading block to hit -- the pieces are read exactly once, by non-temporal loads, after the counter
+            // said so; (2) `s_waitcnt vmcnt(0)` returns only when the fabric has acknowledged this wave's UC stores (write-through
+            // to memory); every storing wave executes it BEFORE the block barrier, and the ONE counter add of the block comes
+            // after that barrier -- the order MI355X_MICROARCH.md gives for a drained write-through publish ("every storing wave's
+            // vmcnt(0), the workgroup's barrier, then the flag / counter"); (3) the counter add is a returning agent-scope atomic,
+            // executed at the memory side, and the reader's loads are issued only after its value came back and after a block
+            // barrier.  Not an architectural guarantee of the HIP memory model: tests/test_train_ops_gpu.py
+            // (test_split_k_hand_off_is_complete_and_stable_under_uneven_load) holds every word of every launch to it, for
+            // every variant and 1 .. 128 remainder tiles, with a second stream loading the memory system unevenly.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's partial stores have been acknowledged
             __syncthreads();                                               // ... everybody's
             int* flag = (int*)smem;

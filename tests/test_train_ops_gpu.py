@@ -458,3 +458,41 @@ def test_split_k_conv_variants_match_the_unsplit_conv(hip_lib, dev, case):
     if M >= 8 * 51 * 51:
         desc = ops.ConvDesc(N, H, W, Cin, Cin, H, W, Cout, Cout, k, k, 1, p, d, 0, kpad, 0, 31)
         assert lib.pemp_conv2d_splitk_workspace_bytes(ops.C.byref(desc)) > 0       # the training shapes do split
+
+
+@pytest.mark.parametrize("tile", [31, 32, 34, 35, 36, 37])
+def test_split_k_hand_off_is_complete_and_stable_under_uneven_load(hip_lib, dev, tile):
+    """The cross-XCD hand-off of the split-K variants (partial tiles through uncached memory, `s_waitcnt vmcnt(0)` + block
+    barrier + one agent-scope atomic add per block, the last block to arrive reads every piece back; conv_dma2.hip) for
+    remainder-tile counts 1 .. 128: every output word of every launch equals the first launch's (a piece read before it
+    had landed would change words of that tile), and the result is the unsplit conv's up to the rounding of the regrouped
+    sum -- while a second stream keeps the memory system busy with a large copy and idle gaps (uneven load: the
+    condition under which a missing release / acquire shows, MI355X_MICROARCH.md "Test every hand-off")."""
+    from pemp_amd import ops
+    bm, bn = ops.TILE_VARIANTS[tile - 10]
+    Cin, Cout = 256, bn                                     # one column of tiles: the tile count is ceil(M / bm)
+    w = _rand(Cout, Cin, 1, 1, seed=2, lo=-0.1, hi=0.1)
+    packed, kpad = ops.pack_conv_weight(w.to(dev))
+    prm = ops.ConvParams(packed, None, None, Cin, Cout, 1, 1, 1, 0, 1, kpad, False, False)
+    big_a, big_b = torch.empty(64 << 20, device=dev), torch.empty(64 << 20, device=dev)       # 256 MB each: past the Infinity Cache
+    side = torch.cuda.Stream(device=dev)
+    for rem in (1, 2, 5, 31, 64, 100, 128):
+        rows = (256 + rem) * bm - 5                         # ragged last tile
+        H = 64
+        Wd = (rows + H - 1) // H
+        x = torch.randn(1, H, Wd, Cin, device=dev, generator=torch.Generator(device=dev).manual_seed(rem))
+        desc = ops.ConvDesc(1, H, Wd, Cin, Cin, H, Wd, Cout, Cout, 1, 1, 1, 0, 1, 0, kpad, 0, tile)
+        split = hip_lib.pemp_conv2d_splitk_workspace_bytes(ops.C.byref(desc)) > 0
+        T_ = (H * Wd + bm - 1) // bm
+        assert split == (1 <= T_ % 256 <= 128), (rem, T_)
+        ref = ops.conv2d(x, prm, tile=tile - 10)
+        first = ops.conv2d(x, prm, tile=tile).clone()
+        assert (first - ref).abs().max() <= 1e-5 * ref.abs().max(), (tile, rem)
+        side.wait_stream(torch.cuda.current_stream())
+        for rep in range(6):
+            with torch.cuda.stream(side):                   # bursts of traffic beside every other launch
+                if rep % 2 == 0:
+                    big_b.copy_(big_a)
+            y = ops.conv2d(x, prm, tile=tile)
+            assert torch.equal(y, first), (tile, rem, rep)
+        torch.cuda.current_stream().wait_stream(side)
