@@ -362,6 +362,12 @@ int pemp_sgd_clip_step_f32(float* params, const float* grads, float* momentum_bu
                            float max_norm, float lr, float momentum, float weight_decay, int first_step,
                            float grad_scale, int nesterov, float* grad_norm_out, void* ws, size_t ws_bytes,
                            void* stream);
+/* clip_grad_norm_(max_norm) + torch.optim.Adam(lr, betas, eps, weight_decay).step() (reference core/solver.py:92-96,
+ * tr.opt = adam; ATen's operation order, L2 weight decay, no amsgrad).  exp_avg / exp_avg_sq: the optimizer state, zero before
+ * the first update; step: 1-based number of this update.  Workspace: pemp_sgd_workspace_bytes().                          */
+int pemp_adam_clip_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                            float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            long long step, float grad_scale, float* grad_norm_out, void* ws, size_t ws_bytes, void* stream);
 
 /* Train-time regularisers.  Random numbers: counter-based Philox4x32-10, element i of stream (seed, offset)
  * (reproducible across launches / graph replays; the reference's torch generator stream is not reproducible,

@@ -6,8 +6,8 @@ as the holder of hyper-parameters and scheduler state (``param_groups[0]["lr"]``
 ReduceLROnPlateau / CosineAnnealingLR / PolyLR all work on it unchanged); the parameter update itself
 is NOT ``optimizer.step()`` but the fused clip-norm + SGD kernel on the flat buffers
 (``Stage1Trainer.optimizer_step``), which reads lr / momentum / weight decay / nesterov from it.
-``opt=adam`` returns a real ``torch.optim.Adam``; the trainers then call its ``step()`` on the parameter
-views (and the reference's own Trainer code can do so directly through ``pemp_amd.autograd``).
+``opt=adam`` returns a real ``torch.optim.Adam`` whose hyper-parameters feed the fused clip + Adam kernel in the same way
+(the reference's own Trainer code can also call its ``step()`` directly through ``pemp_amd.autograd``).
 """
 import torch
 
@@ -93,8 +93,8 @@ def get(model, _config=None, max_steps=200001):
         optimizer = torch.optim.SGD(params, cfg["lr"], momentum=cfg["sgd_momentum"], weight_decay=cfg["weight_decay"],
                                     nesterov=cfg["sgd_nesterov"])
     elif cfg["opt"] == "adam":
-        # no fused kernel for Adam: torch.optim.Adam steps on the parameter views of the flat buffer (the gradients
-        # still come from the HIP backward); reference core/solver.py:92-96
+        # reference core/solver.py:92-96; the trainers run the fused clip + Adam kernel (pemp_adam_clip_step_f32) with this
+        # object's hyper-parameters, as they do for SGD
         optimizer = torch.optim.Adam(params, cfg["lr"], betas=(cfg["adam_beta1"], cfg["adam_beta2"]),
                                      eps=cfg["adam_epsilon"], weight_decay=cfg["weight_decay"])
     else:

@@ -849,8 +849,19 @@ class Stage1Trainer:
 
     def apply_update(self, scale):
         f = self.eng.flat
+        if type(self.optimizer) is torch.optim.Adam and not any(g.get("amsgrad") or g.get("maximize") for g in self.optimizer.param_groups):
+            # tr.opt = adam (core/solver.py:92-96): fused clip + Adam on the flat buffers; the torch object holds the
+            # hyper-parameters (and its LR scheduler), the moments live beside the flat parameters
+            g = self.optimizer.param_groups[0]
+            if getattr(f, "exp_avg", None) is None:
+                f.exp_avg, f.exp_avg_sq, f.adam_step = torch.zeros_like(f.data), torch.zeros_like(f.data), 0
+            f.adam_step += 1
+            self.last_grad_norm = T.adam_clip_step(f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.adam_step, self.max_norm, g["lr"],
+                                                   g["betas"], g["eps"], g.get("weight_decay", 0.0), grad_scale=scale,
+                                                   ws_cache=self.eng.ws)
+            return
         if self.optimizer is not None and not isinstance(self.optimizer, torch.optim.SGD):
-            # any other torch optimizer (tr.opt=adam, core/solver.py:92-96) steps on the parameter views itself
+            # any other torch optimizer steps on the parameter views itself
             if scale != 1.0:
                 f.grad.mul_(scale)
             f.attach_grads()

@@ -425,6 +425,22 @@ def sgd_clip_step(params, grads, buf, max_norm, lr, momentum, weight_decay, firs
     return norm
 
 
+def adam_clip_step(params, grads, exp_avg, exp_avg_sq, step, max_norm, lr, betas, eps, weight_decay, grad_scale=1.0, ws_cache=None):
+    """Flat-buffer clip_grad_norm_ + torch.optim.Adam step (``step``: 1-based number of this update).  Returns the 1-element
+    tensor holding ||grads||_2."""
+    lib = _lib.load()
+    _chk_dev(params, grads, exp_avg, exp_avg_sq)
+    n = params.numel()
+    if any(t.numel() != n or not t.is_contiguous() for t in (params, grads, exp_avg, exp_avg_sq)):
+        raise ValueError("adam_clip_step: flat contiguous buffers of equal length required")
+    norm = torch.empty(1, dtype=torch.float32, device=params.device)
+    ws = _ws(lib.pemp_sgd_workspace_bytes(), params.device, ws_cache, ("sgd",))
+    _lib.check(lib.pemp_adam_clip_step_f32(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), n, float(max_norm), float(lr),
+                                           float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
+                                           float(grad_scale), _p(norm), _p(ws), ws.numel(), _stream()), "adam_clip_step")
+    return norm
+
+
 def head_bwd_dlogits(sup_feat, qry_feat, sup_mask, ctr, fwd_ws, protos, dlogits, dfeat, B, S, p, dist_scalar,
                      ws_cache=None, map_full_res=False):
     """``head_bwd`` for an arbitrary gradient of the logits ``dlogits`` [B,2,Ho,Wo] (autograd's grad_output)."""

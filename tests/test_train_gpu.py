@@ -95,6 +95,30 @@ def test_optimizer_step_matches_torch_sgd(hip_lib, dev):
     fresh.load_state_dict({k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()})
 
 
+def test_fused_adam_step_matches_torch_adam(hip_lib, dev):
+    """tr.opt = adam (reference core/solver.py:92-96): three updates by the fused clip + Adam kernel on the flat buffers ==
+    clip_grad_norm_ + torch.optim.Adam(betas, eps, weight_decay) on copies of the same parameters fed the same gradients."""
+    tr, net = _trainer(dev)
+    plist = [p for p in net.parameters() if p.requires_grad]
+    ref = [torch.nn.Parameter(p.detach().clone().contiguous()) for p in plist]
+    hp = dict(lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    opt_ref = torch.optim.Adam(ref, **hp)
+    tr.attach_optimizer(torch.optim.Adam(plist, **hp))
+    for step, seeds in enumerate(((31, 32), (33, 34), (35, 36))):
+        sup, msk, qry, gt = _batch(dev, seeds)
+        tr.forward_backward(sup, msk, qry, gt)
+        for r, p in zip(ref, plist):
+            r.grad = p.grad.detach().clone().contiguous()
+        total = torch.nn.utils.clip_grad_norm_(ref, 1.1)
+        opt_ref.step()
+        tr.optimizer_step()
+        assert abs(tr.last_grad_norm.item() - total.item()) <= 1e-5 * total.item()
+        for r, p in zip(ref, plist):
+            assert torch.allclose(p.detach(), r.detach(), rtol=2e-6, atol=2e-7), step
+            r.data.copy_(p.detach())           # same starting point for the next step: rounding does not accumulate into the comparison
+    assert tr.eng.flat.adam_step == 3 and not tr.optimizer.state      # the torch object only carries the hyper-parameters
+
+
 def test_two_steps_reduce_loss_and_dropblock_runs(hip_lib, dev):
     from pemp_amd.networks import pemp_stage1 as m
     from pemp_amd.train_engine import Stage1Trainer
