@@ -32,6 +32,7 @@ OUT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from pemp_amd import synth  # noqa: E402
+from tests.golden.cases import cedt_cases, metric_cases, metric_cases_coco, stage2_train_prior  # noqa: E402
 
 
 def _install_standins():
@@ -429,13 +430,6 @@ def gen_train_step_stage1_vgg(tmp):
     print("wrote stage-1 VGG16 train step; loss", float(loss.detach()))
 
 
-def stage2_train_prior(qry_mask):
-    """Deterministic stand-in for the stage-1 argmax prior of the stage-2 train-step fixture: the query
-    foreground shifted by (3, 5) pixels (the real prior path is pinned by the stage-2 eval fixtures)."""
-    fg = (qry_mask[:, 0] == 1)
-    return np.roll(fg, (3, 5), axis=(1, 2)).astype(np.int64)[:, None]          # [BQ,1,H,W]
-
-
 def gen_train_step_stage2(tmp, shot=1, seeds=(31, 32), out="stage2_rn50cm_trainstep", H=97):
     """G11: loss and gradients of one stage-2 training step (entry/pemp_stage2.py:72-83): ResNet-50+CM in
     train() mode (batch-stat BN, Dropout2d off = drop_rate2 0), B=2 episodes, 97x97, CE loss.
@@ -475,18 +469,6 @@ def gen_train_step_stage2(tmp, shot=1, seeds=(31, 32), out="stage2_rn50cm_trains
     print("wrote stage-2 train step", out, "; loss", float(loss))
 
 
-def cedt_cases():
-    """Targets / logits of the CELossDT fixture (shared with the tests): two 97x97 query masks (one with an ignored
-    corner), one 333x500 mask, an all-background and an all-foreground map; logits from a seeded generator."""
-    ts = [torch.from_numpy(synth.make_episode(s, out_hw=hw)["qry_mask"][0]) for s, hw in ((41, (97, 97)), (42, (97, 97)))]
-    t = torch.stack(ts)
-    t[0, :4, :9] = 255
-    cases = [t, torch.from_numpy(synth.make_episode(43, out_hw=(333, 500))["qry_mask"]),
-             torch.zeros(1, 40, 57, dtype=torch.int64), torch.ones(1, 9, 11, dtype=torch.int64)]
-    g = torch.Generator().manual_seed(77)
-    return [(c, torch.rand(c.shape[0], 2, *c.shape[-2:], generator=g) * 6 - 3) for c in cases]
-
-
 def gen_cedt():
     """G18: CELossDT of the reference itself (core/losses.py:17-43): weight maps and loss values.  The class is written
     for numpy < 1.24 and a CUDA box: ``np.bool`` is aliased to ``bool`` and ``Tensor.cuda`` is the identity while it
@@ -514,17 +496,6 @@ def gen_cedt():
     print("wrote cedt_reference", [float(res[f"c{n}_loss"]) for n in range(4)])
 
 
-def metric_cases():
-    rng = np.random.RandomState(0)
-    out = []
-    for cls in (1, 3, 3, 5, 17):
-        pred = rng.randint(0, 2, (1, 40, 50))
-        ref = rng.randint(0, 2, (1, 40, 50))
-        ref[0, :3] = 255
-        out.append((pred, ref, [cls]))
-    return out
-
-
 def gen_metric():
     """G19: FewShotMetric / Accumulator of the reference itself (core/metrics.py:4-66) on seeded predictions."""
     from core.metrics import Accumulator, FewShotMetric
@@ -541,18 +512,6 @@ def gen_metric():
                         biou=np.array(meanb), acc_loss=np.array(acc.mean("loss")), acc_miou=acc.mean("miou", axis=0),
                         acc_n=np.array(acc.mean("n")))
     print("wrote metric_reference", float(mean), float(meanb))
-
-
-def metric_cases_coco():
-    """COCO-20i, split 1: labels 21..40 of an [81, 3] table; every label once, two of them twice, one ignored band."""
-    rng = np.random.RandomState(1)
-    out = []
-    for cls in list(range(21, 41)) + [21, 40]:
-        pred = rng.randint(0, 2, (1, 48, 64))
-        ref = rng.randint(0, 2, (1, 48, 64))
-        ref[0, -2:] = 255
-        out.append((pred, ref, [cls]))
-    return out
 
 
 def gen_metric_coco():

@@ -95,7 +95,7 @@ def test_reference_trainer_body_runs_on_stage1(hip_lib, dev):
 
 def test_reference_trainer_body_runs_on_baseline_and_stage2(hip_lib, dev):
     from pemp_amd.networks import baseline as mb, pemp_stage2 as m2
-    from tests.golden.make_golden import stage2_train_prior
+    from tests.golden.cases import stage2_train_prior
     sup, msk, qry, gt, b = _batch(dev)
     for backbone, tag in (("vgg16", "baseline_vgg16"), ("resnet50", "baseline_rn50")):
         g = util.gold(tag + "_trainstep")

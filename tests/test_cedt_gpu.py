@@ -33,7 +33,7 @@ def test_cedt_weight_and_loss_match_the_reference_class(hip_lib, dev):
     (tests/golden/cedt_reference.npz, make_golden.py --only cedt)."""
     from pemp_amd import ops
     from tests import util
-    from tests.golden.make_golden import cedt_cases
+    from tests.golden.cases import cedt_cases
     g = util.gold("cedt_reference")
     for n, (tgt, logits) in enumerate(cedt_cases()):
         w = ops.cedt_weight(tgt.to(dev), 5.0)

@@ -180,7 +180,7 @@ def test_oracle_train_step_matches_the_reference_gradients():
 def test_oracle_celoss_dt_matches_the_reference_class():
     """CELossDT restatement vs weight maps / losses the reference's own core/losses.py produced (cedt_reference.npz)."""
     from oracle import ref_cpu
-    from tests.golden.make_golden import cedt_cases
+    from tests.golden.cases import cedt_cases
     g = util.gold("cedt_reference")
     for n, (tgt, logits) in enumerate(cedt_cases()):
         assert np.array_equal(ref_cpu.cedt_weight(tgt, 5.0).numpy(), g[f"c{n}_weight"]), n
@@ -228,7 +228,7 @@ def test_metric_matches_the_reference_module():
     """FewShotMetric (oracle and product) and Accumulator vs the numbers the reference's core/metrics.py produced."""
     from oracle import ref_cpu
     from pemp_amd.core.metrics import Accumulator, FewShotMetric
-    from tests.golden.make_golden import metric_cases
+    from tests.golden.cases import metric_cases
     g = util.gold("metric_reference")
     a, b = ref_cpu.FewShotMetric(20), FewShotMetric(20)
     for pred, ref, cls in metric_cases():
@@ -254,7 +254,7 @@ def test_coco20i_metric_matches_the_reference_module():
     from oracle import ref_cpu
     from pemp_amd.core.metrics import FewShotMetric
     from pemp_amd.data_kits.datasets import get_class_name, get_val_labels, num_classes
-    from tests.golden.make_golden import metric_cases_coco
+    from tests.golden.cases import metric_cases_coco
     g = util.gold("metric_reference_coco")
     n = num_classes("COCO")
     assert n == 80 and num_classes("PASCAL") == 20

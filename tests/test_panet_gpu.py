@@ -165,7 +165,7 @@ def test_five_shot_train_steps_match_reference_gradients(hip_lib, dev):
     # stage 2, 5-shot: the communication modules' episode means run over S + Q = 6 images
     from pemp_amd.networks import pemp_stage2 as m2
     from pemp_amd.train_stage2 import Stage2Trainer
-    from tests.golden.make_golden import stage2_train_prior
+    from tests.golden.cases import stage2_train_prior
     b = synth.make_batch([41, 42], shot=5, height=97, width=97, out_hw=(97, 97))
     g = util.gold("stage2_rn50cm_trainstep5")
     net = m2.ModelClass(5, 1, None)

@@ -180,7 +180,7 @@ def test_stage2_train_step_matches_reference(hip_lib, dev, fixture):
     (linear*: with one episode per batch the communication module's output is constant over the batch and the
     following batch-statistics BN removes it -- exact gradient 0, fp32 rounding noise on both sides.)"""
     from pemp_amd import ops
-    from tests.golden.make_golden import stage2_train_prior
+    from tests.golden.cases import stage2_train_prior
     from pemp_amd import synth
     g = util.gold(fixture)
     g64 = util.gold(fixture + "_f64")
@@ -360,7 +360,7 @@ def test_segmented_graph_step_equals_the_eager_step(hip_lib, dev, model):
     from pemp_amd.train_baseline import BaselineTrainer
     from pemp_amd.train_engine import Stage1Trainer
     from pemp_amd.train_stage2 import Stage2Trainer
-    from tests.golden.make_golden import stage2_train_prior
+    from tests.golden.cases import stage2_train_prior
     batches = []
     for s in range(5):
         b = synth.make_batch([31 + 2 * s, 32 + 2 * s], shot=1, height=97, width=97, out_hw=(97, 97))
