@@ -61,6 +61,18 @@ def import_torchvision_trunk(trunk, path, resnet=True):
     trunk.load_state_dict(cur)
 
 
+MAX_PROTOS = 4      # the prototype-head kernels hold 2 * protos <= 8 rows per pixel in registers (csrc/head_common.h: MAXJ)
+
+
+def check_protos(protos, key):
+    """The reference accepts any ``protos`` (networks/pemp_stage1.py:26,104-105; default 3); this build's head kernels are
+    written for at most MAX_PROTOS per class.  Fail at model construction, not inside a kernel launch."""
+    if not 0 <= int(protos) <= MAX_PROTOS:
+        raise ValueError(f"{key} = {protos}: this build supports 0 (plain masked average pooling) .. {MAX_PROTOS} prototypes "
+                         f"per class (the head kernels keep 2 * protos <= 8 rows per pixel in registers; MAXJ in "
+                         f"pemp_amd/csrc/head_common.h)")
+
+
 class _HeadMixin:
     """Episode head shared by stage 1 / stage 2 / baseline: prototypes -> cosine map -> upsample."""
 
@@ -186,6 +198,7 @@ class PEMPStage1(_HeadMixin, backbones.BaseModel):
             import_torchvision_trunk(trunk, pretrained, resnet=backbone != "vgg16")
         elif logger is not None:
             logger.info(f"           ==> pretrained file {pretrained} not found: backbone left at random init")
+        check_protos(protos, "net.protos")
         self.ctr = nn.Parameter(torch.rand(out_channels, protos * 2), requires_grad=True) if protos > 0 else None
         if logger is not None:
             logger.info(f"           ==> Model {self.__class__.__name__} created")

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .. import engine, ops
 from . import backbones
-from .pemp_stage1 import (net_ingredient, PEMPStage1, pretrained_weights, backbone_error,  # noqa: F401
+from .pemp_stage1 import (net_ingredient, PEMPStage1, pretrained_weights, backbone_error, check_protos,  # noqa: F401
                           _HeadMixin, _RES_LAYERS)
 
 PriorNet = PEMPStage1
@@ -84,6 +84,7 @@ class PEMPStage2(_HeadMixin, backbones.BaseModel):
             self.__class__.__name__ = "PEMP_Stage2/Resnet50" + cm * "+CM"
             if pretrained is not None and Path(pretrained).exists():
                 import_torchvision_trunk_cm(trunk, pretrained)
+        check_protos(protos2, "net.protos2")
         self.ctr = nn.Parameter(torch.rand(out_channels, protos2 * 2), requires_grad=True) if protos2 > 0 else None
         self.adaptive_p = None
         if logger is not None:
