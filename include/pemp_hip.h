@@ -313,6 +313,12 @@ int pemp_maxpool2d_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int 
 /* dst[n,hs*s,ws*s,:] = src[n,hs,ws,:], zero elsewhere: input gradient of a stride-s 1x1 conv.     */
 int pemp_scatter_strided_nhwc_f32(const float* src, float* dst, int N, int H, int W, int Hs, int Ws,
                                   int C, int s, void* stream);
+/* The KRSC weights of the input-gradient convs of EVERY conv layer of a flat parameter buffer, in one launch: layer l's
+ * forward weight W[Cout][taps][Cin] at params + off becomes D[Cin][taps][Cout] (taps flipped) at mirror + off -- what
+ * pemp_conv2d_nhwc_f32 needs to compute dL/dx as a convolution of dL/dy (autograd of nn.Conv2d w.r.t. its input,
+ * reference entry/pemp_stage1.py:61).  table: device int32 [L][6] = {off, Cout, taps, Cin, first tile, tiles along Cin},
+ * tiles of 32 x 32 (Cout x Cin) per tap; total_tiles = their sum.  Refreshed once per training step.                     */
+int pemp_dgrad_mirror_f32(const float* params, float* mirror, const int32_t* table, int L, int total_tiles, void* stream);
 /* dst[n][i][c] += v[n][c] / HW : backward of F.adaptive_avg_pool2d(x,(1,1)).                      */
 int pemp_gap_bwd_add_nhwc_f32(const float* v, float* dst, int ld, int N, int HW, int C, void* stream);
 /* Same as pemp_eval_tail_f32 with per-pixel CE weights (CELossDT, core/losses.py:33-43): stats[b][0] =

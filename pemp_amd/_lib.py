@@ -121,6 +121,7 @@ SYMBOLS = {
     "pemp_sgd_workspace_bytes": (c_size, []),
     "pemp_sgd_clip_step_f32": (c_int, [c_fp, c_fp, c_fp, C.c_longlong, C.c_float, C.c_float, C.c_float,
                                        C.c_float, c_int, C.c_float, c_int, c_fp, c_fp, c_size, c_fp]),
+    "pemp_dgrad_mirror_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
     "pemp_adam_clip_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, C.c_longlong] + [C.c_float] * 6 + [C.c_longlong, C.c_float, c_fp, c_fp,
                                                                                                   c_size, c_fp]),
 }

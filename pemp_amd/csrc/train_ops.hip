@@ -536,6 +536,42 @@ __global__ void scatter_strided_kernel(const float* __restrict__ src, float* __r
     }
 }
 
+// Input-gradient weights of every conv of a flat parameter buffer in one launch: for layer l (KRSC weight W[co][t][ci] at
+// params + off) the mirror holds D[ci][T-1-t][co] at mirror + off -- the KRSC weight of the conv that computes the input
+// gradient (taps flipped, channels transposed).  One 32 x 32 (co x ci) tile of one tap per block, transposed through LDS:
+// reads run along ci, writes along co, both in 128-byte rows.  table[l] = {off, cout, taps, cin, first tile, tiles along ci}.
+__global__ __launch_bounds__(256) void dgrad_mirror_kernel(const float* __restrict__ params, float* __restrict__ mirror,
+                                                           const int* __restrict__ table, int L) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.x;
+    int lo = 0, hi = L - 1;                     // last layer whose first tile is <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 6 + 4] <= b) lo = mid; else hi = mid - 1;
+    }
+    const int* e = table + lo * 6;
+    const int off = e[0], cout = e[1], taps = e[2], cin = e[3], tci = e[5];
+    int t = b - e[4];
+    const int ti = t % tci;
+    t /= tci;
+    const int tco = (cout + 31) >> 5;
+    const int to = t % tco, tap = t / tco;
+    const int x = threadIdx.x & 31, y0 = threadIdx.x >> 5;
+    const float* src = params + off;
+    float* dst = mirror + off;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = to * 32 + y0 + 8 * k, ci = ti * 32 + x;
+        tile[y0 + 8 * k][x] = (co < cout && ci < cin) ? src[((size_t)co * taps + tap) * cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ci = ti * 32 + y0 + 8 * k, co = to * 32 + x;
+        if (ci < cin && co < cout) dst[((size_t)ci * taps + (taps - 1 - tap)) * cout + co] = tile[x][y0 + 8 * k];
+    }
+}
+
 // y[n][i][c] = v[n][c] / HW  (backward of the global average pool) added into dst
 __global__ void gap_bwd_add_kernel(const float* __restrict__ v, float* __restrict__ dst, int ld, int HW, int C4,
                                    long long total) {
@@ -808,6 +844,15 @@ extern "C" int pemp_scatter_strided_nhwc_f32(const float* src, float* dst, int N
     hipLaunchKernelGGL(scatter_strided_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, N,
                        H, W, Hs, Ws, C / 4, s);
     return launch_status("scatter_strided");
+}
+
+// table: device int32 [L][6] = {offset (floats), Cout, taps, Cin, first tile, tiles along Cin} per conv weight, layers in
+// ascending tile order; total_tiles = sum over layers of taps * ceil(Cout / 32) * ceil(Cin / 32).
+extern "C" int pemp_dgrad_mirror_f32(const float* params, float* mirror, const int32_t* table, int L, int total_tiles,
+                                     void* stream) {
+    PEMP_REQUIRE(params && mirror && table && L > 0 && total_tiles > 0, "dgrad_mirror: bad arguments");
+    hipLaunchKernelGGL(dgrad_mirror_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, params, mirror, (const int*)table, L);
+    return launch_status("dgrad_mirror");
 }
 
 extern "C" int pemp_gap_bwd_add_nhwc_f32(const float* v, float* dst, int ld, int N, int HW, int C, void* stream) {

@@ -108,31 +108,28 @@ class FlatParams:
         return prev
 
     def build_dgrad_mirror(self):
-        """One int32 permutation that turns the flat parameter buffer into a second buffer holding, for every
-        conv weight, the KRSC weight of its input-gradient conv ([Cin, KH*KW*Cout], taps flipped).  Refreshing the
-        mirror is then ONE gather per step instead of a transpose per layer."""
-        idx = torch.arange(self.n, dtype=torch.int32, device=self.data.device)
-        perm = idx.clone()
-        self.dg_view = {}
+        """A second flat buffer holding, for every conv weight, the KRSC weight of its input-gradient conv ([Cin, KH*KW*Cout],
+        taps flipped) at the same offset; refreshed by ONE kernel launch per step (pemp_dgrad_mirror_f32: tiled transposes
+        of all layers) instead of a transpose per layer."""
+        self.dg_view, layers = {}, []
         for p, o in zip(self.params, self.offs):
             if p.dim() != 4:
                 continue
             co, ci, kh, kw = p.shape
-            src = idx[o:o + p.numel()].view(co, kh * kw * ci)
-            perm[o:o + p.numel()] = T.dgrad_weight(src, kh, kw).reshape(-1)
+            layers.append((o, co, kh * kw, ci))
             self.dg_view[id(p)] = (o, ci, kh * kw * co)
-        self.dg_perm = perm
-        self.dg_data = torch.empty_like(self.data)
+        self.dg_table, self.dg_tiles = T.dgrad_mirror_table(layers, self.data.device)
+        self.dg_data = torch.zeros_like(self.data)
 
     def refresh_dgrad_mirror(self):
-        """Runs on the side stream: only the backward pass reads the mirror (``backward`` joins first), so the gather
+        """Runs on the side stream: only the backward pass reads the mirror (``backward`` joins first), so the launch
         hides under the forward pass."""
         if self.side_stream is None or self.capture is not None:
-            torch.index_select(self.data, 0, self.dg_perm, out=self.dg_data)
+            T.dgrad_mirror(self.data, self.dg_data, self.dg_table, self.dg_tiles)
             return
         self.side_stream.wait_stream(torch.cuda.current_stream())     # after the optimizer step / the last dgrad reader
         with torch.cuda.stream(self.side_stream):
-            torch.index_select(self.data, 0, self.dg_perm, out=self.dg_data)
+            T.dgrad_mirror(self.data, self.dg_data, self.dg_table, self.dg_tiles)
 
     def dgrad_krsc(self, p):
         o, rows, cols = self.dg_view[id(p)]

@@ -227,6 +227,28 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=N
     return dw
 
 
+def dgrad_mirror_table(layers, device):
+    """``layers``: [(offset in floats, Cout, taps, Cin)] of the conv weights inside a flat parameter buffer -> (device int32
+    table [L][6], total tiles) for ``dgrad_mirror``."""
+    rows, first = [], 0
+    for off, cout, taps, cin in layers:
+        tci = (cin + 31) // 32
+        rows.append([off, cout, taps, cin, first, tci])
+        first += taps * ((cout + 31) // 32) * tci
+    return torch.tensor(rows, dtype=torch.int32, device=device).contiguous(), first
+
+
+def dgrad_mirror(params, mirror, table, total_tiles):
+    """mirror[off : off + n] = the input-gradient KRSC weight ([Cin][taps flipped][Cout]) of every conv layer in ``table``,
+    whose forward KRSC weight sits at params[off : off + n]: one launch per training step."""
+    lib = _lib.load()
+    _chk_dev(params, mirror, table)
+    if params.numel() != mirror.numel() or not (params.is_contiguous() and mirror.is_contiguous()) or table.dtype != torch.int32:
+        raise ValueError("dgrad_mirror: flat contiguous buffers of equal length and an int32 table required")
+    _lib.check(lib.pemp_dgrad_mirror_f32(_p(params), _p(mirror), _p(table), table.shape[0], int(total_tiles), _stream()), "dgrad_mirror")
+    return mirror
+
+
 def dgrad_weight(w_krsc, kh, kw):
     """KRSC forward weight [Cout, KH*KW*Cin] -> the KRSC weight of the input-gradient conv
     [Cin, KH*KW*Cout] (taps flipped, channels transposed)."""

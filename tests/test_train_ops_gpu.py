@@ -496,3 +496,32 @@ def test_split_k_hand_off_is_complete_and_stable_under_uneven_load(hip_lib, dev,
             y = ops.conv2d(x, prm, tile=tile)
             assert torch.equal(y, first), (tile, rem, rep)
         torch.cuda.current_stream().wait_stream(side)
+
+
+def test_dgrad_mirror_of_a_flat_buffer_matches_the_per_layer_transpose(hip_lib, dev):
+    """pemp_dgrad_mirror_f32: the input-gradient weights of every conv layer of a flat parameter buffer in one launch ==
+    train_ops.dgrad_weight (flip + transpose in torch) layer by layer; ragged channel counts (3, 66), 1x1 / 3x3 / 7x7,
+    bytes between the layers (BatchNorm parameters) left untouched."""
+    from pemp_amd import train_ops as T
+    shapes = [(64, 3, 7), (64, 64, 1), (256, 66, 1), (128, 128, 3), (512, 1280, 1), (96, 160, 3)]      # (Cout, Cin, k)
+    g = torch.Generator().manual_seed(5)
+    chunks, layers, off = [], [], 0
+    for co, ci, k in shapes:
+        gap = torch.rand(12, generator=g)                                   # something that is not a conv weight
+        chunks.append(gap)
+        off += 12
+        w = torch.rand(co, k * k * ci, generator=g)
+        chunks.append(w.reshape(-1))
+        layers.append((off, co, k * k, ci))
+        off += w.numel()
+    flat = torch.cat(chunks).to(dev)
+    mirror = torch.full_like(flat, -7.0)
+    table, tiles = T.dgrad_mirror_table(layers, dev)
+    T.dgrad_mirror(flat, mirror, table, tiles)
+    pos = 0
+    for (off, co, taps, ci), (_, _, k) in zip(layers, shapes):
+        assert bool((mirror[pos:off] == -7.0).all())
+        n = co * taps * ci
+        ref = T.dgrad_weight(flat[off:off + n].view(co, taps * ci), k, k)
+        assert torch.equal(mirror[off:off + n].view(ci, taps * co), ref), (co, ci, k)
+        pos = off + n
