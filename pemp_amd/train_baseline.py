@@ -23,7 +23,7 @@ class _ResNetProjectionEngine(Stage1TrainEngine):
     def _tail_backward(self, dfeat, up=None):
         x = self.tape["proj_in"]
         g = torch.empty_like(dfeat)
-        self.proj.conv.bias.grad.copy_(T.relu_bias_bwd(dfeat, None, g, relu=False, ws_cache=self.ws))
+        T.relu_bias_bwd(dfeat, None, g, relu=False, ws_cache=self.ws, out=self.proj.conv.bias.grad)
         self.proj.wgrad(x, g, self.ws)
         return conv2d(g, self.proj.dgrad_params())
 
@@ -71,7 +71,7 @@ class _VGGEngine(Stage1TrainEngine):
                 self.flat.cut()                    # stage boundary (segmented graph capture; no-op otherwise)
                 continue
             g = torch.empty_like(y)
-            obj.conv.bias.grad.copy_(T.relu_bias_bwd(dx, y, g, relu=relu, ws_cache=self.ws))
+            T.relu_bias_bwd(dx, y, g, relu=relu, ws_cache=self.ws, out=obj.conv.bias.grad)
             obj.wgrad(x, g, self.ws)
             dx = conv2d(g, obj.dgrad_params()) if not obj.stem else None
 

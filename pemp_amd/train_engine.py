@@ -584,14 +584,13 @@ class Stage1TrainEngine:
             conv, bn = self.aspp_conv[i], self.aspp_bn[i]
             u = tp["cat"][..., (i - 1) * midc:i * midc]
             g = self._new(nimg, h, w, midc)
-            db = T.relu_bias_bwd(dcat[..., (i - 1) * midc:i * midc], u, g, relu=True, ws_cache=self.ws)
-            conv.conv.bias.grad.copy_(db)
+            T.relu_bias_bwd(dcat[..., (i - 1) * midc:i * midc], u, g, relu=True, ws_cache=self.ws, out=conv.conv.bias.grad)
             conv.wgrad(tp["ts"][i - 1], g, self.ws)
             dt = conv2d(g, conv.dgrad_params())
             dt = self._dropblock_bwd(dt, tp["ds"][i - 1])
             dz = self._new(nimg, h, w, dt.shape[-1])
-            dgamma, dbeta = T.bn_bwd(dt, None, tp["xb"], tp["mean_x"], tp["invstd_x"], bn.bn.weight.data, dz, relu=False, ws_cache=self.ws)
-            bn.write_grads(dgamma, dbeta)
+            T.bn_bwd(dt, None, tp["xb"], tp["mean_x"], tp["invstd_x"], bn.bn.weight.data, dz, relu=False, ws_cache=self.ws,
+                     out=bn.grad_out())                  # dgamma / dbeta straight into the flat gradient buffer
             if dxb is None:
                 dxb = dz
             else:
@@ -599,24 +598,22 @@ class Stage1TrainEngine:
         # branch 0 (global)
         conv0, bn0 = self.aspp_conv[0], self.aspp_bn[0]
         g = self._new(nimg, 1, 1, midc)
-        db = T.relu_bias_bwd(dg0, tp["g0"], g, relu=True, ws_cache=self.ws)
-        conv0.conv.bias.grad.copy_(db)
+        T.relu_bias_bwd(dg0, tp["g0"], g, relu=True, ws_cache=self.ws, out=conv0.conv.bias.grad)
         conv0.wgrad(tp["t0d"].view(nimg, 1, 1, -1), g, self.ws)
         dt0 = conv2d(g, conv0.dgrad_params()).view(nimg, -1)
         dt0 = self._dropblock_bwd(dt0, tp["d0"])
         dgap = self._new(nimg, dt0.shape[1])
-        dgamma, dbeta = T.bn_bwd(dt0, None, tp["gap"], tp["m0"], tp["i0"], bn0.bn.weight.data, dgap, relu=False, ws_cache=self.ws)
-        bn0.write_grads(dgamma, dbeta)
+        T.bn_bwd(dt0, None, tp["gap"], tp["m0"], tp["i0"], bn0.bn.weight.data, dgap, relu=False, ws_cache=self.ws, out=bn0.grad_out())
         T.gap_bwd_add(dgap, dxb)
         # purifier.3 and purifier.0 (conv + bias + ReLU (+ DropBlock))
         dxb = self._dropblock_bwd(dxb, tp["db"])
         g = torch.empty_like(tp["yb"])
-        self.p3.conv.bias.grad.copy_(T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws))
+        T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws, out=self.p3.conv.bias.grad)
         self.p3.wgrad(tp["xa"], g, self.ws)
         dxa = conv2d(g, self.p3.dgrad_params())
         dxa = self._dropblock_bwd(dxa, tp["da"])
         g = torch.empty_like(tp["ya"])
-        self.p0.conv.bias.grad.copy_(T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws))
+        T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws, out=self.p0.conv.bias.grad)
         self.p0.wgrad(tp["p0_in"], g, self.ws)
         prm = self.p0.dgrad_params()
         if up is not None and FUSE_BN_BWD and up["mask"] is not None and prm.shift is None and ops.stats_supported(g, prm):

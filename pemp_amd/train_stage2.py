@@ -196,23 +196,23 @@ class Stage2TrainEngine(Stage1TrainEngine):
             conv = self.aspp_conv[i]
             g = self._new(nimg, h, w, midc)
             sl = slice((i - 1) * midc, i * midc)
-            conv.conv.bias.grad.copy_(T.relu_bias_bwd(dcat[..., sl], tp["cat"][..., sl], g, relu=True, ws_cache=self.ws))
+            T.relu_bias_bwd(dcat[..., sl], tp["cat"][..., sl], g, relu=True, ws_cache=self.ws, out=conv.conv.bias.grad)
             conv.wgrad(tp["xb"], g, self.ws)
             dxb = conv2d(g, conv.dgrad_params(), residual=dxb)            # branch gradients accumulate in the epilogue
         conv0 = self.aspp_conv[0]
         dg0 = self._drop_bwd(dg0, tp["m0"])
         g = self._new(nimg, 1, 1, midc)
-        conv0.conv.bias.grad.copy_(T.relu_bias_bwd(dg0, tp["g0"], g, relu=True, ws_cache=self.ws))
+        T.relu_bias_bwd(dg0, tp["g0"], g, relu=True, ws_cache=self.ws, out=conv0.conv.bias.grad)
         conv0.wgrad(tp["gap"].view(nimg, 1, 1, -1), g, self.ws)
         T.gap_bwd_add(conv2d(g, conv0.dgrad_params()).view(nimg, -1), dxb)
         dxb = self._drop_bwd(dxb, tp["mb"])
         g = torch.empty_like(tp["yb"])
-        self.p3.conv.bias.grad.copy_(T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws))
+        T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws, out=self.p3.conv.bias.grad)
         self.p3.wgrad(tp["xa"], g, self.ws)
         dxa = conv2d(g, self.p3.dgrad_params())
         dxa = self._drop_bwd(dxa, tp["ma"])
         g = torch.empty_like(tp["ya"])
-        self.p0.conv.bias.grad.copy_(T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws))
+        T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws, out=self.p0.conv.bias.grad)
         self.p0.wgrad(tp["p0_in"], g, self.ws)
         return conv2d(g, self.p0.dgrad_params())
 
