@@ -350,19 +350,19 @@ def summarize(rec, reps, step_ms=None):
 
 def attach_pmc(roof, workload_key):
     """HBM bytes and MFMA-pipe utilisation come from rocprofv3 --pmc passes (they cannot be collected in-process).  A
-    committed profile is quoted ONLY when it was taken on exactly this kernel source (csrc digest) and workload."""
+    committed profile is quoted ONLY when it was taken on exactly this conv-engine source (build.conv_digest) and workload."""
     from pemp_amd import build
-    digest = build.csrc_digest()
-    for fname, field, key in (("r02_conv_traffic.json", "traffic", "hbm_bytes_per_launch"),
-                              ("r02_mfma_util.json", "mfma_util_pmc_pct", "conv_mfma_util_pct_time_weighted")):
+    digest = build.conv_digest()
+    for fname, field, key in (("r03_conv_traffic.json", "traffic", "hbm_bytes_per_launch"),
+                              ("r03_mfma_util.json", "mfma_util_pmc_pct", "conv_mfma_util_pct_time_weighted")):
         path = os.path.join(ROOT, "profiles", fname)
         if not os.path.exists(path):
             continue
         with open(path) as f:
             rec = json.load(f)
-        if rec.get("csrc_digest") == digest and rec.get("workload_key") == workload_key:
+        if rec.get("conv_digest") == digest and rec.get("workload_key") == workload_key:
             roof[field] = rec.get(key)
-            roof.setdefault("pmc_source", []).append(f"profiles/{fname} (rocprofv3 --pmc, replayed: same kernel source {digest})")
+            roof.setdefault("pmc_source", []).append(f"profiles/{fname} (rocprofv3 --pmc, replayed: same conv-engine source {digest})")
     return roof
 
 

@@ -33,6 +33,19 @@ def csrc_digest():
     return h.hexdigest()[:12]
 
 
+CONV_ENGINE = ("common.h", "conv_common.h", "conv_igemm.hip", "conv_dma.hip", "conv_dma2.hip")
+
+
+def conv_digest():
+    """Content hash of the conv engine's sources only: the PMC figures bench.py quotes for the eval step (HBM bytes per conv
+    launch, MFMA pipe utilisation) belong to these files, a change elsewhere (head, training kernels) does not unpin them."""
+    h = hashlib.sha1()
+    for f in CONV_ENGINE:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

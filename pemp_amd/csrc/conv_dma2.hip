@@ -50,14 +50,6 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
     const int wn0 = (wave % WGN) * WN;
     const int lr = lane & 31, lh = lane >> 5;
 
-    // De-phasing of the blocks that share a CU (flags bits 24..30 = units of 64 cycles; speed only): blocks of the same
-    // program that start together reach their barriers, LDS bursts and MFMA segments together and leave the matrix pipe
-    // idle together.  Dispatch deals the first 256 blocks one per CU, so block ids with bit 8 set are the second residents.
-    {
-        const int stg = (a.flags >> 24) & 127;
-        if (stg && ((blockIdx.x >> 8) & 1))
-            for (int i = 0; i < stg; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     const int ntn = a.Cout / BN;
     // SK: blocks [0, sk_full) compute whole tiles; behind them, sk_S consecutive blocks share one of the remaining tiles,
     // block `piece` of them running K steps [kt0, kt0 + nkl)

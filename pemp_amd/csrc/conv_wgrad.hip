@@ -31,7 +31,6 @@ struct WgradArgs {
     int M, HoWo, ntaps, cin_tiles, steps_total, steps_per_split, nsplit, stem;
     int xcd, nsplit_grid;      // A/B switch (PEMP_WGRAD_XCD=0: tile-major block order, splits of a tile on consecutive ids)
     int gx, gy;        // tiles of the weight matrix along Cout / along its row (conv_wgrad2_kernel decodes a 1-D grid)
-    int stagger;       // conv_wgrad2_kernel: blocks with id bit 8 set start this many x 64 cycles late (de-phasing, speed only)
 };
 
 template <bool STEM>
@@ -285,8 +284,6 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
     // weight matrix needs them), so they should meet in ONE XCD's L2.  Consecutive block ids go round-robin over the 8 XCDs;
     // xcd_tile_order hands every XCD a contiguous range of the split-major logical order.  (Measured before: 10.4 GB of L2
     // fills per training step for 42 MB operands per launch -- each XCD fetched every row for itself.)
-    if (a.stagger && ((blockIdx.x >> 8) & 1))
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
     const int ntile = a.gx * a.gy;
     const int li = a.xcd ? xcd_tile_order(blockIdx.x, gridDim.x) : blockIdx.x;
     const int split = a.xcd ? li / ntile : li % a.nsplit_grid;
@@ -567,7 +564,6 @@ extern "C" int pemp_conv2d_wgrad_nhwc_f32(const pemp_conv_desc* d, const float* 
     a.cin_tiles = stem ? 1 : d->Cin / 64;
     a.steps_total = cdiv(a.M, 32);
     a.stem = stem;
-    a.stagger = (d->flags >> 24) & 127;
     const bool big = wgrad_big_tiles(d);
     const int tw = big ? 128 : 64;
     const int tiles_k = d->Kpad / tw;

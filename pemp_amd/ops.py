@@ -68,9 +68,6 @@ TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15
                  # 2x: the same shapes on conv_dma2.hip (buffer-addressed LDS-DMA, barrier inside the MFMA stream)
                  23: (64, 64), 24: (128, 128), 22: (128, 64), 21: (128, 128), 25: (128, 64), 27: (256, 256), 26: (256, 128)}
 AUTOTUNE = True
-#: de-phasing of co-resident blocks (units of 64 cycles, 0..127) handed to the conv / weight-gradient kernels in flags bits 24..30
-STAGGER = int(os.environ.get("PEMP_CONV_STAGGER", "0"))
-WGRAD_STAGGER = int(os.environ.get("PEMP_WGRAD_STAGGER", "0"))
 SPLITK = os.environ.get("PEMP_CONV_SPLITK", "1") != "0"     # the training convs may pick the split-K variants (A/B switch)
 DEFAULT_TILE = 13
 _TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared by every ConvParams object
@@ -211,7 +208,6 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
         flags |= CONV_SHIFT_PER_IMAGE
     if p.stem:
         flags |= CONV_STEM4
-    flags |= (STAGGER & 127) << 24
     splitk = ((splitk and SPLITK) or (EVAL_SPLITK and n * ho * wo <= EVAL_SPLITK_MAX_ROWS)) and pad_value is None and not p.stem
 
     def launch(t):
@@ -317,7 +313,7 @@ def conv2d_stats(x, p, out=None, tile=0):
     part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)     # the smallest row tile has 64 rows
 
     def launch(t):
-        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, 0, p.kpad, (STAGGER & 127) << 24, t)
+        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, 0, p.kpad, 0, t)
         ws, ws_bytes = _splitk_ws(lib, d, x.device) if t > 30 else (None, 0)
         _check_sk(lib, lib.pemp_conv2d_stats_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(part), C.c_void_p(ws), ws_bytes,
                                                       _stream()), ws, "pemp_conv2d_stats_nhwc_f32")
@@ -368,7 +364,7 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
     part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)
 
     def launch(t):
-        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, (STAGGER & 127) << 24, t)
+        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, 0, t)
         ws, ws_bytes = _splitk_ws(lib, d, x.device) if t > 30 else (None, 0)
         _check_sk(lib, lib.pemp_conv2d_bnbwd_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(residual), _p(mask), _p(z), ldz,
                                                       _p(bn["mean"]), _p(bn["invstd"]), _p(part), C.c_void_p(ws), ws_bytes,

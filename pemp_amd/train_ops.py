@@ -160,7 +160,6 @@ def relu_bias_bwd(dy, y, g, add=None, relu=True, want_dbias=True, ws_cache=None,
     return dbias
 
 
-from . import ops as _ops
 from .ops import WGRAD_PICKS as _WGRAD_BLOCKS      # (layer geometry, input shape) -> (tile kind, block count) that measured fastest
 WGRAD_BLOCK_CHOICES = (512, 768, 1024, 1536)
 
@@ -190,7 +189,7 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=N
         if variant:
             kind = int(variant)              # an explicit kernel generation wins over a remembered tile kind
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, cout, ldg, p.kh, p.kw, p.stride, p.pad, p.dil, 0, kpad,
-                     (CONV_STEM4 if p.stem else 0) | ((_ops.WGRAD_STAGGER & 127) << 24), int(kind) | (int(nb) << 8))
+                     CONV_STEM4 if p.stem else 0, int(kind) | (int(nb) << 8))
         nbytes = lib.pemp_conv2d_wgrad_workspace_bytes(C.byref(d))
         ws = _ws(nbytes, x.device, ws_cache, ("wgrad", nbytes))
         _lib.check(lib.pemp_conv2d_wgrad_nhwc_f32(C.byref(d), _p(x), _p(g), _p(dw), 1 if accumulate else 0, _p(ws),

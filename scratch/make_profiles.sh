@@ -1,18 +1,23 @@
 #!/bin/bash
-# Produces the round-2 measurement artefacts under gpurun_out/r02/ on the GPU box (copy into profiles/ afterwards):
-#   bash scratch/make_profiles.sh
+# Produces the round-3 measurement artefacts under gpurun_out/r03/ on the GPU box (copy into profiles/ afterwards):
+#   bash scratch/make_profiles.sh [part]        part = bench | trace | pmc | all (default)
 # rocprofv3 is always given the program itself after `--` (python3 bench.py ...), never a wrapper.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r02; mkdir -p $O
-B="--cpu-episodes 0 --no-e2e --no-single"
-# 1. bench lines of every BASELINE.json config (live roofline + cpu_baseline where defined)
-timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > $O/bench_eval_b25.json 2> $O/err.log && echo eval ok
+PART=${1:-all}
+O=gpurun_out/r03; mkdir -p $O
+B="--cpu-episodes 0 --no-e2e --no-single --no-sides"
+if [ $PART = bench ] || [ $PART = all ]; then
+# 1. bench lines: the default command (headline + train / stage2_5shot / miou objects), then every other BASELINE.json config
+timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/err.log && echo default ok
 timeout -k 10 500 python3 bench.py --mode train --steps 20 --warmup 5 > $O/bench_train_b4.json 2>> $O/err.log && echo train ok
 timeout -k 10 500 python3 bench.py --mode train --model stage2 --steps 20 --warmup 5 > $O/bench_train_stage2_b4.json 2>> $O/err.log && echo train2 ok
 timeout -k 10 500 python3 bench.py --model stage2 --shot 5 --batch 8 --steps 10 --warmup 3 > $O/bench_stage2_5shot_b8.json 2>> $O/err.log && echo stage2 ok
 timeout -k 10 500 python3 bench.py --dataset COCO --steps 10 --warmup 3 --cpu-episodes 4 > $O/bench_eval_coco_b25.json 2>> $O/err.log && echo coco ok
 timeout -k 10 500 python3 bench.py --model baseline --batch 12 --steps 10 --warmup 3 > $O/bench_baseline_vgg16_b12.json 2>> $O/err.log && echo baseline ok
+timeout -k 10 500 python3 bench.py --batch 1 --steps 100 --warmup 10 $B > $O/bench_eval_b1.json 2>> $O/err.log && echo b1 ok
+fi
+if [ $PART = trace ] || [ $PART = all ]; then
 # 2. kernel traces (rocprofv3 --kernel-trace --stats) of the eval and train commands
 for tag in eval train; do
   extra=""; [ $tag = train ] && extra="--mode train"
@@ -21,9 +26,17 @@ for tag in eval train; do
   find $O/kt_$tag -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${tag}_kernel_stats.csv
   per=52; [ $tag = train ] && per=155
   find $O/kt_$tag -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 scratch/profile_summary.py {} $O/${tag}_steady.json $tag $per
+  [ $tag = train ] && find $O/kt_$tag -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 scratch/phases3.py {} 20 > $O/train_phases.json
   grep '^{' $O/kt_$tag.log | tail -n 1 > $O/bench_${tag}_under_rocprof.json
   rm -rf $O/kt_$tag
 done
+# 4. prototype-head kernels alone
+rm -rf $O/kt_head
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_head -- python3 scratch/head_bench.py 25 > $O/head_b25.log 2>&1 || echo "head failed"
+find $O/kt_head -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/head_b25_kernel_stats.csv
+rm -rf $O/kt_head
+fi
+if [ $PART = pmc ] || [ $PART = all ]; then
 # 3. PMC passes on the eval command (tile picks replayed, so no autotune launches): HBM traffic + MFMA utilisation
 export PEMP_TILE_CACHE=$PWD/$O/tiles.json
 timeout -k 10 400 python3 bench.py --steps 3 --warmup 2 $B --no-roofline > /dev/null 2>&1
@@ -31,25 +44,20 @@ for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
   rm -rf $O/pmc_$c
   timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 5 --warmup 2 $B --no-roofline > $O/pmc_$c.log 2>&1 || echo "pmc $c failed"
 done
-python3 scratch/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MfmaUtil $O 25
+python3 scratch/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MfmaUtil $O 25 > /dev/null || echo "pmc summary failed"
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MfmaUtil
 unset PEMP_TILE_CACHE
-# 3b. MfmaUtil of the training step's implicit-GEMM kernels
+# 3b. MfmaUtil and HBM traffic of the training step
 rm -rf $O/pmc_train
-timeout -k 10 600 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/pmc_train -- python3 bench.py --mode train --steps 5 --warmup 3 --cpu-episodes 0 --no-single --no-roofline > $O/pmc_train.log 2>&1 || echo "pmc train failed"
+timeout -k 10 600 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/pmc_train -- python3 bench.py --mode train --steps 5 --warmup 3 --cpu-episodes 0 --no-roofline > $O/pmc_train.log 2>&1 || echo "pmc train failed"
 python3 scratch/pmc_train_summary.py $O/pmc_train $O > /dev/null || echo "pmc train summary failed"
 rm -rf $O/pmc_train
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmct_$c
-  timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmct_$c -- python3 bench.py --mode train --steps 5 --warmup 3 --cpu-episodes 0 --no-single --no-roofline > $O/pmct_$c.log 2>&1 || echo "pmc train $c failed"
+  timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmct_$c -- python3 bench.py --mode train --steps 5 --warmup 3 --cpu-episodes 0 --no-roofline > $O/pmct_$c.log 2>&1 || echo "pmc train $c failed"
 done
 python3 scratch/pmc_train_traffic.py $O/pmct_FETCH_SIZE $O/pmct_WRITE_SIZE $O > /dev/null || echo "pmc train traffic failed"
 rm -rf $O/pmct_FETCH_SIZE $O/pmct_WRITE_SIZE
-# 4. prototype-head kernels beyond the Infinity Cache (60 / 100 queries: 320 / 533 MB per launch)
-for q in 25 60 100; do
-  rm -rf $O/kt_head
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_head -- python3 scratch/head_bench.py $q > $O/head_b$q.log 2>&1 || echo "head $q failed"
-  find $O/kt_head -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/head_b${q}_kernel_stats.csv
-  rm -rf $O/kt_head
-done
+fi
+rm -f $O/*.log.tmp
 ls -la $O

@@ -1,5 +1,5 @@
 """Three rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, MfmaUtil; --kernel-trace only, CSV) of the eval bench ->
-r02_conv_traffic.json / r02_mfma_util.json with the kernel-source digest bench.py checks before quoting them.
+r03_conv_traffic.json / r03_mfma_util.json with the kernel-source digest bench.py checks before quoting them.
 python scratch/pmc_summary.py <fetch dir> <write dir> <mfma dir> <out dir> <episodes per step>"""
 import csv, glob, json, os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,16 +18,16 @@ def avg(d, counter):
     return sum(v) / len(v), len(v)
 
 
-digest = build.csrc_digest()
+digest = build.conv_digest()
 key = f"stage1-eval-b{batch}-s1"
 fk, n = avg(fdir, "FETCH_SIZE")
 wk, _ = avg(wdir, "WRITE_SIZE")
 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace --output-format csv -- python3 bench.py --steps 5 "
                       "--warmup 2 --cpu-episodes 0 --no-e2e --no-single --no-roofline (%d episodes/step; tile picks replayed through PEMP_TILE_CACHE)" % batch,
-           "csrc_digest": digest, "workload_key": key, "episodes_per_step": batch, "conv_launches": n,
+           "conv_digest": digest, "workload_key": key, "episodes_per_step": batch, "conv_launches": n,
            "FETCH_SIZE_KB_avg_per_launch": round(fk, 2), "WRITE_SIZE_KB_avg_per_launch": round(wk, 2),
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
-           "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}, open(os.path.join(out, "r02_conv_traffic.json"), "w"), indent=1)
+           "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}, open(os.path.join(out, "r03_conv_traffic.json"), "w"), indent=1)
 # MfmaUtil: time-weight by the kernel's duration (same CSV: Start/End timestamps per dispatch)
 by = collections.OrderedDict()
 tot_w = tot = 0.0
@@ -45,9 +45,9 @@ for r in rows(mdir, "MfmaUtil"):
 json.dump({"command": "rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 2 --cpu-episodes 0 --no-e2e "
                       "--no-single --no-roofline (%d episodes/step; tile picks replayed through PEMP_TILE_CACHE)" % batch,
            "counter": "MfmaUtil (rocprofv3 derived counter: MFMA pipe busy share), per launch, weighted by the launch's duration",
-           "csrc_digest": digest, "workload_key": key, "episodes_per_step": batch, "conv_launches": sum(a[0] for a in by.values()),
+           "conv_digest": digest, "workload_key": key, "episodes_per_step": batch, "conv_launches": sum(a[0] for a in by.values()),
            "conv_mfma_util_pct_time_weighted": round(tot_w / max(tot, 1e-9), 2),
            "by_kernel": {k: {"launches": a[0], "mfma_util_pct": round(a[1] / max(a[2], 1e-9), 1)} for k, a in by.items()},
            "cosine_mfma_kernel_mfma_util_pct": round(sum(cosine) / max(len(cosine), 1), 1)},
-          open(os.path.join(out, "r02_mfma_util.json"), "w"), indent=1)
-print(open(os.path.join(out, "r02_conv_traffic.json")).read()); print(open(os.path.join(out, "r02_mfma_util.json")).read())
+          open(os.path.join(out, "r03_mfma_util.json"), "w"), indent=1)
+print(open(os.path.join(out, "r03_conv_traffic.json")).read()); print(open(os.path.join(out, "r03_mfma_util.json")).read())
