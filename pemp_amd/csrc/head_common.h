@@ -5,7 +5,7 @@
 
 namespace pemp {
 
-constexpr int MAXJ = 8;     // 2p <= 8
+// MAXJ (the rows per pixel, 2 * protos, a kernel keeps in registers) is set per instantiation of the head bodies: head.hip
 constexpr int MAXCL = 8;    // channels per lane: c <= 64*MAXCL = 512
 constexpr int PCHUNK = 64;  // pixels per pooling block
 

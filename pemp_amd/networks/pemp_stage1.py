@@ -61,16 +61,16 @@ def import_torchvision_trunk(trunk, path, resnet=True):
     trunk.load_state_dict(cur)
 
 
-MAX_PROTOS = 4      # the prototype-head kernels hold 2 * protos <= 8 rows per pixel in registers (csrc/head_common.h: MAXJ)
+MAX_PROTOS = 8      # the prototype-head kernels are instantiated for 2 * protos <= 8 and <= 16 rows per pixel (csrc/head.hip)
 
 
 def check_protos(protos, key):
     """The reference accepts any ``protos`` (networks/pemp_stage1.py:26,104-105; default 3); this build's head kernels are
-    written for at most MAX_PROTOS per class.  Fail at model construction, not inside a kernel launch."""
+    instantiated for at most MAX_PROTOS per class.  Fail at model construction, not inside a kernel launch."""
     if not 0 <= int(protos) <= MAX_PROTOS:
         raise ValueError(f"{key} = {protos}: this build supports 0 (plain masked average pooling) .. {MAX_PROTOS} prototypes "
-                         f"per class (the head kernels keep 2 * protos <= 8 rows per pixel in registers; MAXJ in "
-                         f"pemp_amd/csrc/head_common.h)")
+                         f"per class (the head kernels keep 2 * protos <= 16 rows per pixel in registers; MAXJ in "
+                         f"pemp_amd/csrc/head.hip)")
 
 
 class _HeadMixin:

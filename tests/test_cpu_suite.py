@@ -741,14 +741,14 @@ def test_oracle_decision_switches_record_and_replay():
 
 
 def test_protos_beyond_the_kernel_limit_fail_at_model_construction():
-    """net.protos / net.protos2 outside 0..4 (the reference accepts any value, networks/pemp_stage1.py:26,104-105): a
+    """net.protos / net.protos2 outside 0..8 (the reference accepts any value, networks/pemp_stage1.py:26,104-105): a
     ValueError that names the key and the limit when the model is built -- not "cosine: bad dims" from a kernel launch."""
     import pytest
     from pemp_amd.networks import pemp_stage1 as m1, pemp_stage2 as m2
-    for p in (0, 1, 4):
+    for p in (0, 1, 4, 5, 8):
         net = m1.PEMPStage1(None, protos=p)
         assert (net.ctr is None) == (p == 0) and (p == 0 or net.ctr.shape == (512, 2 * p))
-    with pytest.raises(ValueError, match="net.protos = 5"):
-        m1.PEMPStage1(None, protos=5)
-    with pytest.raises(ValueError, match="net.protos2 = 6"):
-        m2.PEMPStage2(1, 1, None, protos2=6)
+    with pytest.raises(ValueError, match="net.protos = 9"):
+        m1.PEMPStage1(None, protos=9)
+    with pytest.raises(ValueError, match="net.protos2 = 12"):
+        m2.PEMPStage2(1, 1, None, protos2=12)

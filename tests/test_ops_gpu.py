@@ -199,7 +199,9 @@ def _ref_mpm(sup, qry, fg, bg, ctr, p, ret_ind=True):
                                             (3, 2, 1, 64, 5, 7, 40, 33), (1, 3, 4, 260, 6, 6, 31, 47),      # c = 260: VALU cosine
                                             (2, 1, 2, 96, 17, 3, 50, 20), (4, 1, 3, 512, 6, 5, 19, 15),
                                             (1, 2, 4, 128, 9, 7, 33, 41),                                    # 2p = 8 on the MFMA path
-                                            (1, 1, 3, 512, 1, 1, 9, 9), (2, 2, 3, 512, 3, 5, 20, 33)])      # maps smaller than one 16-pixel tile
+                                            (1, 1, 3, 512, 1, 1, 9, 9), (2, 2, 3, 512, 3, 5, 20, 33),       # maps smaller than one 16-pixel tile
+                                            (1, 2, 5, 512, 9, 7, 33, 41), (2, 1, 6, 256, 7, 9, 50, 47),      # protos 5..8: the MAXJ = 16 instantiation
+                                            (1, 1, 8, 128, 13, 13, 97, 97)])
 def test_mpm_and_cosine(hip_lib, dev, B, S, p, c, h, w, H, W):
     from pemp_amd import ops
     sup = _rand(B, S, c, h, w, seed=1) * 2

@@ -125,3 +125,42 @@ def test_stage1_default_out_shape_and_errors(model, dev):
             model.lowres_graphed(t["sup_img"], t["sup_mask"], t["qry_img"])
     finally:
         model.eval()
+
+
+@pytest.mark.parametrize("protos", [5, 8])
+def test_stage1_with_more_than_four_prototypes_matches_the_oracle(hip_lib, dev, protos, monkeypatch):
+    """net.protos = 5 / 8 (the reference accepts any value, networks/pemp_stage1.py:26,104-105; the head kernels'
+    second instantiation, 2 * protos <= 16): eval forward at 97 x 97 vs the oracle, logits within LOGIT_TOL, arg-max exact
+    outside the margin; and one training step's loss against the oracle's train-mode forward."""
+    from oracle import ref_cpu
+    from pemp_amd import synth
+    from pemp_amd.networks import pemp_stage1 as m
+    from pemp_amd.train_engine import Stage1Trainer
+    monkeypatch.setitem(m.net_ingredient.cfg, "protos", protos)
+    net = m.ModelClass(None)
+    assert net.ctr.shape == (512, 2 * protos)
+    sd = synth.wgen_state_dict_for(net)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    ep = synth.make_episode(7, shot=1, height=97, width=97, out_hw=(97, 97))
+    t = lambda a: torch.from_numpy(a)[None]
+    sup, msk, qry, gt = t(ep["sup_img"]), t(ep["sup_mask"]), t(ep["qry_img"]), t(ep["qry_mask"])
+    with torch.no_grad():
+        ref = ref_cpu.stage1_forward(sd, sup, msk, qry, (97, 97), protos=protos)
+        got = net(sup.to(dev), msk.to(dev), qry.to(dev), (97, 97))
+    assert (got.cpu() - ref).abs().max().item() < util.LOGIT_TOL
+    util.assert_argmax_exact(got, ref.argmax(1), max_masked=0.02, what=f"protos {protos}")
+    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    tb = lambda k: torch.from_numpy(b[k])
+    sup, msk, qry, gt = tb("sup_img"), tb("sup_mask"), tb("qry_img"), tb("qry_mask")[:, 0]
+    tr = Stage1Trainer(net, device=dev, drop_rate=0.0)
+    loss, _ = tr.forward_backward(sup.to(dev), msk.to(dev), qry.to(dev), gt.to(dev))
+    ref_cpu.TRAIN = True
+    try:
+        with torch.no_grad():
+            ref_loss = float(ref_cpu.ce_loss(ref_cpu.stage1_forward({k: v.clone() for k, v in sd.items()}, sup, msk, qry, (97, 97), protos=protos), gt))
+    finally:
+        ref_cpu.TRAIN = False
+    assert abs(loss.item() - ref_loss) < 1e-4           # the CE tolerance of the end-to-end tests
+    g = net.ctr.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0

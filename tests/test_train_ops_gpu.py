@@ -354,7 +354,8 @@ def test_sgd_clip_step_matches_torch(hip_lib, dev):
 
 
 @pytest.mark.parametrize("B,S,p,c,h,w,H,W,Ho,Wo", [(2, 2, 3, 512, 9, 11, 70, 85, 50, 61), (1, 1, 2, 256, 7, 7, 50, 50, 33, 40),
-                                                   (2, 1, 0, 512, 6, 5, 41, 37, 41, 37), (1, 5, 3, 128, 5, 6, 40, 47, 40, 47)])
+                                                   (2, 1, 0, 512, 6, 5, 41, 37, 41, 37), (1, 5, 3, 128, 5, 6, 40, 47, 40, 47),
+                                                   (2, 1, 5, 512, 7, 6, 41, 37, 41, 37), (1, 2, 8, 256, 5, 6, 40, 47, 33, 40)])   # protos 5..8: MAXJ = 16
 def test_head_backward_matches_autograd(hip_lib, dev, B, S, p, c, h, w, H, W, Ho, Wo):
     """pemp_head_bwd_f32 vs torch autograd through the torch restatement of the head (CPU)."""
     from pemp_amd import ops, train_ops as T
