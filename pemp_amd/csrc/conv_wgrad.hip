@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
     constexpr int RPR = 256 / QPR;         // pixel rows per DMA round of the block
     constexpr int NR = 32 / RPR;           // DMA rounds per operand and step
     constexpr int T = TW / 64;             // 32x32 MFMA tiles per wave and dimension
-    constexpr int WNDS = 4 * T;            // ds_read2_b32 per quarter (the compiler pairs the 8 T dword reads)
+    constexpr int WNDS = 8;                // LDS reads per quarter: 4 sub-steps x 2 operands (b64 for TW = 128, b32 for TW = 64)
     constexpr int WPER = (WNDS + 2 * NR + 4 * T * T - 1) / (4 * T * T);
     extern __shared__ __attribute__((aligned(16))) v4f smem[];
     v4f* Gs = smem;                        // [2][32 px][QPR]
@@ -306,12 +306,14 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
     // loader role: thread (row = tid / QPR, q = tid % QPR) fetches quad q of pixel rows row + RPR i of the step
     const int q = tid % QPR, row = tid / QPR;
     unsigned g_voff[NR];
-    int x_m[NR], x_ho[NR], x_wo[NR];
-    unsigned x_off[NR];                    // byte offset of (img, ho*stride, wo*stride) + tap displacement + channel quad
+    int x_m[NR], x_hi[NR], x_wi[NR];       // output pixel index; input row / column of this tap for that pixel (may be outside)
+    unsigned x_off[NR];                    // byte offset of (img, hi, wi) + channel quad; only used when (hi, wi) is inside
     const int ldx4 = a.ldx * 4;
+    const int sW = a.Wo * a.stride, sH = a.Ho * a.stride;
     const int inc32 = 32 * a.stride * ldx4;                                 // 32 output pixels further in the same row
     const int incw = (a.stride * a.W - a.Wo * a.stride) * ldx4;             // wo wrapped: next output row
     const int inch = (a.H * a.W - a.Ho * a.stride * a.W) * ldx4;            // ho wrapped: next image
+    const int wi_hi = dw + sW, hi_hi = dh + sH;                             // first wi / hi beyond the last output column / row
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int m = s_begin * 32 + row + RPR * i;
@@ -321,40 +323,44 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
         const int rem = mm - img * a.HoWo;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
         x_m[i] = m;
-        x_ho[i] = ho;
-        x_wo[i] = wo;
+        x_hi[i] = ho * a.stride + dh;
+        x_wi[i] = wo * a.stride + dw;
         // may be "negative" (wraps) for out-of-image taps; only used when the tap is inside the image
         x_off[i] = (unsigned)((((img * a.H + ho * a.stride + dh) * a.W + wo * a.stride + dw) * a.ldx + ci0 + q * 4) * 4);
     }
-    int s_g = s_begin * 32 * a.ldg * 4;    // SGPR offset of the gradient rows of the step being fetched
-    const int s_ginc = 32 * a.ldg * 4;
+    // The gradient rows of a step are consecutive: their step dependence is ONE wave-uniform byte offset.  It must live in an
+    // SGPR (inline asm: left to hipcc it sits in a VGPR and every LDS-DMA that uses it as soffset becomes a readfirstlane
+    // loop -- four of them per step, which also keeps the scheduler from placing the DMA issue between the MFMAs).
+    int s_g0, s_ginc;                      // soffset of step k of this block = s_g0 + k * s_ginc, computed on the scalar unit
+    asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3"
+                 : "=s"(s_g0), "=s"(s_ginc)
+                 : "v"(s_begin * 32 * a.ldg * 4), "v"(32 * a.ldg * 4));
 
-#define PEMP_WG2_DMA(buf_)                                                                                        \
+#define PEMP_WG2_DMA(buf_, k_)                                                                                      \
     do {                                                                                                          \
         v4f* Gd_ = Gs + (buf_) * 32 * QPR + wave * 64;                                                            \
         v4f* Xd_ = Xs + (buf_) * 32 * QPR + wave * 64;                                                            \
+        const int sg_ = s_g0 + (k_) * s_ginc;                                                                     \
         _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                          \
             const bool mok = x_m[i] < a.M;                                                                        \
-            const int hi = x_ho[i] * a.stride + dh, wi = x_wo[i] * a.stride + dw;                                 \
-            const bool ok = mok & ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);   /* no branches */ \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lptr_t)(Gd_ + i * 256), 16, mok ? g_voff[i] : 0x80000000u, s_g, 0, 0); \
+            const bool ok = mok & ((unsigned)x_hi[i] < (unsigned)a.H) & ((unsigned)x_wi[i] < (unsigned)a.W);      \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lptr_t)(Gd_ + i * 256), 16, mok ? g_voff[i] : 0x80000000u, sg_, 0, 0); \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(Xd_ + i * 256), 16, ok ? x_off[i] : 0x80000000u, 0, 0, 0);    \
             /* advance this row by 32 output pixels (Wo >= 32: at most one wrap of wo, then at most one of ho) */ \
             x_m[i] += 32;                                                                                         \
-            int wo_ = x_wo[i] + 32;                                                                               \
+            int wi_ = x_wi[i] + 32 * a.stride;                                                                    \
             unsigned off_ = x_off[i] + (unsigned)inc32;                                                           \
-            const bool c1 = wo_ >= a.Wo;                                                                          \
-            wo_ = c1 ? wo_ - a.Wo : wo_;                                                                          \
+            const bool c1 = wi_ >= wi_hi;                                                                         \
+            wi_ = c1 ? wi_ - sW : wi_;                                                                            \
             off_ += c1 ? (unsigned)incw : 0u;                                                                     \
-            int ho_ = x_ho[i] + (c1 ? 1 : 0);                                                                     \
-            const bool c2 = ho_ >= a.Ho;                                                                          \
-            ho_ = c2 ? ho_ - a.Ho : ho_;                                                                          \
+            int hi_ = x_hi[i] + (c1 ? a.stride : 0);                                                              \
+            const bool c2 = hi_ >= hi_hi;                                                                         \
+            hi_ = c2 ? hi_ - sH : hi_;                                                                            \
             off_ += c2 ? (unsigned)inch : 0u;                                                                     \
-            x_wo[i] = wo_;                                                                                        \
-            x_ho[i] = ho_;                                                                                        \
+            x_wi[i] = wi_;                                                                                        \
+            x_hi[i] = hi_;                                                                                        \
             x_off[i] = off_;                                                                                      \
         }                                                                                                         \
-        s_g += s_ginc;                                                                                            \
     } while (0)
 
     f32x16 acc[T][T];
@@ -366,9 +372,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (nsteps > 0) {
-        PEMP_WG2_DMA(0);
+        PEMP_WG2_DMA(0, 0);
         if (nsteps > 1) {
-            PEMP_WG2_DMA(1);
+            PEMP_WG2_DMA(1, 1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NR) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -377,19 +383,22 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    const float* Gf = (const float*)Gs;
-    const float* Xf = (const float*)Xs;
-    const int gcol = wr * (TW / 2) + lr, xcol = wc * (TW / 2) + lr;
-    float ga[2][4][T], xa[2][4][T];        // [register buffer][t within the quarter][tile]
+    // Fragment reads.  A wave's T tiles along a dimension are INTERLEAVED channels (tile i = channels T r + i of the wave's
+    // TW / 2, r = MFMA row): lane r then needs T adjacent floats of a pixel row -- one ds_read_b64 for the 128 x 128 tile,
+    // with an immediate offset per (step quarter, sub-step): no per-read address arithmetic.  Which accumulator row holds
+    // which channel only matters to the store at the end; every output element is the same sum in the same order.
+    typedef float fragT __attribute__((ext_vector_type(T == 2 ? 2 : 1)));
+    const int gcol = wr * (TW / 2) + T * lr, xcol = wc * (TW / 2) + T * lr;
+    fragT ga[2][4], xa[2][4];              // [register buffer][t within the quarter]: the wave's T tiles
 
     // quarter Q of a step = reduction sub-steps t = 4Q .. 4Q+3 (pixel pairs 2t, 2t+1)
 #define PEMP_WG2_READ(dst_, buf_, Q_)                                                                             \
     do {                                                                                                          \
-        const float* Gb_ = Gf + (buf_) * 32 * TW + lh * TW + gcol;                                                \
-        const float* Xb_ = Xf + (buf_) * 32 * TW + lh * TW + xcol;                                                \
-        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) _Pragma("unroll") for (int i_ = 0; i_ < T; ++i_) {       \
-            ga[dst_][t_][i_] = Gb_[(4 * (Q_) + t_) * 2 * TW + 32 * i_];                                           \
-            xa[dst_][t_][i_] = Xb_[(4 * (Q_) + t_) * 2 * TW + 32 * i_];                                           \
+        const float* Gb_ = (const float*)Gs + (buf_) * 32 * TW + lh * TW + gcol;                                  \
+        const float* Xb_ = (const float*)Xs + (buf_) * 32 * TW + lh * TW + xcol;                                  \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                        \
+            ga[dst_][t_] = *(const fragT*)(Gb_ + (4 * (Q_) + t_) * 2 * TW);                                       \
+            xa[dst_][t_] = *(const fragT*)(Xb_ + (4 * (Q_) + t_) * 2 * TW);                                       \
         }                                                                                                         \
     } while (0)
 #define PEMP_WG2_MMA(src_)                                                                                        \
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
             _Pragma("unroll") for (int j_ = 0; j_ < T; ++j_)                                                      \
                 acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[src_][t_][i_], xa[src_][t_][j_], acc[i_][j_], 0, 0, 0); \
     } while (0)
-#define PEMP_WG2_STEP(buf_, DMA_, NEXT_)                                                                          \
+#define PEMP_WG2_STEP(buf_, DMA_, NEXT_, k_)                                                                         \
     do {                                                                                                          \
         PEMP_WG2_READ(1, buf_, 1);                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
         __builtin_amdgcn_s_barrier();                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         if (NEXT_) PEMP_WG2_READ(0, (buf_) ^ 1, 0);                                                               \
-        if (DMA_) PEMP_WG2_DMA(buf_);                                                                             \
+        if (DMA_) PEMP_WG2_DMA(buf_, (k_) + 2);                                                                          \
         PEMP_WG2_MMA(1);                                                                                          \
         if (DMA_) {                     /* one LDS read / one DMA between consecutive MFMAs of the last quarter */ \
             _Pragma("unroll") for (int k_ = 0; k_ < 4 * T * T; ++k_) {                                            \
@@ -437,16 +446,16 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
         int k = 0;
         for (; k + 2 < nsteps; ++k) {
             const int buf = k & 1;
-            PEMP_WG2_STEP(buf, true, true);
+            PEMP_WG2_STEP(buf, true, true, k);
         }
         if (k + 1 < nsteps) {
             const int buf = k & 1;
-            PEMP_WG2_STEP(buf, false, true);
+            PEMP_WG2_STEP(buf, false, true, k);
             ++k;
         }
         {
             const int buf = k & 1;
-            PEMP_WG2_STEP(buf, false, false);
+            PEMP_WG2_STEP(buf, false, false, k);
         }
     }
 #undef PEMP_WG2_STEP
@@ -454,16 +463,21 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
 #undef PEMP_WG2_READ
 #undef PEMP_WG2_DMA
 
+    // accumulator tile (i, j), MFMA row r / column lane: output channel co0 + wr TW/2 + T r + i, weight column
+    // ky TW + wc TW/2 + T lr + j (the interleaved assignment of the fragment reads): a lane's T column tiles are adjacent
+    // floats of one weight row -- one 8-byte store for the 128 x 128 tile, 256 contiguous bytes per half wave
     float* out = a.out + (size_t)split * a.Cout * a.Kpad;
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j) {
-            const int col = ky * TW + wc * (TW / 2) + j * 32 + lr;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = co0 + wr * (TW / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                out[(size_t)co * a.Kpad + col] = acc[i][j][e];
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wr * (TW / 2) + T * ((e & 3) + 8 * (e >> 2) + 4 * lh) + i;
+            float* dst = out + (size_t)co * a.Kpad + ky * TW + wc * (TW / 2) + T * lr;
+            if constexpr (T == 2) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                *(f2*)dst = f2{acc[i][0][e], acc[i][1][e]};
+            } else {
+                dst[0] = acc[i][0][e];
             }
         }
 #endif
