@@ -236,6 +236,10 @@ int pemp_conv2d_splitk_nhwc_f32(const pemp_conv_desc* d, const float* x, const f
                                 const float* shift, const float* residual, void* ws, size_t ws_bytes, void* stream);
 void* pemp_uncached_alloc(size_t bytes);       /* zero-filled; NULL on failure (pemp_last_error) */
 int pemp_uncached_free(void* p);
+/* One idle wave for `us` microseconds on `stream` (no memory traffic).  Two of them on two streams take `us` when the streams
+ * run concurrently and 2 x `us` when the runtime maps both to one hardware queue: the training engine uses it to choose a side
+ * stream that really runs beside the main one (HIP deals streams round-robin to a few hardware queues).                    */
+int pemp_spin_us(int us, void* stream);
 /* Zero the arrival counters (first 1024 bytes) of a split-K workspace on `stream`: the kernels leave them zero, a launch
  * that failed may not have -- the host side calls this before it reports the failure.                                     */
 int pemp_splitk_reset(void* ws, void* stream);

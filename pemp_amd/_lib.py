@@ -81,6 +81,7 @@ SYMBOLS = {
     "pemp_uncached_alloc": (c_fp, [c_size]),
     "pemp_uncached_free": (c_int, [c_fp]),
     "pemp_splitk_reset": (c_int, [c_fp, c_fp]),
+    "pemp_spin_us": (c_int, [c_int, c_fp]),
     "pemp_conv2d_stats_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_size, c_fp]),
     "pemp_conv2d_stats_rows": (c_int, [C.POINTER(ConvDesc)]),
     "pemp_bn_stats_partials_f32": (c_int, [c_fp, c_int, c_int, c_int, C.c_float, C.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),

@@ -469,6 +469,25 @@ extern "C" void* pemp_uncached_alloc(size_t bytes) {
     return p;
 }
 
+// One wave that does nothing for `us` microseconds (constant 100 MHz clock; bounded by an iteration count as well): two of
+// these on two streams finish in `us` when the streams map to different hardware queues and in 2 x `us` when they share one --
+// how the training engine checks that its side stream really runs beside the main one (pemp_spin_us).
+__global__ void spin_kernel(unsigned long long ticks, int* sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int n = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && n < (1 << 24)) {
+        __builtin_amdgcn_s_sleep(32);
+        ++n;
+    }
+    if (sink && n < 0) *sink = n;       // never true: keeps the loop
+}
+
+extern "C" int pemp_spin_us(int us, void* stream) {
+    PEMP_REQUIRE(us > 0 && us <= 100000, "spin_us: 1 .. 100000 us");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)us * 100ull, (int*)nullptr);
+    return launch_status("spin_us");
+}
+
 // Zero the arrival counters of a split-K workspace (its first 1024 bytes) on `stream`: the kernels leave them zero, a launch
 // that failed or was aborted may not have.
 extern "C" int pemp_splitk_reset(void* ws, void* stream) {

@@ -226,7 +226,8 @@ class EpisodeLoader:
 
     def __init__(self, batches, transform, depth=2):
         self.it, self.tf = iter(batches), transform
-        self.stream = torch.cuda.Stream(device=transform.device)
+        from .. import ops
+        self.stream = ops.concurrent_stream(torch.device(transform.device))      # a stream that really runs beside the consumer's
         self.slots = [dict(host=None, blob=None, ws=None, tf=EpisodeTransform(transform.H, transform.W, device=transform.device))
                       for _ in range(depth + 1)]
         for s in self.slots:

@@ -64,8 +64,8 @@ class FlatParams:
         self.grad_views = [self._view(self.grad, p, o) for p, o in zip(self.params, offs)]
         self.attach_grads()
         # weight-gradient kernels run on a side stream (see _Conv.wgrad); own workspace cache, joined by the engine
-        self.side_stream = (torch.cuda.Stream(device=device, priority=int(os.environ.get("PEMP_SIDE_PRIORITY", "0")))
-                            if torch.device(device).type == "cuda" else None)
+        self.side_stream = (ops.concurrent_stream(torch.device(device), priority=int(os.environ.get("PEMP_SIDE_PRIORITY", "0")))
+                            if torch.device(device).type == "cuda" else None)      # verified to run BESIDE the current stream
         self.side_ws, self.side_keep = {}, []
         self.capture = None            # a SegmentedCapture while the step is being recorded (Stage1Trainer.use_graph)
 

@@ -526,3 +526,25 @@ def test_dgrad_mirror_of_a_flat_buffer_matches_the_per_layer_transpose(hip_lib, 
         ref = T.dgrad_weight(flat[off:off + n].view(co, taps * ci), k, k)
         assert torch.equal(mirror[off:off + n].view(ci, taps * co), ref), (co, ci, k)
         pos = off + n
+
+
+def test_concurrent_stream_runs_beside_the_current_one(hip_lib, dev):
+    """ops.concurrent_stream: whatever number of streams the process has created before (HIP deals them round-robin to a few
+    hardware queues; the n-th one can share the current stream's queue), the stream it returns overlaps with the current
+    stream: two 300 us idle kernels, one on each, finish in well under 600 us."""
+    import ctypes as C
+    from pemp_amd import ops, _lib
+    cur = torch.cuda.current_stream(dev)
+    for created_before in range(5):
+        junk = [torch.cuda.Stream(device=dev) for _ in range(created_before)]
+        s = ops.concurrent_stream(dev)
+        s.wait_stream(cur)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        _lib.check(hip_lib.pemp_spin_us(300, C.c_void_p(cur.cuda_stream)), "spin")
+        _lib.check(hip_lib.pemp_spin_us(300, C.c_void_p(s.cuda_stream)), "spin")
+        cur.wait_stream(s)
+        e1.record(cur)
+        e1.synchronize()
+        assert e0.elapsed_time(e1) < 480, (created_before, e0.elapsed_time(e1))
+        del junk
