@@ -18,7 +18,11 @@ timeout -k 10 500 python3 bench.py --model baseline --batch 12 --steps 10 --warm
 timeout -k 10 500 python3 bench.py --batch 1 --steps 100 --warmup 10 $B > $O/bench_eval_b1.json 2>> $O/err.log && echo b1 ok
 fi
 if [ $PART = trace ] || [ $PART = all ]; then
-# 2. kernel traces (rocprofv3 --kernel-trace --stats) of the eval and train commands
+# 2. kernel traces (rocprofv3 --kernel-trace --stats) of the eval and train commands.  The eval command runs with ONE engine lane
+#    here (PEMP_BENCH_LANES=1; exported, not passed through a wrapper): with the default two lanes the kernels of consecutive steps
+#    overlap and a trace's per-kernel durations are those of kernels sharing the chip, not of the kernel -- bench.py's live
+#    roofline pass (single lane, events per launch) is what these averages are compared with.
+export PEMP_BENCH_LANES=1
 for tag in eval train; do
   extra=""; [ $tag = train ] && extra="--mode train"
   rm -rf $O/kt_$tag
@@ -30,6 +34,7 @@ for tag in eval train; do
   grep '^{' $O/kt_$tag.log | tail -n 1 > $O/bench_${tag}_under_rocprof.json
   rm -rf $O/kt_$tag
 done
+unset PEMP_BENCH_LANES
 # 4. prototype-head kernels alone
 rm -rf $O/kt_head
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_head -- python3 scratch/head_bench.py 25 > $O/head_b25.log 2>&1 || echo "head failed"
@@ -39,6 +44,7 @@ fi
 if [ $PART = pmc ] || [ $PART = all ]; then
 # 3. PMC passes on the eval command (tile picks replayed, so no autotune launches): HBM traffic + MFMA utilisation
 export PEMP_TILE_CACHE=$PWD/$O/tiles.json
+export PEMP_BENCH_LANES=1
 timeout -k 10 400 python3 bench.py --steps 3 --warmup 2 $B --no-roofline > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
   rm -rf $O/pmc_$c
@@ -46,7 +52,7 @@ for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
 done
 python3 scratch/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MfmaUtil $O 25 > /dev/null || echo "pmc summary failed"
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MfmaUtil
-unset PEMP_TILE_CACHE
+unset PEMP_TILE_CACHE PEMP_BENCH_LANES
 # 3b. MfmaUtil and HBM traffic of the training step
 rm -rf $O/pmc_train
 timeout -k 10 600 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/pmc_train -- python3 bench.py --mode train --steps 5 --warmup 3 --cpu-episodes 0 --no-roofline > $O/pmc_train.log 2>&1 || echo "pmc train failed"
