@@ -226,7 +226,8 @@ def episode_pool(dev, shot, batch, rank, n_groups=5, dataset="PASCAL"):
 # live per-kernel timing over the C ABI
 # ---------------------------------------------------------------------------------------------
 CLASS_OF = {
-    "pemp_conv2d_nhwc_f32": "conv", "pemp_conv2d_padv_nhwc_f32": "conv", "pemp_conv2d_wgrad_nhwc_f32": "wgrad",
+    "pemp_conv2d_nhwc_f32": "conv", "pemp_conv2d_padv_nhwc_f32": "conv", "pemp_conv2d_padv_splitk_nhwc_f32": "conv",
+    "pemp_conv2d_wgrad_nhwc_f32": "wgrad",
     "pemp_conv2d_stats_nhwc_f32": "conv", "pemp_bn_stats_partials_f32": "batchnorm", "pemp_conv2d_splitk_nhwc_f32": "conv",
     "pemp_conv2d_bnbwd_nhwc_f32": "conv", "pemp_bn_bwd_partials_f32": "batchnorm", "pemp_bn_apply_mask_f32": "batchnorm",
     "pemp_bn_fwd_partials_f32": "batchnorm", "pemp_bn_bwd_mask_f32": "batchnorm",
@@ -272,7 +273,7 @@ def _conv_work(name, a):
     m = d.N * d.Ho * d.Wo
     k = d.KH * d.KW * cin
     flops = 2.0 * m * d.Cout * k
-    res = (name in ("pemp_conv2d_nhwc_f32", "pemp_conv2d_padv_nhwc_f32", "pemp_conv2d_splitk_nhwc_f32") and bool(a[6])) or (name == "pemp_conv2d_bnbwd_nhwc_f32" and bool(a[4]))
+    res = (name in ("pemp_conv2d_nhwc_f32", "pemp_conv2d_padv_nhwc_f32", "pemp_conv2d_splitk_nhwc_f32", "pemp_conv2d_padv_splitk_nhwc_f32") and bool(a[6])) or (name == "pemp_conv2d_bnbwd_nhwc_f32" and bool(a[4]))
     outs = (2 if res else 1) + (1 if name == "pemp_conv2d_bnbwd_nhwc_f32" else 0)       # bnbwd also reads the BatchNorm's input z
     nbytes = 4.0 * (d.N * d.H * d.W * d.Cin + m * d.Cout * outs + d.Cout * d.KH * d.KW * d.Cin)
     return flops, nbytes, (m, d.Cout, k, res)

@@ -234,6 +234,11 @@ size_t pemp_conv2d_splitk_workspace_bytes(const pemp_conv_desc* d);
  * CUs idle); larger evaluation steps keep the variants that are bit-identical to each other.                              */
 int pemp_conv2d_splitk_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale,
                                 const float* shift, const float* residual, void* ws, size_t ws_bytes, void* stream);
+/* ... and with a per-channel padding VALUE as well (pemp_conv2d_padv_nhwc_f32 + the split-K tile ids): the dilated ASPPV2
+ * branch convs of a one-episode evaluation step.                                                                        */
+int pemp_conv2d_padv_splitk_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale,
+                                     const float* shift, const float* residual, const float* pad_value, void* ws,
+                                     size_t ws_bytes, void* stream);
 void* pemp_uncached_alloc(size_t bytes);       /* zero-filled; NULL on failure (pemp_last_error) */
 int pemp_uncached_free(void* p);
 /* One idle wave for `us` microseconds on `stream` (no memory traffic).  Two of them on two streams take `us` when the streams

@@ -40,6 +40,7 @@ SYMBOLS = {
     "pemp_last_error": (C.c_char_p, []),
     "pemp_abi_version": (c_int, []),
     "pemp_conv2d_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "pemp_conv2d_padv_splitk_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size, c_fp]),
     "pemp_conv2d_padv_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "pemp_pack_input_nhwc4_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "pemp_maxpool2d_nhwc_f32": (c_int, [c_fp, c_fp] + [c_int] * 11 + [c_fp]),

@@ -434,7 +434,7 @@ template <int BM, int BN, int WGM, int NW>
 static int launch_dma2_sk(const ConvArgs& a, int grid, hipStream_t st) {
     const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
     auto kern = a.stats ? (a.bz ? conv_dma2_kernel<BM, BN, WGM, NW, false, 2, true> : conv_dma2_kernel<BM, BN, WGM, NW, false, 1, true>)
-                        : conv_dma2_kernel<BM, BN, WGM, NW, false, 0, true>;
+                        : a.padv ? conv_dma2_kernel<BM, BN, WGM, NW, true, 0, true> : conv_dma2_kernel<BM, BN, WGM, NW, false, 0, true>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -448,7 +448,7 @@ static int launch_dma2_sk(const ConvArgs& a, int grid, hipStream_t st) {
 
 int launch_conv_dma2_splitk(int tile, ConvArgs a, void* ws, size_t ws_bytes, hipStream_t st) {
     const SplitKPlan p = conv_dma2_splitk_plan(tile, a);
-    if (p.pieces < 2 || a.padv) return launch_conv_dma2(tile, a, st);       // nothing to split: the plain variant
+    if (p.pieces < 2 || (a.padv && a.stats)) return launch_conv_dma2(tile, a, st);       // nothing to split: the plain variant
     if (!ws || ws_bytes < p.ws_bytes || ((uintptr_t)ws & 15)) {
         set_error("conv split-K: workspace of %zu bytes needed (16-byte aligned), got %zu", p.ws_bytes, ws_bytes);
         return -1;

@@ -275,6 +275,13 @@ extern "C" int pemp_conv2d_splitk_nhwc_f32(const pemp_conv_desc* d, const float*
     return conv2d_impl(d, x, w, y, scale, shift, residual, nullptr, ws, ws_bytes, stream);
 }
 
+extern "C" int pemp_conv2d_padv_splitk_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y,
+                                                const float* scale, const float* shift, const float* residual,
+                                                const float* pad_value, void* ws, size_t ws_bytes, void* stream) {
+    PEMP_REQUIRE(pad_value, "conv2d_padv_splitk: pad_value is null");
+    return conv2d_impl(d, x, w, y, scale, shift, residual, pad_value, ws, ws_bytes, stream);
+}
+
 static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale, const float* shift,
                        const float* residual, const float* pad_value, void* ws, size_t ws_bytes, void* stream) {
     PEMP_REQUIRE(d && x && w && y, "conv2d: null pointer");

@@ -233,11 +233,16 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
         flags |= CONV_SHIFT_PER_IMAGE
     if p.stem:
         flags |= CONV_STEM4
-    splitk = ((splitk and SPLITK) or (EVAL_SPLITK and n * ho * wo <= EVAL_SPLITK_MAX_ROWS)) and pad_value is None and not p.stem
+    splitk = ((splitk and SPLITK) or (EVAL_SPLITK and n * ho * wo <= EVAL_SPLITK_MAX_ROWS)) and not p.stem
 
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, flags, t)
-        if t > 30:
+        if t > 30 and pad_value is not None:
+            ws, ws_bytes = _splitk_ws(lib, d, x.device)
+            _check_sk(lib, lib.pemp_conv2d_padv_splitk_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift), _p(residual),
+                                                                _p(pad_value), C.c_void_p(ws), ws_bytes, _stream()), ws,
+                      "pemp_conv2d_padv_splitk_nhwc_f32")
+        elif t > 30:
             ws, ws_bytes = _splitk_ws(lib, d, x.device)
             _check_sk(lib, lib.pemp_conv2d_splitk_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift), _p(residual),
                                                            C.c_void_p(ws), ws_bytes, _stream()), ws, "pemp_conv2d_splitk_nhwc_f32")

@@ -548,3 +548,26 @@ def test_concurrent_stream_runs_beside_the_current_one(hip_lib, dev):
         e1.synchronize()
         assert e0.elapsed_time(e1) < 480, (created_before, e0.elapsed_time(e1))
         del junk
+
+
+def test_split_k_with_a_padding_value_matches_the_unsplit_conv(hip_lib, dev):
+    """pemp_conv2d_padv_splitk_nhwc_f32 (the dilated ASPPV2 branch convs of a one-episode evaluation step: BatchNorm folded in
+    front of a zero-padded conv, out-of-image taps read a per-channel value; 5202 rows = 82 tiles, all of them split along K):
+    every split-K variant against the unsplit padding-value conv, |d| <= 1e-5 max|y|, stable from launch to launch."""
+    from pemp_amd import ops
+    N, H, W, Cin, Cout = 2, 51, 51, 256, 256
+    for d in (6, 12):
+        buf = torch.empty(N * H * W + 4, Cin, device=dev)                      # the padding vector sits behind the tensor
+        buf.copy_(_rand(N * H * W + 4, Cin, seed=11).to(dev))
+        x, pv = buf[:N * H * W].view(N, H, W, Cin), buf[N * H * W]
+        w = _rand(Cout, Cin, 3, 3, seed=2, lo=-0.1, hi=0.1)
+        packed, kpad = ops.pack_conv_weight(w.to(dev))
+        prm = ops.ConvParams(packed, None, _rand(Cout, seed=4).to(dev), Cin, Cout, 3, 3, 1, d, d, kpad, False, True)
+        ref = ops.conv2d(x, prm, pad_value=pv, tile=27)
+        plain = ops.conv2d(x, prm, tile=27)
+        assert (ref - plain).abs().max() > 1e-2                                 # the padding value really enters
+        for tile in [t for t in ops.SPLITK_TILES if Cout % ops.TILE_VARIANTS[t - 10][1] == 0]:
+            y1 = ops.conv2d(x, prm, pad_value=pv, tile=tile).clone()
+            y2 = ops.conv2d(x, prm, pad_value=pv, tile=tile)
+            assert torch.equal(y1, y2), (d, tile)
+            assert (y1 - ref).abs().max() <= 1e-5 * ref.abs().max(), (d, tile)
