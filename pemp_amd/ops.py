@@ -104,6 +104,8 @@ def concurrent_stream(device, priority=0, tries=6, us=200):
     on each stream, finish in clearly less than 2 x ``us``; the last candidate is returned if none does."""
     lib = _lib.load()
     cur = torch.cuda.current_stream(device)
+    _lib.check(lib.pemp_spin_us(1, C.c_void_p(cur.cuda_stream)), "pemp_spin_us")      # the kernel's first launch (code load) is not timed
+    cur.synchronize()
     keep = []                                   # rejected candidates stay alive until the choice is made (no index reuse)
     for _ in range(tries):
         cand = torch.cuda.Stream(device=device, priority=priority)
