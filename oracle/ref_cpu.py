@@ -28,7 +28,66 @@ BN_EPS = 1e-5
 # ------------------------------------------------------------------------------------------
 TRAIN = False     # module switch: True = model.train() semantics for BatchNorm (batch statistics,
                   # running-stat update with momentum 0.1); DropBlock/Dropout2d stay identities, i.e.
-                  # drop_rate = 0 (their random streams cannot be pinned: dropblock's source is absent)
+                  # drop_rate = 0, unless DROPBLOCK below supplies the draws (the layers' own random streams
+                  # cannot be pinned)
+
+# DropBlock2D of the stage-1 purifier / ASPPV2 (networks/pemp_stage1.py:76,79; backbones.py:329-351).  The layer comes from
+# the third-party package dropblock==0.3.0, which is not in /root/reference; its published forward is restated in
+# _dropblock below.  ``DROPBLOCK = DropBlock(drop_prob, block_size, uniforms)`` makes the train-mode pass apply it with the
+# uniform draws GIVEN per layer (tag = the DropBlock2D module's name, e.g. "encoder.purifier.2", ->
+# float tensor [N,H,W] in [0,1), what ``torch.rand`` would have produced inside the layer); None: identity.
+DROPBLOCK = None
+
+
+class DropBlock:
+    def __init__(self, drop_prob, block_size, uniforms):
+        self.drop_prob, self.block_size, self.uniforms = float(drop_prob), int(block_size), uniforms
+        self.used = set()
+
+
+# nn.Dropout2d of the stage-2 purifier / ASPP (networks/pemp_stage2.py:68,71; backbones.py:282-306), same arrangement:
+# ``DROPOUT2D = Dropout2d(p, uniforms)`` with uniforms[tag] = float tensor [N,C] in [0,1) -- the draws behind ATen's
+# bernoulli_(1 - p) noise tensor (feature_dropout: noise = (u < 1 - p) / (1 - p), one value per (image, channel)).
+DROPOUT2D = None
+
+
+class Dropout2d:
+    def __init__(self, p, uniforms):
+        self.p, self.uniforms = float(p), uniforms
+        self.used = set()
+
+
+def _dropout2d(x, tag):
+    d = DROPOUT2D
+    if d is None or not TRAIN or d.p == 0.0:
+        return x
+    u = d.uniforms[tag]
+    d.used.add(tag)
+    if tuple(u.shape) != tuple(x.shape[:2]):
+        raise ValueError(f"dropout2d {tag}: draws {tuple(u.shape)} for activation {tuple(x.shape)}")
+    noise = (u < 1 - d.p).to(x.dtype) / (1 - d.p)
+    return x * noise[:, :, None, None]
+
+
+def _dropblock(x, tag):
+    """dropblock.DropBlock2D.forward (0.3.0) in train(): gamma = drop_prob / block_size^2; seeds = rand(N,H,W) < gamma;
+    block mask = 1 - max_pool2d(seeds, block_size, stride 1, padding block_size // 2) (last row/column cut for an even
+    block size); out = x * mask * numel(mask) / sum(mask)."""
+    d = DROPBLOCK
+    if d is None or not TRAIN or d.drop_prob == 0.0:
+        return x
+    u = d.uniforms[tag]
+    d.used.add(tag)
+    if tuple(u.shape) != (x.shape[0],) + tuple(x.shape[2:]):
+        raise ValueError(f"dropblock {tag}: draws {tuple(u.shape)} for activation {tuple(x.shape)}")
+    bs = d.block_size
+    seeds = (u < d.drop_prob / bs ** 2).to(x.dtype)
+    bm = F.max_pool2d(seeds[:, None], kernel_size=(bs, bs), stride=(1, 1), padding=bs // 2)
+    if bs % 2 == 0:
+        bm = bm[:, :, :-1, :-1]
+    bm = 1 - bm.squeeze(1)
+    out = x * bm[:, None]
+    return out * bm.numel() / bm.sum()
 
 
 # Decision switches (tests/test_grad_frozen_gpu.py).  The path has three kinds of discrete decisions: the sign of a ReLU's
@@ -177,29 +236,31 @@ _ASPP_DIL = (None, 0, 6, 12, 18)  # aspp_0 = global branch, aspp_1 = 1x1, then d
 def aspp_v2(x, sd, p):
     """ASPPV2.forward, BN -> (DropBlock) -> conv -> ReLU per branch (backbones.py:324-369)."""
     g = F.adaptive_avg_pool2d(x, (1, 1))
-    g = _relu(_conv(_bn(g, sd, p + ".aspp_0.0"), sd, p + ".aspp_0.2"), p + ".aspp_0.relu")
+    g = _relu(_conv(_dropblock(_bn(g, sd, p + ".aspp_0.0"), p + ".aspp_0.1"), sd, p + ".aspp_0.2"), p + ".aspp_0.relu")
     outs = [g.expand(-1, -1, *x.shape[-2:])]
     for i in range(1, 5):
         d = _ASPP_DIL[i]
-        outs.append(_relu(_conv(_bn(x, sd, f"{p}.aspp_{i}.0"), sd, f"{p}.aspp_{i}.2",
+        outs.append(_relu(_conv(_dropblock(_bn(x, sd, f"{p}.aspp_{i}.0"), f"{p}.aspp_{i}.1"), sd, f"{p}.aspp_{i}.2",
                                 padding=d, dilation=max(d, 1)), f"{p}.aspp_{i}.relu"))
     return _conv(torch.cat(outs, 1), sd, p + ".layer6")
 
 
 def aspp(x, sd, p):
     """ASPP.forward, conv -> ReLU -> (Dropout2d) per branch (backbones.py:279-321)."""
-    g = F.relu(_conv(F.adaptive_avg_pool2d(x, (1, 1)), sd, p + ".aspp_0.0"))
+    g = _dropout2d(F.relu(_conv(F.adaptive_avg_pool2d(x, (1, 1)), sd, p + ".aspp_0.0")), p + ".aspp_0.2")
     outs = [g.expand(-1, -1, *x.shape[-2:])]
     for i in range(1, 5):
         d = _ASPP_DIL[i]
-        outs.append(F.relu(_conv(x, sd, f"{p}.aspp_{i}.0", padding=d, dilation=max(d, 1))))
+        outs.append(_dropout2d(F.relu(_conv(x, sd, f"{p}.aspp_{i}.0", padding=d, dilation=max(d, 1))), f"{p}.aspp_{i}.2"))
     return _conv(torch.cat(outs, 1), sd, p + ".layer6")
 
 
 def purifier(x, sd, p, v2=True):
     """encoder.purifier (networks/pemp_stage1.py:73-80; pemp_stage2.py:65-72)."""
     x = _relu(_conv(x, sd, p + ".0"), p + ".0.relu")
+    x = _dropblock(x, p + ".2") if v2 else _dropout2d(x, p + ".2")
     x = _relu(_conv(x, sd, p + ".3", padding=1), p + ".3.relu")
+    x = _dropblock(x, p + ".5") if v2 else _dropout2d(x, p + ".5")
     return aspp_v2(x, sd, p + ".6") if v2 else aspp(x, sd, p + ".6")
 
 
@@ -486,18 +547,19 @@ def celoss_dt(logits, target, sigma=5.0):
 # one training step under autograd (the training cpu_baseline of bench.py; tests/golden/make_f64.py does the same in fp64)
 # ------------------------------------------------------------------------------------------
 def train_step(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", qry_prior=None, lr=1e-3, weight_decay=5e-4,
-               max_norm=1.1):
+               max_norm=1.1, dropblock=None):
     """Trainer.train_step (entry/pemp_stage1.py:57-65; stage 2: entry/pemp_stage2.py:72-83): forward with the model in
-    train() mode (batch-statistics BatchNorm; DropBlock / Dropout2d as identities, i.e. rate 0), CrossEntropyLoss(ignore 255),
+    train() mode (batch-statistics BatchNorm; Dropout2d as identity; DropBlock as identity unless ``dropblock`` =
+    DropBlock(...) gives its draws), CrossEntropyLoss(ignore 255),
     backward by autograd, clip_grad_norm_(1.1) (stage 1 only, entry/pemp_stage1.py:63), one SGD step (momentum buffers empty:
     first step, core/solver.py:87-91).  ``sd`` is updated in place (weights and BN running statistics).
     Returns (loss, {name: gradient})."""
-    global TRAIN
+    global TRAIN, DROPBLOCK
     frozen = lambda k: ("running" in k or "num_batches" in k or k.endswith("backbone.bn1.weight") or k.endswith("backbone.bn1.bias")
                         or ".downsample.1." in k)                      # freeze_bn: stem + downsample BN affines (backbones.py:93-95,113-117)
     leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not frozen(k)}
-    old = TRAIN
-    TRAIN = True
+    old = (TRAIN, DROPBLOCK)
+    TRAIN, DROPBLOCK = True, dropblock
     try:
         H, W = qry_msk.shape[-2:]
         if model == "stage1":
@@ -508,7 +570,7 @@ def train_step(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", qry_prio
         names = list(leaves)
         grads = dict(zip(names, torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)))
     finally:
-        TRAIN = old
+        TRAIN, DROPBLOCK = old
     with torch.no_grad():
         live = [g for g in grads.values() if g is not None]
         if model == "stage1" and max_norm > 0:
@@ -526,31 +588,55 @@ def train_step(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", qry_prio
     return float(loss.detach()), grads
 
 
-def frozen_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, decisions, model="stage1", backbone="resnet50",
-                     dtype=torch.float64):
-    """Loss and d loss / d parameter of ONE train-mode forward (batch-statistics BatchNorm, regularisers off, CE) in which
-    every discrete decision -- ReLU sign, max-pool winner, winning prototype -- is TAKEN from ``decisions`` (see Switches),
-    evaluated in ``dtype`` under autograd.  ``sd`` is not modified.  -> (loss float, {name: gradient}, tags used)."""
-    global TRAIN, SWITCHES
+def step_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", backbone="resnet50", qry_prior=None,
+                   dtype=torch.float32, decisions=None, dropblock=None, dropout2d=None, probe=None):
+    """Loss and d loss / d parameter of ONE train-mode forward (batch-statistics BatchNorm, CE) evaluated in ``dtype`` under
+    autograd; ``sd`` is not modified (no update, running statistics untouched).  ``decisions``: see Switches (None: plain
+    ReLU / max); ``dropblock`` / ``dropout2d``: the regularisers with given draws (None: identities).
+    ``probe`` (stage1 / baseline): a tensor R shaped like the encoder's output [B*(S+Q),c,h,w]; the head and the CE are
+    replaced by the linear functional  loss = sum(encoder(images) * R), i.e. d loss / d features = R exactly -- the
+    encoder's backward pass alone, without the conditioning of the prototype head.
+    -> (loss float, {name: gradient}, decision tags used)."""
+    global TRAIN, SWITCHES, DROPBLOCK, DROPOUT2D
     frozen = lambda k: ("running" in k or "num_batches" in k or k.endswith("backbone.bn1.weight") or k.endswith("backbone.bn1.bias")
                         or ".downsample.1." in k)
     w = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
     leaves = {k: v.requires_grad_(True) for k, v in w.items() if v.is_floating_point() and not frozen(k)}
-    old = (TRAIN, SWITCHES)
-    TRAIN, SWITCHES = True, Switches(decisions)
+    old = (TRAIN, SWITCHES, DROPBLOCK, DROPOUT2D)
+    TRAIN, SWITCHES, DROPBLOCK, DROPOUT2D = True, (None if decisions is None else Switches(decisions)), dropblock, dropout2d
     try:
         H, W = qry_msk.shape[-2:]
         ins = (sup_img.to(dtype), sup_mask.to(dtype), qry_img.to(dtype))
-        if model == "stage1":
-            logits = stage1_forward(w, *ins, (H, W), backbone=backbone)
-        elif model == "baseline":
-            logits = baseline_forward(w, *ins, (H, W), backbone=backbone)
+        if probe is not None:
+            if model not in ("stage1", "baseline"):
+                raise ValueError("probe: stage1 / baseline encoders only")
+            x = torch.cat((ins[0], ins[2]), dim=1).flatten(0, 1)              # the image order of *_forward
+            f = encoder_stage1(x, w, backbone) if model == "stage1" else encoder_baseline(x, w, backbone)
+            loss = (f * probe.to(dtype)).sum()
         else:
-            raise ValueError(model)
-        loss = ce_loss(logits, qry_msk.view(-1, H, W))
+            if model == "stage1":
+                logits = stage1_forward(w, *ins, (H, W), backbone=backbone)
+            elif model == "baseline":
+                logits = baseline_forward(w, *ins, (H, W), backbone=backbone)
+            elif model == "stage2":
+                logits = stage2_forward(w, *ins, qry_prior.to(dtype), (H, W), backbone2=backbone)
+            else:
+                raise ValueError(model)
+            loss = ce_loss(logits, qry_msk.view(-1, H, W))
         names = list(leaves)
         grads = dict(zip(names, torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)))
-        used = set(SWITCHES.used)
+        used = set() if SWITCHES is None else set(SWITCHES.used)
     finally:
-        TRAIN, SWITCHES = old
+        TRAIN, SWITCHES, DROPBLOCK, DROPOUT2D = old
     return float(loss.detach()), {k: g for k, g in grads.items() if g is not None}, used
+
+
+def frozen_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, decisions, model="stage1", backbone="resnet50",
+                     dtype=torch.float64, dropblock=None, probe=None):
+    """Loss and d loss / d parameter of ONE train-mode forward (batch-statistics BatchNorm, regularisers off, CE) in which
+    every discrete decision -- ReLU sign, max-pool winner, winning prototype -- is TAKEN from ``decisions`` (see Switches),
+    evaluated in ``dtype`` under autograd.  ``dropblock`` = DropBlock(...) applies the stage-1 DropBlock layers with the
+    given draws (their masks depend on the draws only, so they are part of the frozen function).  ``sd`` is not modified.
+    -> (loss float, {name: gradient}, tags used)."""
+    return step_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, model=model, backbone=backbone, dtype=dtype,
+                          decisions=decisions, dropblock=dropblock, probe=probe)

@@ -356,6 +356,7 @@ class Stage1TrainEngine:
                 p.data = p.data.to(device)
         self.ws = {}
         self.drop_rate, self.block_size = 0.0, 4
+        self.draws = None                                            # see _dropblock
         self.rng = T.RandomStream(torch.initial_seed(), device)      # Philox stream of the DropBlock / Dropout2d kernels
         self._init_trunk(model.encoder.backbone)
         self._init_tail(model)
@@ -392,11 +393,18 @@ class Stage1TrainEngine:
     def _new(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
-    def _dropblock(self, x, n, h, w):
-        """DropBlock2D(drop_rate, block_size) in train(): -> (y, record for the backward) (identity at rate 0)."""
+    def _dropblock(self, x, n, h, w, layer):
+        """DropBlock2D(drop_rate, block_size) in train(): -> (y, record for the backward) (identity at rate 0).  ``layer`` is
+        the module's name in the reference model; ``self.draws`` ({layer: uniforms [n,h,w]}) replaces the Philox stream by
+        given draws (parity tests: the same draws go to the oracle's restatement of the layer)."""
         if self.drop_rate <= 0.0:
             return x, None
-        rec = T.dropblock_mask(n, h, w, self.drop_rate, self.block_size, self.rng, self.device)
+        u = None
+        if self.draws is not None:
+            u = self.draws[layer]
+            if tuple(u.shape) != (n, h, w) or u.dtype != torch.float32 or u.device != x.device or not u.is_contiguous():
+                raise ValueError(f"dropblock draws of {layer}: want contiguous float32 {(n, h, w)} on {x.device}")
+        rec = T.dropblock_mask(n, h, w, self.drop_rate, self.block_size, self.rng, self.device, uniforms=u)
         return T.pixel_scale(x, *rec), rec
 
     @staticmethod
@@ -525,16 +533,16 @@ class Stage1TrainEngine:
         # purifier: conv+bias+ReLU (+DropBlock) twice
         nimg, h, w, _ = x.shape
         ya = conv2d(x, self.p0.fwd_params(relu=True))
-        xa, da = self._dropblock(ya, nimg, h, w)
+        xa, da = self._dropblock(ya, nimg, h, w, "encoder.purifier.2")
         yb = conv2d(xa, self.p3.fwd_params(relu=True))
-        xb, db = self._dropblock(yb, nimg, h, w)
+        xb, db = self._dropblock(yb, nimg, h, w, "encoder.purifier.5")
         tape.update(p0_in=x, ya=ya, da=da, xa=xa, yb=yb, db=db, xb=xb)
         # ASPPV2: five BNs share the statistics of xb (branch 0: of its global average)
         midc = self.midc
         gap = ops.global_avgpool(xb)
         m0, i0 = self.aspp_bn[0].stats(gap, self.ws)
         t0 = T.bn_apply(gap, m0, i0, self.aspp_bn[0].bn.weight.data, self.aspp_bn[0].bn.bias.data, torch.empty_like(gap), relu=False)
-        t0d, d0 = self._dropblock(t0, nimg, 1, 1)
+        t0d, d0 = self._dropblock(t0, nimg, 1, 1, "encoder.purifier.6.aspp_0.1")
         g0 = conv2d(t0d.view(nimg, 1, 1, -1), self.aspp_conv[0].fwd_params(relu=True))
         l6w = self.l6.weight
         w6 = self.flat.krsc(l6w)                                   # [512, 1280]
@@ -549,7 +557,7 @@ class Stage1TrainEngine:
             # that BN's own running statistics
             mean_x, invstd_x = bn.stats(xb, self.ws)
             t = T.bn_apply(xb, mean_x, invstd_x, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(xb), relu=False)
-            td, d = self._dropblock(t, nimg, h, w)
+            td, d = self._dropblock(t, nimg, h, w, f"encoder.purifier.6.aspp_{i}.1")
             conv2d(td, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
             ts.append(td)
             ds_.append(d)

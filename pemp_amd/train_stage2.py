@@ -14,7 +14,8 @@ What differs from stage 1 (pemp_amd/train_engine.py), and how it is laid out her
   are differentiated explicitly (``pemp_cm_bwd_add_f32`` routes the max gradient to the arg-max pixel);
 * the block BatchNorms are trainable here (only the stem / downsample BNs are frozen, backbones.py:175-202);
 * the purifier uses ``ASPP`` (conv -> ReLU -> Dropout2d, no BN; backbones.py:279-321) and Dropout2d(drop_rate2);
-  the channel masks are drawn by the Philox kernels of dropout.hip (draws parity-unpinned, like DropBlock);
+  the channel masks are drawn by the Philox kernels of dropout.hip (the stream itself has no counterpart in the
+  reference; with the draws given -- ``eng.draws`` -- the step is checked against the oracle, tests/test_train_gpu.py);
 * gradients are clipped only for the VGG variant (entry/pemp_stage2.py:79-81), i.e. never for ResNet-50.
 """
 import torch
@@ -140,11 +141,18 @@ class Stage2TrainEngine(Stage1TrainEngine):
         self._cbn_bwd(dy, tp["stem"], *self.stem, need_dx=False)
 
     # -- purifier: conv+ReLU+Dropout2d twice, ASPP (no BN), layer6 ------------------------------
-    def _drop(self, y, n, c):
-        """nn.Dropout2d(drop_rate2) in train(): one Bernoulli(1-p)/(1-p) multiplier per (image, channel)."""
+    def _drop(self, y, n, c, layers):
+        """nn.Dropout2d(drop_rate2) in train(): one Bernoulli(1-p)/(1-p) multiplier per (image, channel).  ``layers``: the
+        reference names of the Dropout2d modules this call stands for, channel ranges in order; ``self.draws``
+        ({layer: uniforms [n, channels]}) replaces the Philox stream by given draws (parity tests)."""
         if self.drop_rate2 <= 0.0:
             return y, None
-        m = T.dropout2d_mask(n, c, self.drop_rate2, self.rng, self.device)
+        u = None
+        if self.draws is not None:
+            u = torch.cat([self.draws[k] for k in layers], dim=1).contiguous()
+            if tuple(u.shape) != (n, c) or u.dtype != torch.float32 or u.device != y.device:
+                raise ValueError(f"dropout2d draws of {layers}: want float32 {(n, c)} on {y.device}")
+        m = T.dropout2d_mask(n, c, self.drop_rate2, self.rng, self.device, uniforms=u)
         return T.channel_scale(y, m), m
 
     @staticmethod
@@ -155,12 +163,12 @@ class Stage2TrainEngine(Stage1TrainEngine):
         nimg, h, w, _ = x.shape
         midc = self.midc
         ya = conv2d(x, self.p0.fwd_params(relu=True))
-        xa, ma = self._drop(ya, nimg, ya.shape[-1])
+        xa, ma = self._drop(ya, nimg, ya.shape[-1], ("encoder.purifier.2",))
         yb = conv2d(xa, self.p3.fwd_params(relu=True))
-        xb, mb = self._drop(yb, nimg, yb.shape[-1])
+        xb, mb = self._drop(yb, nimg, yb.shape[-1], ("encoder.purifier.5",))
         gap = ops.global_avgpool(xb)
         g0 = conv2d(gap.view(nimg, 1, 1, -1), self.aspp_conv[0].fwd_params(relu=True))
-        g0d, m0 = self._drop(g0, nimg, midc)
+        g0d, m0 = self._drop(g0, nimg, midc, ("encoder.purifier.6.aspp_0.2",))
         l6w = self.l6.weight
         w6 = self.flat.krsc(l6w)                                              # [512, 1280]
         w6g = ConvParams(w6[:, :midc].contiguous(), None, self.l6.bias.data, midc, l6w.shape[0], 1, 1, 1, 0, 1, midc, False, False)
@@ -168,7 +176,8 @@ class Stage2TrainEngine(Stage1TrainEngine):
         cat = self._new(nimg, h, w, 4 * midc)                                 # post-ReLU branch outputs u_i
         for i in range(1, 5):
             conv2d(xb, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
-        catd, ms = self._drop(cat, nimg, 4 * midc)                            # the four branch Dropout2d layers at once
+        # the four branch Dropout2d layers at once
+        catd, ms = self._drop(cat, nimg, 4 * midc, tuple(f"encoder.purifier.6.aspp_{i}.2" for i in range(1, 5)))
         w6m = ConvParams(w6[:, midc:].contiguous(), None, None, 4 * midc, l6w.shape[0], 1, 1, 1, 0, 1, 4 * midc, False, False)
         feat = conv2d(catd, w6m, shift_override=bias6.view(nimg, -1), per_image_shift=True)
         tape.update(p0_in=x, ya=ya, ma=ma, xa=xa, yb=yb, mb=mb, xb=xb, gap=gap, g0=g0, m0=m0, g0d=g0d, cat=cat, catd=catd,

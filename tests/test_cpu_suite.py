@@ -752,3 +752,66 @@ def test_protos_beyond_the_kernel_limit_fail_at_model_construction():
         m1.PEMPStage1(None, protos=9)
     with pytest.raises(ValueError, match="net.protos2 = 12"):
         m2.PEMPStage2(1, 1, None, protos2=12)
+
+
+def test_oracle_dropblock_is_the_published_layer_on_hand_cases():
+    """oracle/ref_cpu.py:_dropblock against block masks worked out by hand from dropblock==0.3.0's definition (the package is
+    not in /root/reference): a seed at (r, c) blanks rows r-1..r+1 for block size 3, rows r..r+1 for block size 2 and rows r-1..r+2 for
+    block size 4 (output i of the max pool covers inputs i - block//2 .. i - block//2 + block - 1; last row/column cut for
+    even sizes), the survivors are scaled by numel / kept over the WHOLE batch."""
+    from oracle import ref_cpu
+    x = torch.arange(2 * 3 * 5 * 5, dtype=torch.float32).view(2, 3, 5, 5) + 1
+    old = (ref_cpu.TRAIN, ref_cpu.DROPBLOCK)
+    try:
+        ref_cpu.TRAIN = True
+        for bs, rows in ((3, slice(1, 4)), (2, slice(2, 4)), (4, slice(1, 5))):
+            u = torch.ones(2, 5, 5)
+            u[1, 2, 2] = 0.0                                         # one seed: image 1, pixel (2, 2)
+            ref_cpu.DROPBLOCK = ref_cpu.DropBlock(0.5, bs, {"l": u})
+            keep = torch.ones(2, 5, 5)
+            keep[1, rows, rows] = 0
+            want = x * keep[:, None] * keep.numel() / keep.sum()
+            assert torch.equal(ref_cpu._dropblock(x, "l"), want)
+        # a seed in the corner: the block is clipped by the border
+        u = torch.ones(2, 5, 5)
+        u[0, 0, 4] = 0.0
+        ref_cpu.DROPBLOCK = ref_cpu.DropBlock(0.5, 4, {"l": u})
+        keep = torch.ones(2, 5, 5)
+        keep[0, 0:3, 3:5] = 0                                         # rows -1..2, columns 3..6, clipped
+        assert torch.equal(ref_cpu._dropblock(x, "l"), x * keep[:, None] * 50 / keep.sum())
+        # 1 x 1 maps (the ASPP global branch): a seed drops the whole image
+        g = torch.ones(3, 4, 1, 1)
+        ref_cpu.DROPBLOCK = ref_cpu.DropBlock(0.5, 4, {"g": torch.tensor([1.0, 0.0, 1.0]).view(3, 1, 1)})
+        assert torch.equal(ref_cpu._dropblock(g, "g").flatten(1)[:, 0], torch.tensor([1.5, 0.0, 1.5]))
+        ref_cpu.TRAIN = False                                          # eval(): identity
+        assert ref_cpu._dropblock(x, "l") is x
+        ref_cpu.TRAIN, ref_cpu.DROPBLOCK = True, None                   # no draws given: identity
+        assert ref_cpu._dropblock(x, "l") is x
+    finally:
+        ref_cpu.TRAIN, ref_cpu.DROPBLOCK = old
+
+
+def test_oracle_dropout2d_reproduces_torch_given_its_noise():
+    """oracle/ref_cpu.py:_dropout2d against nn.Dropout2d itself: torch's output determines its noise tensor (0 or 1/(1-p),
+    one value per image and channel); fed draws that give the same keep decisions, the restatement returns torch's output
+    bit for bit.  (ATen's Bernoulli stream itself is not reproducible from torch.rand, hence draws are an input.)"""
+    import torch.nn.functional as F
+    from oracle import ref_cpu
+    torch.manual_seed(5)
+    x = torch.rand(6, 32, 7, 9) + 0.5
+    old = (ref_cpu.TRAIN, ref_cpu.DROPOUT2D)
+    try:
+        ref_cpu.TRAIN = True
+        for p in (0.5, 0.3):
+            y = F.dropout2d(x, p, True)
+            nz = (y != 0).flatten(2)
+            assert torch.equal(nz.all(dim=2), nz.any(dim=2))                              # a channel is kept or dropped whole
+            kept = nz[:, :, 0]
+            assert 0 < int(kept.sum()) < kept.numel()
+            u = torch.where(kept, torch.zeros(()), torch.ones(()))                        # u < 1 - p  <=>  kept
+            ref_cpu.DROPOUT2D = ref_cpu.Dropout2d(p, {"l": u})
+            assert torch.equal(ref_cpu._dropout2d(x, "l"), y)
+        ref_cpu.TRAIN = False
+        assert ref_cpu._dropout2d(x, "l") is x
+    finally:
+        ref_cpu.TRAIN, ref_cpu.DROPOUT2D = old

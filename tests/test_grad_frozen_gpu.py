@@ -8,15 +8,25 @@ layer's output; max pool: the winners of the layer's float32 input, first maximu
 choose; prototype maximum: the winners the cosine backward recorded in its workspace), and the oracle evaluates the SAME decision-frozen function in float64
 under autograd (oracle/ref_cpu.py: Switches, frozen_gradients).  What is left between the two gradients is rounding only:
 
-    every parameter tensor:  |hip - g64|_2 <= max(1e-5 * |g64|_2,  3 * |cpu32 - g64|_2)
+    every parameter tensor:  |hip - g64|_2 <= max(1e-5 * |g64|_2,  factor * |cpu32 - g64|_2)
 
-where cpu32 is the same frozen function evaluated in float32 by the oracle on the CPU.  The two Baselines stay under the
-absolute 1e-5 (measured: VGG-16 2e-6 .. 3.3e-6, ResNet-50 3e-6 .. 6.8e-6; their end-to-end bound is 3e-3).  Stage 1's
-meta-prototype head is ill-conditioned in float32 -- a softmax over -|x - c|^2 of 512-dimensional features, |x - c|^2 in the
-hundreds -- and there float32 arithmetic itself, CPU or GPU, sits ~1e-4 from float64; the second term holds the HIP path to
-that floor instead of letting the conditioning of the function pass as slack everywhere
-for stage-1 ResNet-50, Baseline ResNet-50 and Baseline VGG-16 at 97 x 97 (the cases whose end-to-end bound was widened in
-round 2).  The loss agrees to 1e-6."""
+where cpu32 is the same frozen function evaluated in float32 by the oracle on the CPU.
+
+* The two Baselines stay under the absolute 1e-5 (measured: VGG-16 2e-6 .. 3.3e-6, ResNet-50 3e-6 .. 7.6e-6; their
+  end-to-end bound is 3e-3).
+* Stage 1's ENCODER (trunk, purifier, ASPPV2, DropBlock on and off) is taken alone under a linear probe -- the head
+  replaced by sum(features * R) -- and held to factor 3 with a cap of 5e-5 (measured 1.2e-5 .. 2.5e-5, the oracle's float32
+  1.2e-5 .. 2.6e-5: a white-noise R through 50 batch-statistics BatchNorm backward passes).
+* Stage 1's FULL step is ill-conditioned in float32 whoever evaluates it: the meta-prototype head takes a softmax over
+  -|x - c|^2 of 512-dimensional features with |x - c|^2 in the hundreds, so the 1e-5 relative error a float32 forward pass
+  leaves in the features (and, in the reference's formulation, the 1e-4 absolute rounding of the distances themselves --
+  the HIP head avoids that part, csrc/head_common.h) comes out as ~1e-4 in every gradient.  Measured over several runs: HIP
+  0.9e-4 .. 4.4e-4, the oracle's float32 0.7e-4 .. 2.7e-4, in no fixed ratio (0.6 .. 3.8: the realised decisions differ from
+  run to run with the autotuned tile choices).  Those two tests use factor 8: they pin the step's structure (every decision
+  consumed, the DropBlock masks, the prototype routing) and a 1e-3-class error, not the last digit; the last digit is pinned
+  by the probe test and by the per-kernel tests of the head (test_train_ops_gpu.py).
+
+The loss agrees to 2e-6 in the full-step cases."""
 import numpy as np
 import pytest
 import torch
@@ -27,6 +37,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 BOUND = 1e-5
 FACTOR = 3.0
+FULL_STEP_FACTOR = 8.0         # stage 1 through its float32-ill-conditioned head, see above
 
 
 def _nchw(t, perm=None):
@@ -79,8 +90,9 @@ def _vgg_decisions(tape, perm, prefix="encoder.backbone"):
     return d
 
 
-def _run(tr, net, batch, model, backbone, tail):
-    """-> (hip loss, {name: hip gradient}, decisions of the HIP forward pass, oracle-ordered CPU inputs)."""
+def _run(tr, net, batch, model, backbone, tail, probe=False):
+    """-> (hip loss, {name: hip gradient}, decisions of the HIP forward pass[, the probe R in the oracle's layout]).
+    ``probe``: the head is replaced by loss = sum(features * R) with a random R, so d loss / d features = R exactly."""
     from oracle import ref_cpu
     sup, msk, qry, gt = batch
     B, S = sup.shape[:2]
@@ -96,7 +108,14 @@ def _run(tr, net, batch, model, backbone, tail):
 
     def spy_head(feat, *a):
         grabbed["feat"] = feat.detach().clone()
-        return orig_head(feat, *a)
+        if not probe:
+            return orig_head(feat, *a)
+        gen = torch.Generator().manual_seed(5)
+        R = (torch.randn(feat.shape, generator=gen) / feat.shape[0] ** 0.5).to(feat.device)     # NHWC, the engine's image order
+        grabbed["R"] = R
+        loss = (feat.double() * R.double()).sum()
+        eng.backward(R.clone())
+        return loss, None
 
     eng.backward, tr._head_hip = spy_backward, spy_head
     try:
@@ -108,7 +127,7 @@ def _run(tr, net, batch, model, backbone, tail):
     dec = _vgg_decisions(tape, perm) if backbone == "vgg16" else _resnet_decisions(tape, perm)
     if tail:
         dec.update(_stage1_tail_decisions(tape, perm, eng.midc))
-    if model == "stage1":
+    if model == "stage1" and not probe:
         # winning prototypes: what the cosine backward itself routed every (query pixel, group) gradient to -- it leaves them
         # in the tail of its workspace (pemp_head_bwd_workspace_bytes).  Coinciding meta-prototypes give exact ties over whole
         # regions, so a recomputation in other arithmetic would not reproduce these choices.
@@ -124,17 +143,21 @@ def _run(tr, net, batch, model, backbone, tail):
         # oracle layout (compute_similarity): channel 0 = background, 1 = foreground, index inside the group
         dec["head.proto_max"] = torch.stack((win[:, 1] - p, win[:, 0]), dim=1)
     grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.requires_grad and p.grad is not None}
+    if probe:
+        grads.pop("ctr", None)                                         # the head's parameter: no gradient from the probe
+        return float(loss.item()), grads, dec, _nchw(grabbed["R"], perm)
     return float(loss.item()), grads, dec
 
 
-def _compare(what, hip_loss, hip, sd, batch, dec, model, backbone):
+def _compare(what, hip_loss, hip, sd, batch, dec, model, backbone, dropblock=None, probe=None, factor=FACTOR, loss_rtol=2e-6):
     from oracle import ref_cpu
     sup, msk, qry, gt = (t.cpu() for t in batch)
-    loss64, g64, used = ref_cpu.frozen_gradients(sd, sup, msk, qry, gt, dec, model=model, backbone=backbone)
+    kw = dict(model=model, backbone=backbone, dropblock=dropblock, probe=probe)
+    loss64, g64, used = ref_cpu.frozen_gradients(sd, sup, msk, qry, gt, dec, **kw)
     assert used == set(dec), (sorted(set(dec) - used), sorted(used - set(dec)))      # every decision of the pass was frozen
     # the same frozen function in float32 on the CPU: what float32 arithmetic itself leaves of the float64 gradient
-    _, g32, _ = ref_cpu.frozen_gradients(sd, sup, msk, qry, gt, dec, model=model, backbone=backbone, dtype=torch.float32)
-    assert abs(hip_loss - loss64) <= 2e-6 * max(1.0, abs(loss64)), (hip_loss, loss64)
+    _, g32, _ = ref_cpu.frozen_gradients(sd, sup, msk, qry, gt, dec, dtype=torch.float32, **kw)
+    assert loss_rtol is None or abs(hip_loss - loss64) <= loss_rtol * max(1.0, abs(loss64)), (hip_loss, loss64)
     assert set(hip) == set(g64), sorted(set(hip) ^ set(g64))[:10]
     rows = []
     for name, g in g64.items():
@@ -146,7 +169,7 @@ def _compare(what, hip_loss, hip, sd, batch, dec, model, backbone):
           f"cpu float32 max {max(r[1] for r in rows):.2e}, median {sorted(r[1] for r in rows)[len(rows) // 2]:.2e}")
     for e_hip, e_32, name in rows[:5]:
         print(f"   {name:50s} hip {e_hip:.2e}   cpu float32 {e_32:.2e}")
-    bad = [(n, eh, e32) for eh, e32, n in rows if eh > max(BOUND, FACTOR * e32)]
+    bad = [(n, eh, e32) for eh, e32, n in rows if eh > max(BOUND, factor * e32)]
     assert not bad, (what, bad[:10])
     return rows
 
@@ -167,7 +190,69 @@ def test_stage1_rn50_gradients_with_frozen_decisions(hip_lib, dev):
     tr = Stage1Trainer(net, device=dev, drop_rate=0.0)
     batch = _batch(dev)
     hip_loss, hip, dec = _run(tr, net, batch, "stage1", "resnet50", tail=True)
-    _compare("stage1_rn50", hip_loss, hip, sd, batch, dec, "stage1", "resnet50")
+    _compare("stage1_rn50", hip_loss, hip, sd, batch, dec, "stage1", "resnet50", factor=FULL_STEP_FACTOR)
+
+
+def _dropblock_case(dev, rate, bs, B=2, S=1, Q=1, H=97):
+    """-> ({layer: draws on the device, engine image order}, oracle DropBlock with the same draws in its image order)."""
+    from oracle import ref_cpu
+    nimg, perm = B * (S + Q), _perm(B, S, Q)
+    h = w = (H - 1) // 8 + 1
+    layers = {"encoder.purifier.2": (h, w), "encoder.purifier.5": (h, w), "encoder.purifier.6.aspp_0.1": (1, 1)}
+    layers.update({f"encoder.purifier.6.aspp_{i}.1": (h, w) for i in range(1, 5)})
+    gen = torch.Generator().manual_seed(77)
+    draws = {k: torch.rand((nimg,) + hw, generator=gen) for k, hw in layers.items()}
+    # the 1 x 1 global branch drops a whole image with probability rate / block^2: make sure one such drop is in the case
+    draws["encoder.purifier.6.aspp_0.1"][1] = 0.0
+    assert all(bool((v < rate / bs ** 2).any()) for v in draws.values())         # every layer drew at least one seed
+    return {k: v.to(dev) for k, v in draws.items()}, ref_cpu.DropBlock(rate, bs, {k: v[perm] for k, v in draws.items()})
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.1])
+def test_stage1_encoder_gradients_under_a_linear_probe(hip_lib, dev, rate):
+    """The stage-1 ENCODER alone (ResNet-50 trunk, purifier, ASPPV2 with its five batch-statistics BNs and -- rate 0.1 -- the
+    seven DropBlock layers): the prototype head, whose float32 conditioning sets the ~1e-4 floor of the full-step tests
+    below, is replaced on both sides by the linear functional sum(features * R), so the gradient entering the encoder's
+    backward pass is R exactly.  Bound: factor 3 on the oracle's float32 error, capped at 5e-5."""
+    from pemp_amd.networks import pemp_stage1 as m
+    from pemp_amd.train_engine import Stage1Trainer
+    sd = util.wgen_state_dict("stage1_rn50")
+    net = m.ModelClass(None)
+    net.load_state_dict(sd)
+    tr = Stage1Trainer(net, device=dev, drop_rate=rate, block_size=4)
+    db = None
+    if rate > 0:
+        tr.eng.draws, db = _dropblock_case(dev, rate, 4)
+    batch = _batch(dev)
+    hip_loss, hip, dec, R = _run(tr, net, batch, "stage1", "resnet50", tail=True, probe=True)
+    rows = _compare(f"stage1_rn50 encoder, probe, drop_rate {rate}", hip_loss, hip, sd, batch, dec, "stage1", "resnet50",
+                    dropblock=db, probe=R, loss_rtol=None)      # the probe's value is a sum of 3.5e5 signed terms: no test
+    assert rows[0][0] <= 5e-5
+    assert db is None or len(db.used) == 7
+
+
+def test_stage1_rn50_gradients_with_dropblock_active(hip_lib, dev):
+    """The full step with the regulariser ON (the shipped configuration: drop_rate 0.1, block_size 4): the seven DropBlock2D
+    layers of the purifier / ASPPV2 get the SAME uniform draws on both sides -- the engine through ``eng.draws``, the oracle
+    through its restatement of dropblock==0.3.0 (oracle/ref_cpu.py: DropBlock) -- so the block masks, their
+    numel / sum normalisation over all images of the step, and their place in the backward pass are all inside the comparison
+    (image order differs between the two sides, the draws are permuted with it)."""
+    from pemp_amd.networks import pemp_stage1 as m
+    from pemp_amd.train_engine import Stage1Trainer
+    sd = util.wgen_state_dict("stage1_rn50")
+    net = m.ModelClass(None)
+    net.load_state_dict(sd)
+    rate, bs = 0.1, 4
+    tr = Stage1Trainer(net, device=dev, drop_rate=rate, block_size=bs)
+    tr.eng.draws, db = _dropblock_case(dev, rate, bs)
+    batch = _batch(dev)
+    hip_loss, hip, dec = _run(tr, net, batch, "stage1", "resnet50", tail=True)
+    _compare("stage1_rn50 + DropBlock", hip_loss, hip, sd, batch, dec, "stage1", "resnet50", dropblock=db, factor=FULL_STEP_FACTOR)
+    assert len(db.used) == 7
+    # and the draws mattered: the loss differs from the regulariser-free step of the same batch
+    tr0 = Stage1Trainer(net, device=dev, drop_rate=0.0)
+    loss0, _ = tr0.forward_backward(*batch)
+    assert abs(float(loss0.item()) - hip_loss) > 1e-4
 
 
 @pytest.mark.parametrize("backbone,tag", [("vgg16", "baseline_vgg16"), ("resnet50", "baseline_rn50")])

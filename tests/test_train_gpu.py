@@ -210,6 +210,44 @@ def test_stage2_train_step_matches_reference(hip_lib, dev, fixture):
         assert torch.allclose(sd[name].cpu().to(ref.dtype), ref, rtol=1e-4, atol=1e-5), name
 
 
+def test_stage2_train_step_with_dropout2d_active_matches_oracle(hip_lib, dev):
+    """Stage 2 with its regulariser ON (Dropout2d(0.5) after both purifier convs and after every ASPP branch): the seven layers
+    get the SAME uniform draws on both sides -- the engine through ``eng.draws``, the oracle through its restatement of
+    ATen's feature dropout (oracle/ref_cpu.py: Dropout2d) -- and the loss (2e-5) and every gradient (the fp64-relative bound
+    of the other train-step tests, with the oracle's own float32 evaluation as ref32) must agree.  The engine draws the four
+    spatial branches' masks in one [N, 4 * 256] call; the draws are given per reference layer."""
+    from oracle import ref_cpu
+    from tests.golden.cases import stage2_train_prior
+    from pemp_amd import synth
+    p, seeds, H = 0.5, [31, 32], 97
+    tr, net = _stage2_trainer(dev, drop_rate2=p)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    sup, msk, qry, gt = _batch(dev, seeds, H)
+    b = synth.make_batch(seeds, shot=1, height=H, width=H, out_hw=(H, H))
+    prior = torch.from_numpy(stage2_train_prior(b["qry_mask"]))
+    B, S, Q = 2, 1, 1
+    perm = torch.tensor([x for e in range(B) for x in ([e * S + s for s in range(S)] + [B * S + e * Q + q for q in range(Q)])])
+    layers = ["encoder.purifier.2", "encoder.purifier.5"] + [f"encoder.purifier.6.aspp_{i}.2" for i in range(5)]
+    gen = torch.Generator().manual_seed(78)
+    draws = {k: torch.rand((B * (S + Q), 256), generator=gen) for k in layers}
+    tr.eng.draws = {k: v.to(dev) for k, v in draws.items()}
+    loss, _ = tr.forward_backward(sup, msk, qry, gt, prior.to(dev))
+    torch.cuda.synchronize()
+    hip = {k: v.grad.detach().cpu().clone() for k, v in net.named_parameters() if v.requires_grad and v.grad is not None}
+    ins = (sup.cpu(), msk.cpu(), qry.cpu(), gt.cpu())
+    out = {}
+    for dt in (torch.float32, torch.float64):
+        do = ref_cpu.Dropout2d(p, {k: v[perm] for k, v in draws.items()})
+        out[dt] = ref_cpu.step_gradients(sd, *ins, model="stage2", qry_prior=prior, dtype=dt, dropout2d=do)
+        assert do.used == set(layers)
+    assert abs(loss.item() - out[torch.float32][0]) < 2e-5 and abs(loss.item() - out[torch.float64][0]) < 2e-5
+    util.check_gradients_live(hip, out[torch.float32][1], out[torch.float64][1], "stage2 + Dropout2d")
+    # the draws mattered
+    tr0, _ = _stage2_trainer(dev, drop_rate2=0.0)
+    loss0, _ = tr0.forward_backward(sup, msk, qry, gt, prior.to(dev))
+    assert abs(loss0.item() - loss.item()) > 1e-4
+
+
 def test_stage2_train_steps_with_stage1_prior_and_dropout(hip_lib, dev):
     """Whole train_step: frozen stage-1 prior on the HIP eval path, Dropout2d active, SGD without clipping."""
     from pemp_amd.networks import pemp_stage1 as m1, pemp_stage2 as m2
