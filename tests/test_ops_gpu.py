@@ -230,6 +230,38 @@ def test_mpm_and_cosine(hip_lib, dev, B, S, p, c, h, w, H, W):
         util.assert_response_exact(resp, resp_ref, margin, margin=1e-4, max_masked=0.1 if h * w > 100 else 1.0, what=f"mpm {B}x{S} c{c} {h}x{w}")
 
 
+@pytest.mark.parametrize("c,p", [(512, 3), (320, 3), (512, 5)])       # MFMA row stream / wave-per-pixel / MAXJ = 16
+def test_soft_assignment_is_closer_to_float64_than_the_float32_formulation(hip_lib, dev, c, p):
+    """The MPM assignment at the magnitudes trained features have (|x - c|^2 in the hundreds).  The reference's
+    softmax(-sum (x - c)^2) in float32 carries the rounding of those sums (~1e-4 relative in the weights); the kernels
+    evaluate the same softmax in its shift-invariant form (csrc/head_common.h) and must sit well inside that."""
+    from pemp_amd import ops
+    B, S, h, w = 1, 2, 13, 13
+    n, J = h * w, 2 * p
+    feat = _rand(B * S, h, w, c, seed=1, lo=-2.0, hi=2.0)
+    ctr = _rand(c, J, seed=2, lo=-1.0, hi=1.0)
+    m = (_rand(B * S, 1, h, w, seed=3) > 0.0).float()
+    mask = torch.cat((m, 1 - m), dim=1)                                   # masks at feature resolution
+    ws = {}
+    ops.mpm_protos(feat.to(dev), mask.to(dev), ctr.to(dev), B, S, p, ws_cache=ws)
+    A = ws[("mpm", B, S, h, w, c, p)][:B * S * J * n * 4].view(torch.float32).view(B * S, J, n).cpu().double()
+
+    def assign(dt):
+        x = feat.to(dt).reshape(B * S, n, c)
+        D = -((x[:, :, None, :] - ctr.to(dt).t()[None, None]) ** 2).sum(-1)           # [BS, n, J]
+        assert D.abs().mean() > 300
+        P = torch.softmax(D.view(B * S, n, 2, p), dim=3).view(B * S, n, J).transpose(1, 2)
+        return P * mask.to(dt).view(B * S, 2, 1, n).expand(-1, -1, p, -1).reshape(B * S, J, n)
+
+    a64, a32 = assign(torch.float64), assign(torch.float32).double()
+    big = a64 > 1e-3
+    e_hip = ((A - a64).abs() / a64.clamp_min(1e-30))[big].max().item()
+    e_ref = ((a32 - a64).abs() / a64.clamp_min(1e-30))[big].max().item()
+    print(f"soft assignment c={c} p={p}: max relative error vs float64  hip {e_hip:.2e}   float32 reference form {e_ref:.2e}")
+    assert e_hip < 5e-5 and e_hip < 0.5 * e_ref, (e_hip, e_ref)
+    assert (A[a64 == 0] == 0).all()                                                     # masked-out pixels stay exactly zero
+
+
 def test_masked_avg_pool_lowres_and_fullres(hip_lib, dev):
     from pemp_amd import ops
     B, S, c, h, w, H, W = 2, 2, 256, 7, 9, 50, 65
