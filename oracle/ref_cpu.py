@@ -212,7 +212,7 @@ def _comm(x, mask, sd, lin, stride, spq):
     mask = F.max_pool2d(mask, 3, stride, 1)
     masked = (x * mask).view(x.shape[0], x.shape[1], -1)
     mean = masked.mean(dim=-1).view(x.shape[0] // spq, spq, -1).mean(dim=1)
-    mx = masked.max(dim=-1)[0].view(x.shape[0] // spq, spq, -1).mean(dim=1)
+    mx = _group_max(masked, -1, lin + ".max")[0].view(x.shape[0] // spq, spq, -1).mean(dim=1)
     feat = F.linear(torch.cat([mean, mx], dim=1), sd[lin + ".weight"], sd[lin + ".bias"])
     feat = feat[:, None, :, None, None].expand(-1, spq, -1, *x.shape[-2:])
     return feat.reshape(x.shape[0], -1, *x.shape[-2:]), mask
@@ -247,11 +247,12 @@ def aspp_v2(x, sd, p):
 
 def aspp(x, sd, p):
     """ASPP.forward, conv -> ReLU -> (Dropout2d) per branch (backbones.py:279-321)."""
-    g = _dropout2d(F.relu(_conv(F.adaptive_avg_pool2d(x, (1, 1)), sd, p + ".aspp_0.0")), p + ".aspp_0.2")
+    g = _dropout2d(_relu(_conv(F.adaptive_avg_pool2d(x, (1, 1)), sd, p + ".aspp_0.0"), p + ".aspp_0.relu"), p + ".aspp_0.2")
     outs = [g.expand(-1, -1, *x.shape[-2:])]
     for i in range(1, 5):
         d = _ASPP_DIL[i]
-        outs.append(_dropout2d(F.relu(_conv(x, sd, f"{p}.aspp_{i}.0", padding=d, dilation=max(d, 1))), f"{p}.aspp_{i}.2"))
+        outs.append(_dropout2d(_relu(_conv(x, sd, f"{p}.aspp_{i}.0", padding=d, dilation=max(d, 1)), f"{p}.aspp_{i}.relu"),
+                               f"{p}.aspp_{i}.2"))
     return _conv(torch.cat(outs, 1), sd, p + ".layer6")
 
 
@@ -451,19 +452,26 @@ def panet_forward(sd, sup_img, sup_mask, qry_img, out_shape=None, backbone="vgg1
     return out, panet_align_loss(qry_fts, pred, sup_fts, mfg, Q, dist_scalar)
 
 
-def stage2_forward(sd, sup_img, sup_mask, qry_img, qry_prior, out_shape=None, ret_ind=False,
-                   protos2=3, dist_scalar=20, ret_lowres=False, backbone2="resnet50"):
-    """PEMPStage2.forward (networks/pemp_stage2.py:104-162): ResNet-50+CM with the purifier, or VGG16CM (no purifier)."""
+def encoder_stage2(sd, sup_img, sup_mask, qry_img, qry_prior, backbone2="resnet50"):
+    """The encoder call of PEMPStage2.forward (networks/pemp_stage2.py:127-140): images with the prior as 4th channel
+    (support: its foreground mask, query: the stage-1 prediction) -> features [B*(S+Q),c,h,w], episode-major."""
     B, S, ch, H, W = sup_img.shape
     Q = qry_img.shape[1]
     img = torch.cat((sup_img, qry_img), dim=1).view(B * (S + Q), ch, H, W)
     prior = torch.cat((sup_mask[:, :, :1], qry_prior.view(B, Q, *qry_prior.shape[-3:]).float()), dim=1)
     prior = prior.view(B * (S + Q), 1, H, W)
     if backbone2 == "vgg16":
-        f = vgg16_cm(torch.cat((img, prior), dim=1), prior, sd, "encoder.backbone", S + Q)
-    else:
-        f = resnet_cm(torch.cat((img, prior), dim=1), prior, sd, "encoder.backbone", S + Q)
-        f = purifier(f, sd, "encoder.purifier", v2=False)
+        return vgg16_cm(torch.cat((img, prior), dim=1), prior, sd, "encoder.backbone", S + Q)
+    f = resnet_cm(torch.cat((img, prior), dim=1), prior, sd, "encoder.backbone", S + Q)
+    return purifier(f, sd, "encoder.purifier", v2=False)
+
+
+def stage2_forward(sd, sup_img, sup_mask, qry_img, qry_prior, out_shape=None, ret_ind=False,
+                   protos2=3, dist_scalar=20, ret_lowres=False, backbone2="resnet50"):
+    """PEMPStage2.forward (networks/pemp_stage2.py:104-162): ResNet-50+CM with the purifier, or VGG16CM (no purifier)."""
+    B, S, ch, H, W = sup_img.shape
+    Q = qry_img.shape[1]
+    f = encoder_stage2(sd, sup_img, sup_mask, qry_img, qry_prior, backbone2)
     _, c, h, w = f.shape
     f = f.view(B, S + Q, c, h, w)
     m = F.interpolate(sup_mask.view(B * S, 2, H, W), (h, w), mode="nearest")
@@ -593,7 +601,7 @@ def step_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", back
     """Loss and d loss / d parameter of ONE train-mode forward (batch-statistics BatchNorm, CE) evaluated in ``dtype`` under
     autograd; ``sd`` is not modified (no update, running statistics untouched).  ``decisions``: see Switches (None: plain
     ReLU / max); ``dropblock`` / ``dropout2d``: the regularisers with given draws (None: identities).
-    ``probe`` (stage1 / baseline): a tensor R shaped like the encoder's output [B*(S+Q),c,h,w]; the head and the CE are
+    ``probe``: a tensor R shaped like the encoder's output [B*(S+Q),c,h,w]; the head and the CE are
     replaced by the linear functional  loss = sum(encoder(images) * R), i.e. d loss / d features = R exactly -- the
     encoder's backward pass alone, without the conditioning of the prototype head.
     -> (loss float, {name: gradient}, decision tags used)."""
@@ -608,10 +616,11 @@ def step_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", back
         H, W = qry_msk.shape[-2:]
         ins = (sup_img.to(dtype), sup_mask.to(dtype), qry_img.to(dtype))
         if probe is not None:
-            if model not in ("stage1", "baseline"):
-                raise ValueError("probe: stage1 / baseline encoders only")
-            x = torch.cat((ins[0], ins[2]), dim=1).flatten(0, 1)              # the image order of *_forward
-            f = encoder_stage1(x, w, backbone) if model == "stage1" else encoder_baseline(x, w, backbone)
+            if model == "stage2":
+                f = encoder_stage2(w, *ins, qry_prior.to(dtype), backbone)
+            else:
+                x = torch.cat((ins[0], ins[2]), dim=1).flatten(0, 1)          # the image order of *_forward
+                f = encoder_stage1(x, w, backbone) if model == "stage1" else encoder_baseline(x, w, backbone)
             loss = (f * probe.to(dtype)).sum()
         else:
             if model == "stage1":
@@ -632,11 +641,11 @@ def step_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", back
 
 
 def frozen_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, decisions, model="stage1", backbone="resnet50",
-                     dtype=torch.float64, dropblock=None, probe=None):
+                     dtype=torch.float64, dropblock=None, probe=None, qry_prior=None, dropout2d=None):
     """Loss and d loss / d parameter of ONE train-mode forward (batch-statistics BatchNorm, regularisers off, CE) in which
     every discrete decision -- ReLU sign, max-pool winner, winning prototype -- is TAKEN from ``decisions`` (see Switches),
     evaluated in ``dtype`` under autograd.  ``dropblock`` = DropBlock(...) applies the stage-1 DropBlock layers with the
     given draws (their masks depend on the draws only, so they are part of the frozen function).  ``sd`` is not modified.
     -> (loss float, {name: gradient}, tags used)."""
     return step_gradients(sd, sup_img, sup_mask, qry_img, qry_msk, model=model, backbone=backbone, dtype=dtype,
-                          decisions=decisions, dropblock=dropblock, probe=probe)
+                          decisions=decisions, dropblock=dropblock, probe=probe, qry_prior=qry_prior, dropout2d=dropout2d)
