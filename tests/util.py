@@ -55,7 +55,9 @@ def counts(pred, ref):
 # prototype head on torch ops (GPU), differentiated by autograd -- reference networks/pemp_stage1.py:142-163,195-261
 # (cross-check of the HIP head kernels; test infrastructure)
 # ---------------------------------------------------------------------------------------------
-def head_loss(feat_nhwc, sup_mask, qry_mask, ctr, B, S, Q, protos, dist_scalar, out_shape, weight=None):
+def head_loss(feat_nhwc, sup_mask, qry_mask, ctr, B, S, Q, protos, dist_scalar, out_shape, weight=None, win=None):
+    """``win`` (int64 [B*Q,2,h,w], channel 0 = background): take these prototypes instead of the group maxima (a frozen
+    decision, see test_grad_frozen_gpu.py)."""
     n, h, w, c = feat_nhwc.shape
     f = feat_nhwc.permute(0, 3, 1, 2)
     sup = f[:B * S].reshape(B, S, c, h * w).reshape(B * S, c, h * w)
@@ -73,7 +75,8 @@ def head_loss(feat_nhwc, sup_mask, qry_mask, ctr, B, S, Q, protos, dist_scalar, 
         fgp, bgp = new.view(B, c, protos, 2).unbind(dim=3)
         fgd = F.cosine_similarity(qry, fgp[..., None, None], dim=1) * dist_scalar
         bgd = F.cosine_similarity(qry, bgp[..., None, None], dim=1) * dist_scalar
-        pred = torch.stack((bgd, fgd), dim=1).max(dim=2).values
+        st = torch.stack((bgd, fgd), dim=1)
+        pred = st.max(dim=2).values if win is None else st.gather(2, win.unsqueeze(2)).squeeze(2)
     else:
         fgv = (sup * fg).sum(-1) / (fg.sum(-1) + 1e-5)
         bgv = (sup * bg).sum(-1) / (bg.sum(-1) + 1e-5)
