@@ -19,6 +19,12 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                   events on the stream each kernel is launched on (an instrumented pass over the C ABI, eager, same
                   workload); ``by_class`` splits the step over conv / weight-gradient / BatchNorm / head / optimizer
   single_episode  (eval, N = 1) the reference's own protocol, one episode per test_step (data_kits/datasets.py:23)
+  comm            what the ranks exchanged inside the timed region and how evenly they ran: backend, world, RCCL version,
+                  bytes all-reduced, the gradient buckets with their element ranges (train), exposed communication time,
+                  every rank's own ms_per_step; eval: the round's metric table is all-reduced INSIDE the timed region and
+                  checked against the sum of the rank shards (``miou`` is printed from the reduced table)
+  cedt            (default line) the eval step and the train step with loss=cedt (CELossDT on the device), next to loss=ce
+  protocol_5x1000 (default line) the reference's evaluation protocol: 5 rounds x 1000 episodes, one episode per test_step
   cpu_baseline    the CPU oracle (oracle/ref_cpu.py, bit-equal to the reference here) timed on the host cores in child
                   processes: 1 thread and all cores of the box's share, bounded samples of the same workload
 """
@@ -55,6 +61,9 @@ def parse():
                     help="eval (headline metric, BASELINE.json configs[1]) or train (configs[2])")
     ap.add_argument("--dataset", choices=("PASCAL", "COCO"), default="PASCAL",
                     help="COCO: BASELINE.json configs[4] -- COCO-20i label set and picture formats (ground truth up to 640x640)")
+    ap.add_argument("--loss", choices=("ce", "cedt"), default="ce",
+                    help="cedt: CELossDT (core/losses.py:17-43; what the reference's scripts train with) -- boundary + exact "
+                         "distance transform + weighted CE on the device, inside the timed region")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-episodes", type=int, default=12, help="bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--train-graph", action="store_true", help="--mode train: replay forward/backward from a hipGraph")
@@ -78,6 +87,117 @@ def beat():
             os.utime(path, None)
 
 
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def host_threads_per_rank(local_world):
+    """Host threads one of ``local_world`` ranks on this host may use: cores / ranks (PEMP_BENCH_THREADS overrides)."""
+    return max(1, int(os.environ.get("PEMP_BENCH_THREADS", host_cores() // max(1, local_world))))
+
+
+# ---------------------------------------------------------------------------------------------
+# what the ranks exchanged, and how evenly they ran (the `comm` object of every line)
+# ---------------------------------------------------------------------------------------------
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def gather_rank_ms(local_dt, steps, world, dev):
+    """Every rank's OWN elapsed time of the timed region (the headline uses the MAX), as ms per step, rank order."""
+    if world == 1:
+        return [local_dt / steps * 1e3]
+    mine = torch.tensor([local_dt], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) / steps * 1e3 for t in out]
+
+
+def comm_object(world, rank_ms, **fields):
+    backend = dist.get_backend() if world > 1 and dist.is_initialized() else None
+    out = {"backend": backend, "world": world, "rccl_version": rccl_version() if backend == "nccl" else None,
+           "host_threads_per_rank": torch.get_num_threads()}
+    out.update(fields)
+    out["rank_ms_per_step"] = {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4), "all": [round(v, 4) for v in rank_ms]}
+    return out
+
+
+class RoundReduce:
+    """The evaluation round's aggregation INSIDE the timed region (reference core/base_trainer.py:70-100: the metric table
+    of the round's episodes, mIoU per round): statistics rows -> [C+1, 3] table by class on the device, ONE all-reduce(SUM)
+    of table + loss sum + episode count (``DeviceRoundTable``), bracketed by events.  ``verify`` (after the timed region)
+    gathers every rank's own shard and checks that the reduced table is exactly their sum."""
+
+    def __init__(self, nclass, dev, dataset="PASCAL"):
+        from pemp_amd.entry.pemp_stage1 import DeviceRoundTable
+        self.table, self.dev, self.dataset, self.nclass = DeviceRoundTable(nclass, dev), dev, dataset, nclass
+        self.local, self.nbytes, self.events = None, 0, None
+
+    def reduce(self, stats, classes):
+        self.table.reset()
+        self.table.add(stats, classes)
+        self.local = self.table.pack.clone()
+        if self.dev.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.nbytes = self.table.allreduce()
+            e1.record()
+            self.events = (e0, e1)
+        else:
+            t0 = time.perf_counter()
+            self.nbytes = self.table.allreduce()
+            self.events = (time.perf_counter() - t0) * 1e3
+
+    def allreduce_ms(self):
+        if isinstance(self.events, tuple):
+            self.events[1].synchronize()
+            return self.events[0].elapsed_time(self.events[1])
+        return self.events
+
+    def verify(self, world):
+        """-> (reduced table == sum of the rank shards [exact: integer-valued doubles], miou object) -- a collective: every
+        rank calls it."""
+        from pemp_amd import synth
+        from pemp_amd.core.metrics import FewShotMetric
+        shards = [self.local]
+        if world > 1:
+            shards = [torch.zeros_like(self.local) for _ in range(world)]
+            dist.all_gather(shards, self.local)
+        total = torch.stack(shards).sum(dim=0)
+        same = bool(torch.equal(total[:-2], self.table.pack[:-2])) and float(total[-1]) == float(self.table.pack[-1])
+        stat, loss_sum, count = self.table.fetch()
+        m = FewShotMetric(self.nclass)
+        m.stat = stat
+        seen = [c for c in synth.val_labels(0, self.dataset) if stat[c].sum() > 0]
+        miou = {"miou": round(float(m.mIoU(seen)[1]), 6) if seen else None,
+                "biou": round(float(m.mIoU(seen, binary=True)[1]), 6) if seen else None,
+                "episodes": int(count), "classes": len(seen), "mean_ce_loss": round(loss_sum / max(count, 1.0), 6),
+                "episodes_per_rank": [int(t[-1].item()) for t in shards],
+                "source": "the round's tp/fp/fn table, all-reduced inside the timed region (synthetic episodes: the value says "
+                          "nothing about PASCAL accuracy)"}
+        return same, miou
+
+
+def sync_replicas(tr):
+    """Rank 0's parameters and buffers on every rank (after the rank-local tuning pass moved BatchNorm running statistics)."""
+    flat = tr.eng.flat
+    dist.broadcast(flat.data, 0)
+    model = getattr(tr, "model", None)
+    if model is not None:
+        for b in model.buffers():
+            dist.broadcast(b.data, 0)
+        for q in model.parameters():
+            if not q.requires_grad:
+                dist.broadcast(q.data, 0)
+
+
 def launch_ranks(n):
     """Start ``n`` copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
     as torchrun would), wait for them and return the exit code: 0 only if every rank exited 0.  Runs BEFORE this
@@ -96,12 +216,14 @@ def launch_ranks(n):
     silence = float(os.environ.get("PEMP_BENCH_SILENCE_S", "300"))
     hbdir = tempfile.mkdtemp(prefix="pemp_bench_hb_")
     procs, beats = [], []
-    for r in range(n):
+    threads = str(host_threads_per_rank(n))       # N ranks share the host: numpy / torch-CPU episode synthesis and the eager
+    for r in range(n):                            # enqueue loop of every rank run with cores / N threads, not with all of them
         hb = os.path.join(hbdir, f"rank{r}")
         open(hb, "w").close()
         beats.append(hb)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PEMP_BENCH_CHILD="1", PEMP_BENCH_HEARTBEAT=hb)
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PEMP_BENCH_CHILD="1", PEMP_BENCH_HEARTBEAT=hb,
+                   OMP_NUM_THREADS=threads, MKL_NUM_THREADS=threads)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -147,40 +269,71 @@ def launch_ranks(n):
     return rc
 
 
+def dry_rows(n, rank, nclass=20):
+    """Statistics rows [n, 8] (integer tp/fp/fn counts, a loss sum, a pixel count) and classes of rank ``rank``'s episodes of a
+    dry run: what pemp_eval_tail would have left on the device."""
+    rng = np.random.RandomState(777 + rank)
+    st = np.zeros((n, 8))
+    st[:, 2:] = rng.randint(0, 50000, (n, 6))
+    st[:, 1] = 401 * 401
+    st[:, 0] = rng.rand(n) * st[:, 1]
+    return torch.from_numpy(st), torch.from_numpy(rng.randint(1, 6, n).astype(np.int64))
+
+
 def dry_run(args, world, rank):
-    """PEMP_BENCH_DRYRUN=1 (tests, CPU): the control flow of an N-rank run -- rendezvous, barriers, K timed steps,
-    MAX over ranks, ONE line on rank 0 -- with a sleep in place of the GPU step.  PEMP_BENCH_FAIL_RANK=r makes rank r
-    exit non-zero before the first barrier (the launcher must then fail the whole job)."""
+    """PEMP_BENCH_DRYRUN=1 (tests, CPU): the control flow of an N-rank run -- rendezvous, barriers, K timed steps, the eval
+    round's metric all-reduce inside the timed region, MAX over ranks, the `comm` object, process group gone before rank 0's
+    extras, ONE line on rank 0 -- with a sleep in place of the GPU step.  PEMP_BENCH_FAIL_RANK=r makes rank r exit non-zero
+    before the first barrier (the launcher must then fail the whole job)."""
     if os.environ.get("PEMP_BENCH_FAIL_RANK") == str(rank):
         raise SystemExit(3)
     beat()
     if os.environ.get("PEMP_BENCH_HANG_RANK") == str(rank):       # a rank that never reaches the collective the others wait in
         time.sleep(3600)
+    dev = torch.device("cpu")
     if world > 1:
         dist.init_process_group(os.environ.get("PEMP_BENCH_BACKEND", "gloo"))
         dist.barrier()
     for _ in range(args.warmup):
         time.sleep(0.001)
+    rr = RoundReduce(20, dev) if args.mode == "eval" else None
+    rows, classes = dry_rows(args.steps * args.batch, rank)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.002 * (1 + rank))
+    local_dt = time.perf_counter() - t0           # this rank's own steps, before the round's collective couples the ranks
+    if rr is not None:
+        rr.reduce(rows, classes)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    extra = {}
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    rank_ms = gather_rank_ms(local_dt, args.steps, world, dev)
+    if rr is not None:
+        same, miou = rr.verify(world)
+        extra["miou"] = miou
+        comm = comm_object(world, rank_ms, collectives_in_timed_region=1 if world > 1 else 0, allreduce_bytes_per_round=rr.nbytes,
+                           allreduce_ms=round(rr.allreduce_ms(), 4), table_equals_sum_of_rank_shards=same)
+    else:
+        comm = comm_object(world, rank_ms)
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "episodes/sec (dry run: no GPU work)", "value": round(args.steps * args.batch * world / dt, 2),
-                          "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
-                          "config": {"workload": "dry run", "mode": args.mode}}))
+        out = {"metric": "episodes/sec (dry run: no GPU work)", "value": round(args.steps * args.batch * world / dt, 2),
+               "unit": "episodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+               "config": {"workload": "dry run", "mode": args.mode}, "comm": comm,
+               "process_group_alive_at_print": bool(dist.is_initialized())}
+        out.update(extra)
+        print(json.dumps(out))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -218,7 +371,7 @@ def episode_pool(dev, shot, batch, rank, n_groups=5, dataset="PASCAL"):
         pool.append(dict(
             sup_img=torch.from_numpy(b["sup_img"]).to(dev), sup_mask=torch.from_numpy(b["sup_mask"]).to(dev),
             qry_img=torch.from_numpy(b["qry_img"]).to(dev), qry_mask=torch.from_numpy(b["qry_mask"][:, 0]).to(dev),
-            seeds=seeds, hw=hw))
+            cls=torch.from_numpy(np.asarray(b["cls"], np.int64)).to(dev), seeds=seeds, hw=hw))
     return pool
 
 
@@ -349,21 +502,48 @@ def summarize(rec, reps, step_ms=None):
     return roof
 
 
+PROFILE_ROUNDS = ("r04", "r03")      # committed PMC summaries are looked up newest round first
+
+
 def attach_pmc(roof, workload_key):
     """HBM bytes and MFMA-pipe utilisation come from rocprofv3 --pmc passes (they cannot be collected in-process).  A
     committed profile is quoted ONLY when it was taken on exactly this conv-engine source (build.conv_digest) and workload."""
     from pemp_amd import build
     digest = build.conv_digest()
-    for fname, field, key in (("r03_conv_traffic.json", "traffic", "hbm_bytes_per_launch"),
-                              ("r03_mfma_util.json", "mfma_util_pmc_pct", "conv_mfma_util_pct_time_weighted")):
-        path = os.path.join(ROOT, "profiles", fname)
+    for stem, field, key in (("conv_traffic.json", "traffic", "hbm_bytes_per_launch"),
+                             ("mfma_util.json", "mfma_util_pmc_pct", "conv_mfma_util_pct_time_weighted")):
+        for rnd in PROFILE_ROUNDS:
+            fname = f"{rnd}_{stem}"
+            path = os.path.join(ROOT, "profiles", fname)
+            if not os.path.exists(path):
+                continue
+            with open(path) as f:
+                rec = json.load(f)
+            if rec.get("conv_digest") == digest and rec.get("workload_key") == workload_key:
+                roof[field] = rec.get(key)
+                roof.setdefault("pmc_source", []).append(f"profiles/{fname} (rocprofv3 --pmc, replayed: same conv-engine source {digest})")
+                break
+    return roof
+
+
+def attach_train_pmc(roof, args):
+    """The training step's HBM traffic per implicit-GEMM launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    `bench.py --mode train`, scratch/pmc_train_traffic.py), quoted only next to the kernel sources it was measured on."""
+    from pemp_amd import build
+    if args.model != "stage1" or args.batch != 4 or args.shot != 1 or not isinstance(roof, dict) or "error" in roof:
+        return roof
+    digest = build.csrc_digest()
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_train_traffic.json")
         if not os.path.exists(path):
             continue
         with open(path) as f:
             rec = json.load(f)
-        if rec.get("conv_digest") == digest and rec.get("workload_key") == workload_key:
-            roof[field] = rec.get(key)
-            roof.setdefault("pmc_source", []).append(f"profiles/{fname} (rocprofv3 --pmc, replayed: same conv-engine source {digest})")
+        if rec.get("csrc_digest") == digest and rec.get("gemm_hbm_bytes_per_launch"):
+            roof["traffic"] = rec["gemm_hbm_bytes_per_launch"]
+            roof["hbm_GB_per_step_total"] = rec.get("hbm_GB_per_step_total")
+            roof.setdefault("pmc_source", []).append(f"profiles/{rnd}_train_traffic.json (rocprofv3 --pmc, same kernel sources {digest})")
+            break
     return roof
 
 
@@ -561,15 +741,17 @@ def end_to_end(net, args, dev):
 def single_episode(net, dev, args, n=120):
     """The reference's own protocol: ONE episode per test_step (data_kits/datasets.py:23 test_bs = 1,
     entry/pemp_stage1.py:47-53), no host synchronisation per episode (statistics are fetched once per round).
-    Results are bit-identical to the batched step (every image's rows are independent in the conv GEMMs).
-    ``in_flight`` > 1: episodes issued round-robin over that many engine replicas on their own streams."""
+    ``value``: with the opt-in split-K conv variants for the 5202-row layers (Evaluator(splitk=True): equal to the batched
+    step to rounding); ``exact``: the default, bit-identical variants (a one-episode step equals the batched step bit for
+    bit).  ``in_flight`` > 1: episodes issued round-robin over that many engine replicas on their own streams."""
     from pemp_amd.entry.pemp_stage1 import Evaluator
     pool = episode_pool(dev, args.shot, 1, 0, n_groups=5, dataset=args.dataset)
-    out = {}
-    for lanes in (1, int(os.environ.get("PEMP_EVAL_LANES", "4"))):
-        ev = Evaluator(net, device=dev, lanes=lanes)
-        eps = [((p["sup_img"], p["sup_mask"], p["qry_img"]), p["qry_mask"][None]) for p in pool]
-        rows = ev.test_steps_device([eps[i % len(eps)] for i in range(2 * len(eps) * lanes)])     # warm-up: graphs captured
+    eps = [((p["sup_img"], p["sup_mask"], p["qry_img"]), p["qry_mask"][None]) for p in pool]
+    lanes_n = int(os.environ.get("PEMP_EVAL_LANES", "4"))
+
+    def run(lanes, splitk):
+        ev = Evaluator(net, device=dev, lanes=lanes, splitk=splitk)
+        ev.test_steps_device([eps[i % len(eps)] for i in range(2 * len(eps) * lanes)])     # warm-up: graphs captured
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         rows = ev.test_steps_device([eps[i % len(eps)] for i in range(n)])
@@ -577,12 +759,18 @@ def single_episode(net, dev, args, n=120):
         dt = time.perf_counter() - t0
         st = rows.cpu().numpy()
         assert np.isfinite(st).all() and (st[:, 1] > 0).all()
-        key = "value" if lanes == 1 else f"value_{lanes}_in_flight"
-        out[key] = round(n / dt, 2)
-        out["ms_per_episode" if lanes == 1 else f"ms_per_episode_{lanes}_in_flight"] = round(dt / n * 1e3, 4)
+        return round(n / dt, 2), round(dt / n * 1e3, 4)
+
+    out = {}
+    out["value"], out["ms_per_episode"] = run(1, True)
+    out[f"value_{lanes_n}_in_flight"], out[f"ms_per_episode_{lanes_n}_in_flight"] = run(lanes_n, True)
+    ex1, exn = run(1, False), run(lanes_n, False)
+    out["exact"] = {"value": ex1[0], "ms_per_episode": ex1[1], f"value_{lanes_n}_in_flight": exn[0],
+                    "what": "the default conv variants (all bit-identical): one episode per step == the batched step bit for bit"}
+    out["conv_variants"] = "split-K allowed for layers of <= 12000 output rows (Evaluator(splitk=True) / PEMP_EVAL_SPLITK=1; opt-in)"
     # The reference's Evaluator.test_step body as written (entry/pemp_stage1.py:48-53): host tensors in, three .cuda()
     # copies, forward, loss.item() and argmax .cpu().numpy() out -- two host synchronisations per episode.
-    ev = Evaluator(net, device=dev)
+    ev = Evaluator(net, device=dev, splitk=True)
     host = [(tuple(x.cpu() for x in ins), msk.cpu()) for ins, msk in eps]
     for ins, msk in host:
         ev.test_step(ins, msk)
@@ -599,6 +787,93 @@ def single_episode(net, dev, args, n=120):
     out.update(unit="episodes/s", episodes_per_step=1,
                protocol="one episode per test_step (reference data.test_bs = 1), hipGraph replay, statistics fetched once per round")
     return out
+
+
+class ResidentEpisodes:
+    """``Evaluator.start_eval_loop``'s dataset protocol over episodes already resident in HBM: task ``i`` of round ``r`` is
+    episode ``(r * test_n + i) mod P`` of a pool of P distinct E(seed) episodes (generating 5000 distinct 401 x 401 episodes on
+    the host would take minutes; the device work per episode does not depend on which one it is).  Episodes of the five
+    query formats alternate, as in the reference's loader."""
+
+    def __init__(self, pool, test_n):
+        per = [[((g["sup_img"][b:b + 1], g["sup_mask"][b:b + 1], g["qry_img"][b:b + 1]), g["qry_mask"][b:b + 1][None], c)
+                for b, c in enumerate(g["cls"].tolist())] for g in pool]
+        self.eps = [grp[j] for j in range(max(len(g) for g in per)) for grp in per if j < len(grp)]
+        if test_n % len(self.eps) == 0 and len(self.eps) > 2:
+            self.eps = self.eps[:-2]               # rounds then differ in which episodes they hold
+        self.test_n, self.round = test_n, -1
+        self.shot, self.height, self.width = pool[0]["sup_img"].shape[1], *pool[0]["sup_img"].shape[-2:]
+
+    def reset_sampler(self):
+        self.round = -1
+
+    def sample_tasks(self):
+        self.round += 1
+
+    def __len__(self):
+        return self.test_n
+
+    def task(self, i):
+        ins, msk, c = self.eps[(self.round * self.test_n + i) % len(self.eps)]
+        return ins, msk, torch.tensor([c])
+
+
+def protocol_5x1000(net, pool, dev, args, rounds=5, test_n=1000, lanes=4):
+    """The reference's evaluation protocol (core/solver.py:47-50 te.epochs = 5, data_kits/datasets.py:23,27 test_bs = 1,
+    test_n = 1000; core/base_trainer.py:59-102): 5 rounds x 1000 episodes, one episode per test_step, mIoU per round, through
+    ``Evaluator.start_eval_loop`` -- the loop the ``test`` command runs -- with ``lanes`` steps in flight."""
+    from pemp_amd.entry.pemp_stage1 import Evaluator
+    nclass = 20 if args.dataset == "PASCAL" else 80
+    data = ResidentEpisodes(pool, test_n)
+    ev = Evaluator(net, device=dev, lanes=lanes, splitk=True)
+    warm = ResidentEpisodes(pool, 8 * lanes)
+    ev.start_eval_loop(warm, nclass, 0, te_epochs=1, batch=1, dataset_name=args.dataset)      # graphs of every lane / label size
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss, miou, biou = ev.start_eval_loop(data, nclass, 0, te_epochs=rounds, batch=1, dataset_name=args.dataset)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {"rounds": rounds, "episodes_per_round": test_n, "test_bs": 1, "in_flight": lanes,
+            "episodes_per_s": round(rounds * test_n / wall, 2), "wall_s": round(wall, 3),
+            "timer_cps": round(ev.cps, 2),
+            "miou_per_round": [round(float(np.nanmean(r)), 6) for r in ev.round_miou],
+            "biou_per_round": [round(float(np.nanmean(r)), 6) for r in ev.round_biou],
+            "miou": round(float(np.nanmean(miou)), 6), "biou": round(float(np.nanmean(biou)), 6), "mean_ce_loss": round(float(loss), 6),
+            "distinct_episodes": len(data.eps),
+            "what": "Evaluator.start_eval_loop: 5 rounds x 1000 single-episode test_steps (split-K conv variants allowed), per-round "
+                    "device-side metric table + one fetch; timer_cps = calls / time inside test_step (the reference's Timer), "
+                    "episodes_per_s = wall clock of the whole loop; episodes cycle through a resident pool of synthetic E(seed) "
+                    "episodes (the mIoU says nothing about PASCAL accuracy)"}
+
+
+def side_cedt_eval(run, dev, args, steps=10, warmup=3):
+    """The eval step with loss = cedt (CELossDT: boundary + exact distance transform + weighted CE on the device, all inside the
+    timed region; reference entry/pemp_stage1.py:51, core/losses.py:17-43) next to the same step with loss = ce, measured the
+    same way on the headline run's engine and episodes."""
+    res = {}
+    for kind in ("ce", "cedt"):
+        r = EvalRunner(dev, 0, "stage1", args.shot, args.batch, args.dataset, steps, loss=kind, net=run.net, pool=run.pool)
+        dt, ml, _ = r.timed(steps, warmup, 1, dev)
+        res[kind] = (dt / steps * 1e3, ml)
+    ms, ce_ms = res["cedt"][0], res["ce"][0]
+    return {"workload": "pemp_stage1 eval test_step with loss=cedt, %d episodes/step" % args.batch, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms, 4), "ce_ms_per_step": round(ce_ms, 4), "delta_ms_vs_ce": round(ms - ce_ms, 4),
+            "episodes_per_s": round(args.batch / ms * 1e3, 2), "mean_weighted_ce_loss": round(res["cedt"][1], 6),
+            "mean_ce_loss": round(res["ce"][1], 6)}
+
+
+def side_cedt_train(keep, dev, steps=10, warmup=3):
+    """The train step with loss = cedt (reference entry/pemp_stage1.py:60, scripts/pemp_stage1.sh:11) on the `train` object's
+    trainer and batches, next to its loss = ce figure."""
+    from pemp_amd.core import losses
+    tr, pool = keep["trainer"], keep["pool"]
+    tr.loss_obj = losses.get({"loss": "cedt", "sigma": 5.0})
+    dt, host_ms, ls, _, _ = timed_train_steps(tr, pool, steps, warmup, 1, dev)
+    ms = dt / steps * 1e3
+    B = pool[0][0].shape[0]
+    return {"workload": "pemp_stage1 train_step with loss=cedt, %d episodes/step" % B, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms, 3), "ce_ms_per_step": round(keep["step_ms"], 3), "delta_ms_vs_ce": round(ms - keep["step_ms"], 3),
+            "episodes_per_s": round(B / ms * 1e3, 2), "last_loss": round(float(ls[-1]), 5)}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -637,7 +912,7 @@ def stub_trainer(rank):
     return Stub()
 
 
-def make_trainer(model, shot, dev, rank, use_graph=False):
+def make_trainer(model, shot, dev, rank, use_graph=False, loss="ce"):
     if os.environ.get("PEMP_BENCH_STUB"):
         return stub_trainer(rank)
     from pemp_amd.train_engine import Stage1Trainer
@@ -645,9 +920,9 @@ def make_trainer(model, shot, dev, rank, use_graph=False):
     if model == "stage2":          # frozen stage-1 prior + stage-2 step (entry/pemp_stage2.py:72-83)
         from pemp_amd.train_stage2 import Stage2Trainer
         net2, _ = build_model(None, "stage2", shot)
-        return Stage2Trainer(net.to(dev).eval(), net2, device=dev, use_graph=use_graph)
+        return Stage2Trainer(net.to(dev).eval(), net2, device=dev, use_graph=use_graph, loss=loss)
     # eager by default: the weight-gradient kernels run on a side stream concurrently with the input-gradient chain
-    return Stage1Trainer(net, device=dev, use_graph=use_graph)
+    return Stage1Trainer(net, device=dev, use_graph=use_graph, loss=loss)
 
 
 def train_pool(dev, rank, shot, B, groups=3):
@@ -666,20 +941,24 @@ def device_sync(dev):
 
 
 def timed_train_steps(tr, pool, steps, warmup, world, dev):
-    """W untimed + K timed ``train_step`` calls between barriers -> (seconds [MAX over ranks], host ms per step, losses)."""
+    """W untimed + K timed ``train_step`` calls between barriers
+    -> (seconds [MAX over ranks], host ms per step, losses, this rank's own seconds, exposed communication ms per step)."""
     if world > 1:
-        # kernel variants are timed by rank 0 only and broadcast (pemp_amd.ops.tuned_by_rank0); that extra step is rank-local
-        # (no gradient collective: the ranks do not run it at the same time)
+        # kernel variants are timed by rank 0 only and broadcast (pemp_amd.ops.tuned_by_rank0).  That pass is rank-local (no
+        # gradient collective: the ranks do not run it at the same time) and has no optimizer step; what it does move --
+        # BatchNorm running statistics -- is brought back in line by broadcasting rank 0's replica afterwards, so that the
+        # timed run starts from identical replicas and is the data-parallel run of ONE model.
         from pemp_amd import ops
 
-        def local_step():
+        def local_pass():
             tr.collectives = False
             try:
-                tr.train_step(*pool[0])
+                tr.forward_backward(*pool[0])
                 device_sync(dev)
             finally:
                 tr.collectives = True
-        ops.tuned_by_rank0(local_step)
+        ops.tuned_by_rank0(local_pass)
+        sync_replicas(tr)
         beat()
     for i in range(warmup):
         tr.train_step(*pool[i % len(pool)])
@@ -691,6 +970,7 @@ def timed_train_steps(tr, pool, steps, warmup, world, dev):
         device_sync(dev)
 
     barrier()
+    tr.comm_log = []
     t0 = time.perf_counter()
     losses = []
     host = 0.0
@@ -698,6 +978,8 @@ def timed_train_steps(tr, pool, steps, warmup, world, dev):
         h0 = time.perf_counter()
         losses.append(tr.train_step(*pool[i % len(pool)]))
         host += time.perf_counter() - h0
+    device_sync(dev)
+    local_dt = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     beat()
@@ -705,9 +987,25 @@ def timed_train_steps(tr, pool, steps, warmup, world, dev):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    exposed = tr.exposed_comm_ms()
+    tr.comm_log = None
     ls = torch.stack(losses).cpu().numpy()
     assert np.isfinite(ls).all()
-    return dt, host / steps * 1e3, ls
+    return dt, host / steps * 1e3, ls, local_dt, exposed
+
+
+def train_comm(tr, world, rank_ms, exposed):
+    """The `comm` object of a training line: the gradient exchange of one step as the trainer issues it."""
+    flat = tr.eng.flat
+    buckets = [[int(lo), int(hi)] for lo, hi in tr.eng.buckets.buckets]
+    return comm_object(
+        world, rank_ms, collective="all_reduce(SUM) per gradient bucket, launched as the backward pass finishes the bucket "
+                                   "(GradBuckets), mean + clip + SGD fused behind the last one",
+        allreduce_bytes_per_step=int(flat.grad.numel() * flat.grad.element_size()) if world > 1 else 0,
+        gradient_elements=int(flat.grad.numel()), buckets=buckets,
+        bucket_bytes=[(hi - lo) * 4 for lo, hi in buckets], collectives_per_step=len(buckets) if world > 1 else 0,
+        exposed_comm_ms=None if exposed is None else round(exposed, 4),
+        exposed_comm_what="HIP events around reduce_gradients() on the step's stream: launch of the last bucket + wait for all")
 
 
 def train_roofline(tr, pool, step_ms, reps=2):
@@ -734,56 +1032,64 @@ def main_train(args, world, rank, dev):
     data.bs = 4), data-parallel: bucketed flat-gradient all-reduce over RCCL, overlapped with backward."""
     use_graph = args.train_graph
     s2 = args.model == "stage2"
-    tr = make_trainer(args.model, args.shot, dev, rank, use_graph)
+    tr = make_trainer(args.model, args.shot, dev, rank, use_graph, loss=args.loss)
     B = args.batch
     pool = train_pool(dev, rank, args.shot, B)
     beat()
-    dt, host_ms, ls = timed_train_steps(tr, pool, args.steps, args.warmup, world, dev)
-    out = None
-    if rank == 0:
-        step_ms = dt / args.steps * 1e3
-        out = {
-            "metric": "train episodes/sec (PEMP %s train_step, ResNet-50, %d-shot, 401x401)" % ("stage-2" if s2 else "stage-1", args.shot),
-            "value": round(args.steps * B * world / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("pemp_stage2 train_step (frozen stage-1 prior pass, batch-stat BN, CM, Dropout2d 0.5, CE, SGD), "
-                                    if s2 else "pemp_stage1 train_step (batch-stat BN, DropBlock 0.1, CE, clip 1.1, SGD), ") +
-                                   "ResNet-50, %d-shot, 401x401, %d episodes/rank/step, synthetic E(seed) episodes + Wgen weights" % (args.shot, B),
-                       "episodes_per_step": B, "shot": args.shot, "hipgraph": use_graph, "host_enqueue_ms_per_step": round(host_ms, 2),
-                       "first_loss": round(float(ls[0]), 5), "last_loss": round(float(ls[-1]), 5)}}
-        if os.environ.get("PEMP_BENCH_STUB"):
-            out["config"]["stub_weight"] = float(tr.eng.flat.data[0])      # before the rank-local roofline pass
-
-        def guarded(key, fn):
-            try:
-                out[key] = fn()
-            except Exception as exc:  # noqa: BLE001
-                out[key] = {"error": f"{type(exc).__name__}: {exc}"}
-            beat()
-
-        if not args.no_roofline:
-            # rank 0 alone runs these extra steps while the other ranks wait in the barrier below: the pass is rank-local
-            # by construction (train_roofline switches every collective of the step off)
-            guarded("roofline", lambda: train_roofline(tr, pool, step_ms))
-        if world == 1 and args.cpu_episodes > 0 and not os.environ.get("PEMP_BENCH_STUB"):
-            guarded("cpu_baseline", lambda: cpu_baseline(args))
+    dt, host_ms, ls, local_dt, exposed = timed_train_steps(tr, pool, args.steps, args.warmup, world, dev)
+    rank_ms = gather_rank_ms(local_dt, args.steps, world, dev)
+    comm = train_comm(tr, world, rank_ms, exposed)
     if world > 1:
+        # the process group ends HERE: what rank 0 measures below is rank-local, and the other ranks leave instead of spinning
+        # in a barrier kernel on their GPUs for its whole duration
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+    if rank != 0:
+        return
+    step_ms = dt / args.steps * 1e3
+    out = {
+        "metric": "train episodes/sec (PEMP %s train_step, ResNet-50, %d-shot, 401x401)" % ("stage-2" if s2 else "stage-1", args.shot),
+        "value": round(args.steps * B * world / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("pemp_stage2 train_step (frozen stage-1 prior pass, batch-stat BN, CM, Dropout2d 0.5, %s, SGD), "
+                                if s2 else "pemp_stage1 train_step (batch-stat BN, DropBlock 0.1, %s, clip 1.1, SGD), ") % args.loss.upper() +
+                               "ResNet-50, %d-shot, 401x401, %d episodes/rank/step, synthetic E(seed) episodes + Wgen weights" % (args.shot, B),
+                   "episodes_per_step": B, "shot": args.shot, "loss": args.loss, "hipgraph": use_graph,
+                   "host_enqueue_ms_per_step": round(host_ms, 2),
+                   "first_loss": round(float(ls[0]), 5), "last_loss": round(float(ls[-1]), 5)},
+        "comm": comm}
+    if os.environ.get("PEMP_BENCH_STUB"):
+        out["config"]["stub_weight"] = float(tr.eng.flat.data[0])      # before the rank-local roofline pass
+        out["process_group_alive_at_roofline"] = bool(dist.is_initialized())
+
+    def guarded(key, fn):
+        try:
+            out[key] = fn()
+        except Exception as exc:  # noqa: BLE001
+            out[key] = {"error": f"{type(exc).__name__}: {exc}"}
+        beat()
+
+    if not args.no_roofline:
+        # rank 0 alone, after the process group is gone; the pass is collective-free by construction as well
+        # (train_roofline switches every collective of the step off)
+        guarded("roofline", lambda: attach_train_pmc(train_roofline(tr, pool, step_ms), args))
+    if world == 1 and args.cpu_episodes > 0 and not os.environ.get("PEMP_BENCH_STUB"):
+        guarded("cpu_baseline", lambda: cpu_baseline(args))
+    print(json.dumps(out))
 
 
-def side_train(dev, model="stage1", shot=1, batch=4, steps=10, warmup=4):
+def side_train(dev, model="stage1", shot=1, batch=4, steps=10, warmup=4, keep=None):
     """The training step (BASELINE.json configs[2]; the reference's data.bs = 4) measured inside the default run, so that it
     sits under the driver's clock too: same code as ``--mode train``, compact record."""
     tr = make_trainer(model, shot, dev, 0)
     pool = train_pool(dev, 0, shot, batch)
-    dt, host_ms, ls = timed_train_steps(tr, pool, steps, warmup, 1, dev)
+    dt, host_ms, ls, _, _ = timed_train_steps(tr, pool, steps, warmup, 1, dev)
     step_ms = dt / steps * 1e3
     r = train_roofline(tr, pool, step_ms, reps=1)
     eff = r.get("step_effective_tflops", 0.0)
+    if keep is not None:
+        keep.update(trainer=tr, pool=pool, step_ms=step_ms)
     return {"workload": "pemp_%s train_step, ResNet-50, %d-shot, 401x401, %d episodes/step (see --mode train)" % (model, shot, batch),
             "episodes_per_step": batch, "steps": steps, "warmup": warmup, "ms_per_step": round(step_ms, 3),
             "episodes_per_s": round(steps * batch / dt, 2), "host_enqueue_ms_per_step": round(host_ms, 2),
@@ -800,18 +1106,25 @@ def side_train(dev, model="stage1", shot=1, batch=4, steps=10, warmup=4):
 # ---------------------------------------------------------------------------------------------
 class EvalRunner:
     """The device work of Evaluator.test_step for ``batch`` resident episodes: hipGraph replay of the shape-static part +
-    the fused tail; ``model`` stage2 = stage-1 prior pass + stage 2 (entry/pemp_stage2.py:53-61)."""
+    the fused tail; ``model`` stage2 = stage-1 prior pass + stage 2 (entry/pemp_stage2.py:53-61).  ``loss`` cedt: the
+    CELossDT weight map of every ground truth (boundary, exact distance transform; core/losses.py:23-41) is computed on the
+    device inside the step and weights the fused tail's cross-entropy."""
 
-    def __init__(self, dev, rank, model="stage1", shot=1, batch=25, dataset="PASCAL", steps=40, graph=True):
+    def __init__(self, dev, rank, model="stage1", shot=1, batch=25, dataset="PASCAL", steps=40, graph=True, loss="ce", net=None,
+                 pool=None):
         from pemp_amd import ops
+        from pemp_amd.core import losses
         self.graph = graph
         self.ops, self.model, self.shot, self.batch = ops, model, shot, batch
         self.vgg = model in ("baseline", "panet")
-        self.net, _ = build_model(dev, model if self.vgg else "stage1", shot)
+        self.net = net if net is not None else build_model(dev, model if self.vgg else "stage1", shot)[0]
         self.stage2 = build_model(dev, "stage2", shot)[0] if model == "stage2" else None
-        self.pool = episode_pool(dev, shot, batch, rank, dataset=dataset)
+        self.pool = pool if pool is not None else episode_pool(dev, shot, batch, rank, dataset=dataset)
+        self.loss = losses.get({"loss": loss, "sigma": 5.0})
         self.ws, self.ws_align, self.aux_log = {}, {}, []
         self.stats_log = torch.zeros((steps, batch, 8), dtype=torch.float64, device=dev)
+        self.cls_log = torch.stack([self.pool[i % len(self.pool)]["cls"] for i in range(steps)])      # [steps, batch]
+        self.round = RoundReduce(20 if dataset == "PASCAL" else 80, dev, dataset)
         # Consecutive steps alternate between two engine replicas on their own HIP streams (model.lane(k): same weights, own
         # activation arena, graphs and workspaces): the prototype head + tail of step i (HBM-bound, 0.3 ms) and the gap
         # between two graph replays run beside the first convolutions of step i + 1.  Every step still does all of its work
@@ -820,6 +1133,12 @@ class EvalRunner:
         self.lane_streams = [torch.cuda.Stream(device=dev) for _ in range(self.lanes)] if self.lanes > 1 else []
         self.lane_ws = [{} for _ in range(self.lanes)]
 
+    def _tail(self, pred, ep, ws):
+        wmap = None
+        if self.loss.kind == "cedt":
+            wmap = self.ops.cedt_weight(ep["qry_mask"], self.loss.sigma, ws_cache=ws)
+        return self.ops.eval_tail(pred, ep["qry_mask"], ws_cache=ws, weight=wmap)
+
     def step(self, i, log=True, graph=None):
         graph = self.graph if graph is None else graph
         if self.lanes > 1 and graph:
@@ -827,7 +1146,7 @@ class EvalRunner:
             ep = self.pool[i % len(self.pool)]
             with torch.cuda.stream(self.lane_streams[k]), self.net.lane(k), torch.no_grad():
                 pred, _ = self.net.lowres_graphed(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
-                am, stats, _ = self.ops.eval_tail(pred, ep["qry_mask"], ws_cache=self.lane_ws[k])
+                am, stats, _ = self._tail(pred, ep, self.lane_ws[k])
                 if log:
                     self.stats_log[i].copy_(stats)
             return am
@@ -843,12 +1162,15 @@ class EvalRunner:
             if self.model == "panet":       # auxiliary prototype-alignment loss of every episode (entry/panet.py:51-57)
                 from pemp_amd.networks.panet import align_forward
                 self.aux_log.append(align_forward(net._last_feats, pred, ins[1], ins[0].shape[0], self.shot, 1, 20, self.ws_align)["loss"])
-            am, stats, _ = ops.eval_tail(pred, ep["qry_mask"], ws_cache=self.ws)
+            am, stats, _ = self._tail(pred, ep, self.ws)
         if log:
             self.stats_log[i].copy_(stats)
         return am
 
     def timed(self, steps, warmup, world, dev):
+        """-> (seconds [MAX over ranks], mean CE loss, this rank's own seconds).  The round's metric aggregation -- statistics
+        rows -> class table -> ONE all-reduce over the ranks -- happens inside the timed region, once per K steps (the
+        reference aggregates per round, core/base_trainer.py:84-100)."""
         def prime():                    # setup, not a step: every lane records its hipGraph (and rank 0 times kernel variants)
             for k in range(max(self.lanes, 1)):
                 self.step(k, log=False)
@@ -867,12 +1189,22 @@ class EvalRunner:
                 dist.barrier()
             torch.cuda.synchronize()
 
+        cur = torch.cuda.current_stream()
+        e_start, e_steps = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         t0 = time.perf_counter()
+        e_start.record()
+        for st in self.lane_streams:
+            st.wait_stream(cur)
         for i in range(steps):
             self.step(i)
+        for st in self.lane_streams:    # the lanes' last steps have logged their rows before the table is built
+            cur.wait_stream(st)
+        e_steps.record()                # this rank's own steps are done here; the collective below couples the ranks
+        self.round.reduce(self.stats_log[:steps].view(-1, 8), self.cls_log[:steps].reshape(-1))
         barrier()
         dt = time.perf_counter() - t0
+        local_dt = e_start.elapsed_time(e_steps) * 1e-3
         beat()
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -881,13 +1213,24 @@ class EvalRunner:
         # sanity on the logged statistics (the work really happened): finite losses, counts add up
         st = self.stats_log[:steps].cpu().numpy()
         assert np.isfinite(st).all() and (st[..., 1] > 0).all(), "eval tail produced invalid statistics"
-        return dt, float((st[..., 0] / st[..., 1]).mean())
+        return dt, float((st[..., 0] / st[..., 1]).mean()), local_dt
+
+    def comm(self, steps, world, local_dt, dev):
+        """A collective (every rank calls it, right after ``timed``): -> (`comm` object, `miou` object of the reduced table)."""
+        rank_ms = gather_rank_ms(local_dt, steps, world, dev)
+        same, miou = self.round.verify(world)
+        if not same:
+            raise AssertionError("the all-reduced metric table is not the sum of the rank shards")
+        return comm_object(world, rank_ms, collective="all_reduce(SUM) of the round's [C+1, 3] tp/fp/fn table + loss sum + episode "
+                                                      "count, once per K steps, inside the timed region",
+                           collectives_in_timed_region=1 if world > 1 else 0, allreduce_bytes_per_round=self.round.nbytes,
+                           allreduce_ms=round(self.round.allreduce_ms(), 4), table_equals_sum_of_rank_shards=same), miou
 
 
 def side_stage2(dev, shot=5, batch=8, steps=8, warmup=3):
     """BASELINE.json configs[3] inside the default run: stage-1 prior + stage 2, 5-shot, 8 episodes per step."""
     run = EvalRunner(dev, 0, "stage2", shot, batch, steps=steps)
-    dt, mean_loss = run.timed(steps, warmup, 1, dev)
+    dt, mean_loss, _ = run.timed(steps, warmup, 1, dev)
     step_ms = dt / steps * 1e3
     rec = instrumented(lambda r: run.step(r, log=False, graph=False), reps=1)
     r = summarize(rec, 1, step_ms)
@@ -945,6 +1288,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
+    if world > 1:
+        # N ranks share this host's cores (episode synthesis in numpy / torch-CPU, the eager enqueue loop): cores / N threads
+        # each, set before any GPU call (torchrun's own default would be OMP_NUM_THREADS = 1)
+        torch.set_num_threads(host_threads_per_rank(int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     if os.environ.get("PEMP_BENCH_DRYRUN"):
         return dry_run(args, world, rank)
     beat()
@@ -979,69 +1326,91 @@ def main():
     if args.mode == "train":
         return main_train(args, world, rank, dev)
     vgg = args.model in ("baseline", "panet")
-    run = EvalRunner(dev, rank, args.model, args.shot, args.batch, args.dataset, args.steps, graph=not args.no_graph)
+    run = EvalRunner(dev, rank, args.model, args.shot, args.batch, args.dataset, args.steps, graph=not args.no_graph, loss=args.loss)
     net, pool = run.net, run.pool
     beat()
-    dt, mean_loss = run.timed(args.steps, args.warmup, world, dev)
-
-    out = None
-    if rank == 0:
-        eps_total = args.steps * args.batch * world
-        name = "Baseline" if args.model == "baseline" else "PANet" if args.model == "panet" else \
-            "PEMP stage-1" if run.stage2 is None else "PEMP stage-1 prior + stage-2"
-        dsn = "PASCAL-5i" if args.dataset == "PASCAL" else "COCO-20i"
-        step_ms = dt / args.steps * 1e3
-        out = {
-            "metric": "episodes/sec (%s eval step, %s-shaped %d-shot, %s)" % (name, dsn, args.shot, "VGG-16" if vgg else "ResNet-50"),
-            "value": round(eps_total / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s eval test_step, %s, %d-shot, 401x401, %d episode(s)/step, %s-shaped "
-                                   "synthetic E(seed) episodes + Wgen(1234) weights; episodes resident in HBM when the timed "
-                                   "region starts, statistics fetched once after it (the reference's Timer region also holds the "
-                                   "three H2D copies and the argmax/loss D2H of every episode: that figure is `end_to_end` and "
-                                   "`single_episode.reference_body`)" % (
-                                       args.model if vgg else "pemp_" + args.model, "VGG-16" if vgg else "ResNet-50",
-                                       args.shot, args.batch, dsn),
-                       "episodes_per_step": args.batch, "shot": args.shot, "hipgraph": not args.no_graph,
-                       "engine_lanes": run.lanes if not args.no_graph else 1,
-                       "dataset": args.dataset, "mean_ce_loss": round(mean_loss, 6)},
-        }
-        # the auxiliary measurements must never cost the headline line: a failure is reported in place
-        def guarded(key, fn):
-            try:
-                out[key] = fn()
-            except Exception as exc:  # noqa: BLE001
-                out[key] = {"error": f"{type(exc).__name__}: {exc}"}
-            beat()
-
-        if not args.no_roofline:
-            def roof():
-                rec = instrumented(lambda r: run.step(r, log=False, graph=False), reps=3)
-                r = summarize(rec, 3, step_ms)
-                r["cosine_kernel"] = cosine_roofline(net, pool)
-                return attach_pmc(r, f"{args.model}-eval-b{args.batch}-s{args.shot}")
-            guarded("roofline", roof)
-        headline = world == 1 and args.model == "stage1" and not args.no_graph
-        if headline and not args.no_single:
-            guarded("single_episode", lambda: single_episode(net, dev, args))
-        if headline and not args.no_e2e and args.dataset == "PASCAL":
-            guarded("end_to_end", lambda: end_to_end(net, args, dev))
-        if world == 1 and args.cpu_episodes > 0 and not vgg:
-            guarded("cpu_baseline", lambda: cpu_baseline(args))
-            if args.model == "stage1" and isinstance(out["cpu_baseline"], dict) and "episodes" in out["cpu_baseline"]:
-                rows = {"episodes": out["cpu_baseline"].pop("episodes")}
-                guarded("miou", lambda: miou_vs_cpu(net, dev, rows))
-        # the other BASELINE.json configurations, measured in this process so that they sit under the driver's clock too
-        if headline and args.dataset == "PASCAL" and args.shot == 1 and not args.no_sides:
-            del run
-            guarded("train", lambda: side_train(dev))
-            guarded("stage2_5shot", lambda: side_stage2(dev))
+    dt, mean_loss, local_dt = run.timed(args.steps, args.warmup, world, dev)
+    comm, round_miou = run.comm(args.steps, world, local_dt, dev)
     if world > 1:
+        # the process group ends HERE: everything rank 0 measures below is rank-local, and the other ranks leave instead of
+        # spinning in a barrier kernel on their GPUs while it does
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+    if rank != 0:
+        return
+
+    eps_total = args.steps * args.batch * world
+    name = "Baseline" if args.model == "baseline" else "PANet" if args.model == "panet" else \
+        "PEMP stage-1" if run.stage2 is None else "PEMP stage-1 prior + stage-2"
+    dsn = "PASCAL-5i" if args.dataset == "PASCAL" else "COCO-20i"
+    step_ms = dt / args.steps * 1e3
+    out = {
+        "metric": "episodes/sec (%s eval step, %s-shaped %d-shot, %s)" % (name, dsn, args.shot, "VGG-16" if vgg else "ResNet-50"),
+        "value": round(eps_total / dt, 2), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(step_ms, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s eval test_step, %s, %d-shot, 401x401, %d episode(s)/step, %s-shaped "
+                               "synthetic E(seed) episodes + Wgen(1234) weights; episodes resident in HBM when the timed "
+                               "region starts; the round's metric table is built and all-reduced inside the timed region and "
+                               "fetched once after it (the reference's Timer region also holds the "
+                               "three H2D copies and the argmax/loss D2H of every episode: that figure is `end_to_end` and "
+                               "`single_episode.reference_body`)" % (
+                                   args.model if vgg else "pemp_" + args.model, "VGG-16" if vgg else "ResNet-50",
+                                   args.shot, args.batch, dsn),
+                   "episodes_per_step": args.batch, "shot": args.shot, "loss": args.loss, "hipgraph": not args.no_graph,
+                   "engine_lanes": run.lanes if not args.no_graph else 1,
+                   "dataset": args.dataset, "mean_ce_loss": round(mean_loss, 6)},
+        "comm": comm,
+    }
+    if world > 1:
+        out["miou"] = round_miou      # N = 1 prints `miou` against the CPU oracle below; `round_miou` holds this table there
+    else:
+        out["round_miou"] = round_miou
+
+    # the auxiliary measurements must never cost the headline line: a failure is reported in place
+    def guarded(key, fn):
+        try:
+            out[key] = fn()
+        except Exception as exc:  # noqa: BLE001
+            out[key] = {"error": f"{type(exc).__name__}: {exc}"}
+        beat()
+
+    if not args.no_roofline:
+        def roof():
+            rec = instrumented(lambda r: run.step(r, log=False, graph=False), reps=3)
+            r = summarize(rec, 3, step_ms)
+            r["cosine_kernel"] = cosine_roofline(net, pool)
+            return attach_pmc(r, f"{args.model}-eval-b{args.batch}-s{args.shot}")
+        guarded("roofline", roof)
+    headline = world == 1 and args.model == "stage1" and not args.no_graph and args.loss == "ce"
+    if headline and not args.no_single:
+        guarded("single_episode", lambda: single_episode(net, dev, args))
+    if headline and not args.no_e2e and args.dataset == "PASCAL":
+        guarded("end_to_end", lambda: end_to_end(net, args, dev))
+    if world == 1 and args.cpu_episodes > 0 and not vgg:
+        guarded("cpu_baseline", lambda: cpu_baseline(args))
+        if args.model == "stage1" and isinstance(out["cpu_baseline"], dict) and "episodes" in out["cpu_baseline"]:
+            rows = {"episodes": out["cpu_baseline"].pop("episodes")}
+            guarded("miou", lambda: miou_vs_cpu(net, dev, rows))
+    # the other BASELINE.json configurations, measured in this process so that they sit under the driver's clock too
+    if headline and args.dataset == "PASCAL" and args.shot == 1 and not args.no_sides:
+        guarded("protocol_5x1000", lambda: protocol_5x1000(net, pool, dev, args))
+        cedt = {}
+        try:
+            cedt["eval"] = side_cedt_eval(run, dev, args)
+        except Exception as exc:  # noqa: BLE001
+            cedt["eval"] = {"error": f"{type(exc).__name__}: {exc}"}
+        del run
+        keep = {}
+        guarded("train", lambda: side_train(dev, keep=keep))
+        try:
+            cedt["train"] = side_cedt_train(keep, dev) if keep else {"error": "the `train` object failed"}
+        except Exception as exc:  # noqa: BLE001
+            cedt["train"] = {"error": f"{type(exc).__name__}: {exc}"}
+        keep.clear()
+        out["cedt"] = cedt
+        guarded("stage2_5shot", lambda: side_stage2(dev))
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -104,14 +104,54 @@ def allreduce_round(stat, loss_sum, count, device=None):
     return pack[:-2].numpy().reshape(np.shape(stat)), float(pack[-2]), float(pack[-1])
 
 
+class DeviceRoundTable:
+    """The metric table of ONE evaluation round (reference core/base_trainer.py:70-100: ``FewShotMetric.update`` per episode,
+    mIoU per round) kept where the statistics rows are produced: the rows of the fused tail (``pemp_eval_tail``: loss sum,
+    pixel count, tp/fp/fn of background and foreground) are folded into a ``[C+1, 3]`` float64 table by the episode's class,
+    the table + loss sum + episode count travel as ONE vector through ONE ``all_reduce(SUM)`` as it lies (RCCL on device
+    memory, gloo on host memory; no staging copy) and reach the host once per round.  Every entry of the table is an integer
+    below 2^53, so the sums -- on the device and across ranks -- are exact in any order and the mIoU does not depend on the
+    number of ranks."""
+
+    def __init__(self, num_classes, device):
+        self.rows = num_classes + 1
+        self.pack = torch.zeros(self.rows * 3 + 2, dtype=torch.float64, device=device)
+
+    def reset(self):
+        self.pack.zero_()
+
+    def add(self, stats, classes):
+        """``stats`` f64 [n, 8] (rows of the tail kernel), ``classes`` int64 [n] on the same device."""
+        table = self.pack[:self.rows * 3].view(self.rows, 3)
+        table[0] += stats[:, 2:5].sum(dim=0)
+        table.index_add_(0, classes, stats[:, 5:8])
+        self.pack[-2] += (stats[:, 0] / stats[:, 1].clamp_min(1.0)).sum()      # mean over episodes of the episode's CE mean
+        self.pack[-1] += float(stats.shape[0])
+
+    def allreduce(self):
+        """The round's only collective; returns the number of bytes reduced (0 without a process group)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.pack, op=dist.ReduceOp.SUM)
+            return self.pack.numel() * self.pack.element_size()
+        return 0
+
+    def fetch(self):
+        """-> (stat [C+1, 3] float64 ndarray, loss sum, episode count) on the host (one synchronising copy)."""
+        pack = self.pack.cpu().numpy()
+        return pack[:-2].reshape(self.rows, 3).copy(), float(pack[-2]), float(pack[-1])
+
+
 class Evaluator:
     """``lanes`` > 1: single-episode steps (the reference's test_bs = 1 protocol) are issued round-robin over that many
     engine replicas, each on its own HIP stream -- a one-episode step leaves most of the 256 CUs idle (M = 5202 rows
     give 1.3 waves per SIMD), several in flight fill them.  Per-episode results do not change (same kernels, same
     operands); ``test_steps_device`` is the entry point that overlaps them."""
 
-    def __init__(self, model, device=None, use_graph=True, lanes=1):
+    def __init__(self, model, device=None, use_graph=True, lanes=1, splitk=None):
         self.model = model
+        #: True: one-episode steps may run the split-K conv variants (faster, equal to the exact path to rounding; see
+        #: pemp_amd.ops.EVAL_SPLITK); None: the process-wide setting (off unless PEMP_EVAL_SPLITK=1)
+        self.splitk = splitk
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.use_graph = use_graph
         self._ws = {}
@@ -124,10 +164,7 @@ class Evaluator:
         dev_in = [x.to(self.device, non_blocking=True) for x in inputs]
         tgt = qry_msk.view(-1, *qry_msk.shape[-2:]).to(self.device, non_blocking=True)
         with torch.no_grad():
-            if self.use_graph:
-                pred, _ = self.model.lowres_graphed(*dev_in)
-            else:
-                pred, _ = self.model.lowres(*dev_in)
+            pred = self._lowres(dev_in)
             am, stats, _ = ops.eval_tail(pred, tgt, ws_cache=self._ws)
         return am, stats
 
@@ -178,7 +215,10 @@ class Evaluator:
 
     def _lowres(self, dev_in):
         """Feature-resolution prediction of a batch of episodes (stage 2 overrides: stage-1 prior first)."""
-        return (self.model.lowres_graphed(*dev_in) if self.use_graph else self.model.lowres(*dev_in))[0]
+        if self.splitk is None:
+            return (self.model.lowres_graphed(*dev_in) if self.use_graph else self.model.lowres(*dev_in))[0]
+        with ops.eval_splitk(self.splitk):
+            return (self.model.lowres_graphed(*dev_in) if self.use_graph else self.model.lowres(*dev_in))[0]
 
     def test_step(self, inputs, qry_msk, **kwargs):
         """Reference contract (entry/pemp_stage1.py:48-53): -> (qry_pred numpy [B,H,W], loss float)."""
@@ -217,6 +257,7 @@ class Evaluator:
         rank = dist.get_rank() if dist.is_initialized() else 0
         accum = Accumulator(loss=[], miou=[], biou=[])
         val_labels = get_val_labels(split, dataset_name)
+        table = DeviceRoundTable(num_classes, self.device)
         timed, calls = 0.0, 0
         for epoch in range(1, te_epochs + 1):
             metric = FewShotMetric(num_classes)
@@ -255,13 +296,15 @@ class Evaluator:
                 rows.append(self.test_steps_device(pending))
                 timed += time.time() - t0
                 calls += len(pending)
+            # the round's aggregation stays on the device: rows -> [C+1, 3] table by class, ONE all-reduce, one fetch
+            # (per-episode losses are averaged like the reference: mean over episodes of the episode's CE mean)
             t0 = time.time()
-            st = torch.cat(rows).cpu().numpy() if rows else np.zeros((0, 8))
+            table.reset()
+            if rows:
+                table.add(torch.cat(rows), torch.tensor(classes, dtype=torch.int64, device=self.device))
+            table.allreduce()
+            metric.stat, loss_tot, n_tot = table.fetch()
             timed += time.time() - t0
-            metric.update_counts(st[:, 2:], classes)
-            # per-episode losses are averaged like the reference: mean over episodes of (CE mean)
-            loss_sum = float((st[:, 0] / np.maximum(st[:, 1], 1.0)).sum())
-            metric.stat, loss_tot, n_tot = allreduce_round(metric.stat, loss_sum, len(classes), self.device)
             miou_c, miou = metric.mIoU(val_labels)
             biou_c, biou = metric.mIoU(val_labels, binary=True)
             if logger is not None and rank == 0:

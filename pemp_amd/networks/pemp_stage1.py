@@ -141,7 +141,7 @@ class _HeadMixin:
         """
         self._require_eval_gpu(self, *inputs)
         eng = self._engine_for(inputs[0].device)
-        key = tuple((tuple(t.shape), t.dtype) for t in inputs) + (ret_ind,)
+        key = tuple((tuple(t.shape), t.dtype) for t in inputs) + (ret_ind, ops.EVAL_SPLITK)    # the conv variants are baked in
         graphs = eng.setdefault("graphs", {})
         entry = graphs.get(key)
         if entry is None:

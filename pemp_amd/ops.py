@@ -272,10 +272,13 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
 #: them, and so may the evaluation path for SMALL row counts (one or two episodes per step: 5202 rows leave two thirds of the
 #: chip idle on the 3x3 layers otherwise) -- see EVAL_SPLITK
 SPLITK_TILES = (31, 32, 34, 35, 36, 37)
-#: evaluation convs of at most EVAL_SPLITK_MAX_ROWS output rows may use the split-K variants (PEMP_EVAL_SPLITK=0: never --
-#: every evaluation variant is then bit-identical again and a one-episode step equals the batched step bit for bit; with it,
-#: they agree to rounding: tests/test_eval_protocol_gpu.py states the bounds)
-EVAL_SPLITK = os.environ.get("PEMP_EVAL_SPLITK", "1") != "0"
+#: evaluation convs of at most EVAL_SPLITK_MAX_ROWS output rows may use the split-K variants.  OFF by default: every evaluation
+#: variant is then bit-identical, a one-episode step equals the batched step bit for bit, and metrics cannot differ between
+#: processes or ranks through the (timing-based) variant pick.  ON (PEMP_EVAL_SPLITK=1, ``with ops.eval_splitk():``,
+#: ``Evaluator(splitk=True)``): one-episode steps are ~1.15x faster and agree with the exact path to rounding
+#: (tests/test_eval_protocol_gpu.py states the bounds); the split-K hand-off rests on the behaviour of uncached device memory
+#: described in csrc/conv_dma2.hip, not on the HIP memory model.  Multi-rank jobs broadcast rank 0's picks (tuned_by_rank0).
+EVAL_SPLITK = os.environ.get("PEMP_EVAL_SPLITK", "0") == "1"
 EVAL_SPLITK_MAX_ROWS = int(os.environ.get("PEMP_EVAL_SPLITK_MAX_ROWS", "12000"))
 #: Uncached split-K workspaces, one per (device, scope).  A workspace must never serve two launches that can run beside each
 #: other, so everything that runs on its own stream has its own SCOPE: 0 = the main chain (training step, evaluation engine),
@@ -284,6 +287,24 @@ EVAL_SPLITK_MAX_ROWS = int(os.environ.get("PEMP_EVAL_SPLITK_MAX_ROWS", "12000"))
 _SK_WS = {}
 SK_SCOPE = 0
 _SK_WS_BYTES = 72 << 20            # 256 partial tiles of 256 x 256 floats + counters
+
+
+class eval_splitk:
+    """``with ops.eval_splitk(True):`` -- evaluation convs issued (or recorded into a hipGraph) inside the block may use the
+    split-K variants for small row counts; restores the previous setting on exit."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global EVAL_SPLITK
+        self.prev, EVAL_SPLITK = EVAL_SPLITK, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global EVAL_SPLITK
+        EVAL_SPLITK = self.prev
+        return False
 
 
 def _splitk_ws(lib, desc, device):

@@ -42,19 +42,40 @@ SEG_EVERY = int(os.environ.get("PEMP_SEG_EVERY", "1"))     # residual blocks per
 # ---------------------------------------------------------------------------------------------
 # flat parameter storage
 # ---------------------------------------------------------------------------------------------
+def flat_layout(model):
+    """-> (trainable parameters in ``model.parameters()`` order, their offsets in the flat buffers [floats, 16-byte aligned],
+    total length).  Pure: no device memory (tests derive the all-reduce schedule of the real model from it on the CPU)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    offs, n = [], 0
+    for p in params:
+        offs.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    return params, offs, n
+
+
+def stage1_bucket_cuts(model, params=None, offs=None):
+    """Candidate bucket boundaries of the stage-1 ResNet model's flat gradient buffer: the offset of every residual block's
+    first conv weight (forward order) + the offset where the purifier / ASPP parameters start (``GradBuckets`` forms the
+    buckets from them) -> (block offsets, tail offset)."""
+    if params is None:
+        params, offs, _ = flat_layout(model)
+    at = {id(p): o for p, o in zip(params, offs)}
+    bb = model.encoder.backbone
+    block_off = [at.get(id(blk.conv1.weight), 0) for name in ("layer1", "layer2", "layer3") for blk in getattr(bb, name)]
+    pur = getattr(model.encoder, "purifier", None)
+    tail_off = min([at[id(p)] for p in pur.parameters() if id(p) in at], default=0) if pur is not None else 0
+    return block_off, tail_off
+
+
 class FlatParams:
     """Re-homes the trainable parameters of ``model`` into one flat buffer (+ one for gradients)."""
 
     def __init__(self, model, device):
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        offs, n = [], 0
-        for p in self.params:
-            offs.append(n)
-            n += (p.numel() + 3) // 4 * 4
+        self.params, offs, n = flat_layout(model)
         self.n = n
         self.data = torch.zeros(n, dtype=torch.float32, device=device)
         self.grad = torch.zeros(n, dtype=torch.float32, device=device)
-        self.mom = torch.zeros(n, dtype=torch.float32, device=device)
+        self._mom = None               # SGD momentum, allocated by the first SGD step (an Adam run never needs it)
         self.offs = offs
         self.first_step = True
         for p, o in zip(self.params, offs):
@@ -68,6 +89,12 @@ class FlatParams:
                             if torch.device(device).type == "cuda" else None)      # verified to run BESIDE the current stream
         self.side_ws, self.side_keep = {}, []
         self.capture = None            # a SegmentedCapture while the step is being recorded (Stage1Trainer.use_graph)
+
+    @property
+    def mom(self):
+        if self._mom is None:
+            self._mom = torch.zeros_like(self.data)
+        return self._mom
 
     def cut(self):
         """Segment point of the backward pass (no-op unless a segmented capture is recording): everything enqueued so far
@@ -363,10 +390,8 @@ class Stage1TrainEngine:
         self.flat.build_dgrad_mirror()
         self.bn_counters = [m.num_batches_tracked for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
         # overlapped gradient all-reduce: bucket boundaries at residual-block starts (see GradBuckets)
-        offs = {id(p): o for p, o in zip(self.flat.params, self.flat.offs)}
-        self.block_off = [offs.get(id(b["c1"].conv.weight), 0) for b in getattr(self, "blocks", [])]
-        pur = getattr(getattr(model, "encoder", None), "purifier", None)     # laid out after the backbone, finished first
-        self.tail_off = min([offs[id(p)] for p in pur.parameters() if id(p) in offs], default=0) if pur is not None else 0
+        # (the purifier / ASPP parameters are laid out after the backbone and finished first)
+        self.block_off, self.tail_off = stage1_bucket_cuts(model, self.flat.params, self.flat.offs)
         self.buckets = GradBuckets(self.flat.grad, self.block_off + [self.tail_off], side_stream=self.flat.side_stream)
 
     def _init_trunk(self, bb):
@@ -746,6 +771,8 @@ class Stage1Trainer:
     #: For passes that only one rank runs (bench.py's instrumented roofline pass): a collective issued by one rank alone
     #: would pair with whatever the other ranks issue next.
     collectives = True
+    #: a list: ``reduce_gradients`` appends one timing record per step (bench.py's ``comm.exposed_comm_ms``); None: not timed
+    comm_log = None
 
     def encode(self, sup_img, sup_mask, qry_img, qry_prior=None):
         """Train-mode encoder forward -> NHWC features [B*S + B*Q, h, w, c] (supports first); tape kept in the engine."""
@@ -818,11 +845,11 @@ class Stage1Trainer:
             cap.begin()
             try:
                 loss, _ = self.forward_backward(*static)
+                cap.end()
             except BaseException:
-                cap.abort()                # keeps the original error; the next call records again
+                cap.abort()                # keeps the original error; two eager calls later the step is recorded again
                 ent["calls"] = 0
                 raise
-            cap.end()
             ent.update(cap=cap, static=static, loss=loss)
         for s_, t in zip(ent["static"], ins):
             s_.copy_(t, non_blocking=True)
@@ -840,7 +867,33 @@ class Stage1Trainer:
         process group for a rank-local step (``collectives`` False)."""
         if not self.collectives:
             return 1.0
-        return self.eng.buckets.finish() if self.eng.buckets.next else allreduce_gradients(self.eng.flat.grad)
+        log = self.comm_log
+        if log is None:
+            return self.eng.buckets.finish() if self.eng.buckets.next else allreduce_gradients(self.eng.flat.grad)
+        # measured: how long the step's own stream is held by the collective(s) it has to wait for here -- the EXPOSED part of
+        # the gradient exchange (the buckets launched during the backward pass ran under it)
+        if self.device.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            scale = self.eng.buckets.finish() if self.eng.buckets.next else allreduce_gradients(self.eng.flat.grad)
+            e1.record()
+            log.append((e0, e1))
+        else:
+            import time
+            t0 = time.perf_counter()
+            scale = self.eng.buckets.finish() if self.eng.buckets.next else allreduce_gradients(self.eng.flat.grad)
+            log.append((time.perf_counter() - t0) * 1e3)
+        return scale
+
+    def exposed_comm_ms(self):
+        """Mean over the logged steps (``comm_log``) of the time ``reduce_gradients`` held the step's stream; None without a log."""
+        log = self.comm_log
+        if not log:
+            return None
+        if isinstance(log[0], tuple):
+            log[-1][1].synchronize()
+            return sum(a.elapsed_time(b) for a, b in log) / len(log)
+        return sum(log) / len(log)
 
     def optimizer_step(self):
         if self.optimizer is not None:
@@ -849,9 +902,33 @@ class Stage1Trainer:
             self.nesterov = bool(g.get("nesterov", False))
         self.apply_update(self.reduce_gradients())
 
+    def optimizer_state(self):
+        """What the fused optimizer kernels keep beside the flat parameters (``optimizer.state`` of an attached torch object
+        stays empty): SGD momentum, or Adam's moments and step count -- flat tensors in the layout of ``flat_layout``."""
+        f = self.eng.flat
+        st = {"first_step": f.first_step, "momentum": None if f._mom is None else f._mom.clone()}
+        if getattr(f, "exp_avg", None) is not None:
+            st.update(exp_avg=f.exp_avg.clone(), exp_avg_sq=f.exp_avg_sq.clone(), adam_step=f.adam_step)
+        return st
+
+    def load_optimizer_state(self, st):
+        f = self.eng.flat
+        f.first_step = bool(st["first_step"])
+        if st.get("momentum") is not None:
+            f.mom.copy_(st["momentum"])
+        if "exp_avg" in st:
+            if getattr(f, "exp_avg", None) is None:
+                f.exp_avg, f.exp_avg_sq = torch.zeros_like(f.data), torch.zeros_like(f.data)
+            f.exp_avg.copy_(st["exp_avg"])
+            f.exp_avg_sq.copy_(st["exp_avg_sq"])
+            f.adam_step = int(st["adam_step"])
+
     def apply_update(self, scale):
         f = self.eng.flat
-        if type(self.optimizer) is torch.optim.Adam and not any(g.get("amsgrad") or g.get("maximize") for g in self.optimizer.param_groups):
+        if (type(self.optimizer) is torch.optim.Adam and len(self.optimizer.param_groups) == 1
+                and not any(g.get("amsgrad") or g.get("maximize") for g in self.optimizer.param_groups)):
+            # (an Adam with several groups -- per-layer lr / weight decay -- steps through torch below: the fused kernel has
+            # one set of hyper-parameters for the whole flat buffer)
             # tr.opt = adam (core/solver.py:92-96): fused clip + Adam on the flat buffers; the torch object holds the
             # hyper-parameters (and its LR scheduler), the moments live beside the flat parameters
             g = self.optimizer.param_groups[0]

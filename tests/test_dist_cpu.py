@@ -190,6 +190,87 @@ def test_bench_launches_its_own_ranks():
         assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["config"]["mode"] == mode
         # MAX over ranks: rank 1 sleeps twice as long per step as rank 0 (4 ms vs 2 ms)
         assert out["ms_per_step"] >= 3.9
+        _check_comm(out, 2, mode)
+
+
+def _check_comm(out, world, mode):
+    """The self-verifying part of an N-rank line: who took part, what was exchanged inside the timed region, how evenly the
+    ranks ran -- and that the process group was gone before rank 0 went on alone."""
+    comm = out["comm"]
+    assert comm["backend"] == "gloo" and comm["world"] == world and comm["rccl_version"] is None
+    per = comm["rank_ms_per_step"]
+    assert len(per["all"]) == world and per["min"] == min(per["all"]) and per["max"] == max(per["all"])
+    # every rank's OWN step time (before the collective couples them): rank r sleeps 2 (r + 1) ms per step
+    assert all(2.0 * (r + 1) <= v < 2.0 * (r + 1) + 3.0 for r, v in enumerate(per["all"])), per
+    assert 1 <= comm["host_threads_per_rank"] <= max(1, len(os.sched_getaffinity(0)) // world)
+    assert out["process_group_alive_at_print"] is False
+    if mode == "eval":
+        assert comm["collectives_in_timed_region"] == 1 and comm["allreduce_bytes_per_round"] == (21 * 3 + 2) * 8
+        assert comm["table_equals_sum_of_rank_shards"] is True and comm["allreduce_ms"] >= 0
+        m = out["miou"]
+        assert m["episodes"] == out["steps"] * 25 * world and m["episodes_per_rank"] == [out["steps"] * 25] * world
+        assert 0 < m["miou"] < 1 and 0 < m["biou"] < 1 and m["classes"] == 5
+        # the same table from the rank shards, built here: the printed mIoU is the one of the SUM over ranks
+        import bench
+        from pemp_amd.core.metrics import FewShotMetric
+        fm = FewShotMetric(20)
+        for r in range(world):
+            rows, cls = bench.dry_rows(out["steps"] * 25, r)
+            fm.update_counts(rows[:, 2:].numpy(), cls.tolist())
+        assert abs(fm.mIoU([1, 2, 3, 4, 5])[1] - m["miou"]) < 1e-6 and abs(fm.mIoU([1, 2, 3, 4, 5], binary=True)[1] - m["biou"]) < 1e-6
+
+
+def test_bench_eight_rank_eval_line_is_self_verifying():
+    """`bench.py --gpus 8` (dry run, gloo): the round's metric table is all-reduced inside the timed region and equals the sum
+    of the eight rank shards; per-rank step times, thread cap, no process group left when rank 0 prints."""
+    import json
+    r = _run_bench({}, "--gpus", "8", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8
+    _check_comm(out, 8, "eval")
+
+
+def test_device_round_table_equals_host_metric():
+    """DeviceRoundTable (rows -> class table with index_add, one packed vector) == FewShotMetric.update_counts on the host."""
+    import bench
+    from pemp_amd.core.metrics import FewShotMetric
+    from pemp_amd.entry.pemp_stage1 import DeviceRoundTable
+    rows, cls = bench.dry_rows(57, 3)
+    t = DeviceRoundTable(20, torch.device("cpu"))
+    t.add(rows[:30], cls[:30])
+    t.add(rows[30:], cls[30:])
+    assert t.allreduce() == 0                                    # no process group: nothing to reduce
+    stat, loss_sum, count = t.fetch()
+    fm = FewShotMetric(20)
+    fm.update_counts(rows[:, 2:].numpy(), cls.tolist())
+    assert np.array_equal(stat, fm.stat) and count == 57
+    assert abs(loss_sum - float((rows[:, 0] / rows[:, 1]).sum())) < 1e-9
+    t.reset()
+    assert float(t.pack.abs().sum()) == 0.0
+
+
+def test_gradient_bucket_schedule_of_the_real_stage1_layout():
+    """The all-reduce schedule DESIGN.md section 6 promises, derived on the CPU from the real model: 11 955 392 gradient floats,
+    FIVE buckets cut at residual-block starts, launched from the END of the buffer (purifier / ASPP first, ctr .. layer2 last,
+    from finish())."""
+    from pemp_amd.networks import pemp_stage1 as m
+    from pemp_amd.train_engine import GradBuckets, flat_layout, stage1_bucket_cuts
+    net = m.ModelClass(None)
+    params, offs, n = flat_layout(net)
+    assert n == 11955392 and len(params) == 148 and all(o % 4 == 0 for o in offs)
+    blocks, tail = stage1_bucket_cuts(net, params, offs)
+    assert len(blocks) == 3 + 4 + 6 and blocks == sorted(blocks) and tail == 8542656 and tail > blocks[-1]
+    bk = GradBuckets(torch.empty(n), blocks + [tail])
+    assert bk.buckets == [(8542656, 11955392),      # purifier + ASPPV2: 13.65 MB, ready when the tail's backward is enqueued
+                          (6308288, 8542656),       # layer3 blocks 4-5: 8.94 MB
+                          (4073920, 6308288),       # layer3 blocks 2-3: 8.94 MB
+                          (1446336, 4073920),       # layer3 blocks 0-1 + its downsample: 10.51 MB
+                          (0, 1446336)]             # ctr, stem, layer1, layer2: 5.79 MB, sent by finish()
+    assert sum(hi - lo for lo, hi in bk.buckets) == n and all(b[0] in blocks + [tail, 0] for b in bk.buckets)
+    assert all((hi - lo) * 4 >= 8 << 20 for lo, hi in bk.buckets[:-1])
 
 
 def test_bench_launcher_fails_when_a_rank_fails():
@@ -216,11 +297,18 @@ def test_bench_train_control_flow_two_ranks_with_the_rank0_roofline_pass():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["episodes_per_step"] == 4
     assert "roofline" in out and "error" not in out["roofline"], out.get("roofline")
-    # rank 0: one rank-local step first (kernel variants are timed by rank 0 alone and broadcast, ops.tuned_by_rank0: its own
-    # gradient 1, no collective), then 5 steps of lr 0.1 on the MEAN gradient of the ranks ((1 + 2) / 2): every all-reduce
-    # of the warm-up and of the timed part paired up
-    assert abs(out["config"]["stub_weight"] - (-0.1 * 1.0 - 0.1 * 1.5 * 5)) < 1e-6
+    # rank 0: one rank-local forward + backward first (kernel variants are timed by rank 0 alone and broadcast,
+    # ops.tuned_by_rank0) -- NO optimizer step, and the replicas are re-synchronised after it -- then 5 steps of lr 0.1 on the
+    # MEAN gradient of the ranks ((1 + 2) / 2): the data-parallel result, every all-reduce of the warm-up and of the timed
+    # part paired up
+    assert abs(out["config"]["stub_weight"] - (-0.1 * 1.5 * 5)) < 1e-6
     assert out["config"]["last_loss"] == 6.0          # rank 0 made exactly 1 + 5 calls before the roofline pass
+    assert out["process_group_alive_at_roofline"] is False      # the roofline pass ran after destroy_process_group
+    comm = out["comm"]
+    assert comm["backend"] == "gloo" and comm["world"] == 2 and len(comm["rank_ms_per_step"]["all"]) == 2
+    assert comm["gradient_elements"] == 1 << 16 and comm["allreduce_bytes_per_step"] == 4 << 16
+    assert comm["buckets"] == [[49152, 65536], [32768, 49152], [16384, 32768], [0, 16384]] and comm["collectives_per_step"] == 4
+    assert sum(comm["bucket_bytes"]) == comm["allreduce_bytes_per_step"] and comm["exposed_comm_ms"] > 0
 
 
 def test_bench_train_stub_roofline_pass_with_collectives_left_on_would_mismatch():
