@@ -95,8 +95,9 @@ def host_cores():
 
 
 def host_threads_per_rank(local_world):
-    """Host threads one of ``local_world`` ranks on this host may use: cores / ranks (PEMP_BENCH_THREADS overrides)."""
-    return max(1, int(os.environ.get("PEMP_BENCH_THREADS", host_cores() // max(1, local_world))))
+    """Host threads one of ``local_world`` ranks on this host may use: cores / ranks, at most 16 -- what one rank's episode
+    synthesis and enqueue loop can use (PEMP_BENCH_THREADS overrides)."""
+    return max(1, int(os.environ.get("PEMP_BENCH_THREADS", min(16, host_cores() // max(1, local_world)))))
 
 
 # ---------------------------------------------------------------------------------------------

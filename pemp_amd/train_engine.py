@@ -53,16 +53,19 @@ def flat_layout(model):
     return params, offs, n
 
 
-def stage1_bucket_cuts(model, params=None, offs=None):
-    """Candidate bucket boundaries of the stage-1 ResNet model's flat gradient buffer: the offset of every residual block's
-    first conv weight (forward order) + the offset where the purifier / ASPP parameters start (``GradBuckets`` forms the
-    buckets from them) -> (block offsets, tail offset)."""
+def stage1_bucket_cuts(model, params=None, offs=None, first_convs=None):
+    """Candidate bucket boundaries of a model's flat gradient buffer: the offset of every residual block's first conv weight
+    (forward order; ``first_convs``: those weights, default: ``model.encoder.backbone.layer1..3[*].conv1.weight``) + the offset
+    where the purifier / ASPP parameters start (``GradBuckets`` forms the buckets from them) -> (block offsets, tail offset)."""
     if params is None:
         params, offs, _ = flat_layout(model)
     at = {id(p): o for p, o in zip(params, offs)}
-    bb = model.encoder.backbone
-    block_off = [at.get(id(blk.conv1.weight), 0) for name in ("layer1", "layer2", "layer3") for blk in getattr(bb, name)]
-    pur = getattr(model.encoder, "purifier", None)
+    enc = getattr(model, "encoder", None)
+    if first_convs is None:
+        bb = getattr(enc, "backbone", None)
+        first_convs = [blk.conv1.weight for name in ("layer1", "layer2", "layer3") for blk in getattr(bb, name, [])]
+    block_off = [at.get(id(w), 0) for w in first_convs]
+    pur = getattr(enc, "purifier", None)
     tail_off = min([at[id(p)] for p in pur.parameters() if id(p) in at], default=0) if pur is not None else 0
     return block_off, tail_off
 
@@ -391,7 +394,8 @@ class Stage1TrainEngine:
         self.bn_counters = [m.num_batches_tracked for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
         # overlapped gradient all-reduce: bucket boundaries at residual-block starts (see GradBuckets)
         # (the purifier / ASPP parameters are laid out after the backbone and finished first)
-        self.block_off, self.tail_off = stage1_bucket_cuts(model, self.flat.params, self.flat.offs)
+        self.block_off, self.tail_off = stage1_bucket_cuts(model, self.flat.params, self.flat.offs,
+                                                           first_convs=[b["c1"].conv.weight for b in getattr(self, "blocks", [])])
         self.buckets = GradBuckets(self.flat.grad, self.block_off + [self.tail_off], side_stream=self.flat.side_stream)
 
     def _init_trunk(self, bb):

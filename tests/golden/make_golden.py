@@ -530,6 +530,74 @@ def gen_metric_coco():
     print("wrote metric_reference_coco", m.stat.shape, float(mean), float(meanb))
 
 
+REAL_DIR = REF / "http" / "static" / "1005_pascal_1shot_pemp_stage2_s0"
+
+
+def gen_real_episodes(tmp, stage1_model):
+    """G24: the two REAL PASCAL episodes the reference ships with its viewer (http/static/1005_pascal_1shot_pemp_stage2_s0/
+    {000_01,001_03}: support / query JPEG, 0/255 PNG label images, data.json) through the reference's own pipeline:
+    Pillow decode, the evaluation transform of data_kits/pascal_voc.py:200-229 (bilinear resize to 401 x 401, ToTensor,
+    Normalize; support label nearest-resized, query label left at its size; that module needs torchvision, which is absent,
+    so its four Pillow / tensor operations are written out here), then the imported PEMPStage1 -> argmax prior -> PEMPStage2
+    with Wgen weights (entry/pemp_stage2.py:53-61).  Stored: the DECODED uint8 arrays (what Image.open yields; the GPU test
+    feeds them to pemp_episode_preprocess), strided samples of the normalised tensors, and the outputs of both stages."""
+    from PIL import Image
+    from networks import pemp_stage2 as m2
+    cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3,
+               drop_rate=0.1, block_size=4, backbone2="resnet50", protos2=3, drop_rate2=0.5, cm=True)
+    stage2 = _build(m2, "PEMPStage2", cfg, (1, 1), tmp)
+    _load_wgen(stage2, seed=4321)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)            # data_kits/datasets.py:18-19
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    H = W = 401
+
+    def image_tensor(pil):             # resize_image + ToTensor + Normalize (pascal_voc.py:141-144,201-202)
+        a = np.asarray(pil.resize((W, H), Image.BILINEAR), np.uint8)
+        t = torch.from_numpy(a.copy()).permute(2, 0, 1).contiguous().float().div(255)
+        return (t - mean) / std
+
+    res = {"dirs": np.array(sorted(d.name for d in REAL_DIR.iterdir() if d.is_dir()))}
+    for n, name in enumerate(res["dirs"]):
+        d = REAL_DIR / str(name)
+        meta = json.loads((d / "data.json").read_text())
+        cn = meta["cls_name"]
+        sup_pil = Image.open(d / f"{cn}_sup_img_{meta['sup']}.jpg").convert("RGB")
+        qry_pil = Image.open(d / f"{cn}_qry_img_{meta['qry']}.jpg").convert("RGB")
+        sup_lab_pil = Image.open(d / f"{cn}_sup_msk_{meta['sup']}.png")
+        qry_lab_pil = Image.open(d / f"{cn}_qry_msk_{meta['qry']}.png")
+        sup_rgb, qry_rgb = image_tensor(sup_pil), image_tensor(qry_pil)
+        sup_lab = np.asarray(sup_lab_pil.resize((W, H), Image.NEAREST), np.uint8)
+        fg = torch.from_numpy((sup_lab // 255).astype(np.float32))
+        sup_mask = torch.stack((fg, 1 - fg), dim=0)
+        qry_lab = np.asarray(qry_lab_pil, np.uint8)
+        gt = torch.from_numpy((qry_lab // 255).astype(np.int64))[None]
+        sup, msk, qry = sup_rgb[None, None], sup_mask[None, None], qry_rgb[None, None]
+        out_shape = tuple(gt.shape[-2:])
+        with torch.no_grad():
+            logits1, resp1 = stage1_model(sup, msk, qry, out_shape, ret_ind=True)
+            prior = stage1_model(sup, msk, qry).argmax(dim=1, keepdim=True)           # entry/pemp_stage2.py:58-60
+            logits2, resp2 = stage2(sup, msk, qry, prior, out_shape, ret_ind=True)
+        e = f"e{n}_"
+        res[e + "cls"] = np.array(int(meta["cls_id"]))
+        res[e + "sup_img_u8"], res[e + "qry_img_u8"] = np.asarray(sup_pil, np.uint8), np.asarray(qry_pil, np.uint8)
+        res[e + "sup_lab_u8"], res[e + "qry_lab_u8"] = np.asarray(sup_lab_pil, np.uint8), qry_lab
+        res[e + "sup_rgb_s5"], res[e + "qry_rgb_s5"] = sup_rgb[:, ::5, ::5].numpy(), qry_rgb[:, ::5, ::5].numpy()
+        res[e + "sup_fg_bits"] = np.packbits((sup_lab // 255).reshape(-1))
+        res[e + "prior_bits"] = np.packbits(prior.numpy().astype(np.uint8).reshape(-1))
+        for tag, logits, resp in (("s1_", logits1, resp1), ("s2_", logits2, resp2)):
+            pred = logits.argmax(1).numpy().astype(np.uint8)
+            res[e + tag + "loss"] = np.array(float(torch.nn.functional.cross_entropy(logits, gt, ignore_index=255)), np.float64)
+            res[e + tag + "argmax_bits"] = np.packbits(pred.reshape(-1))
+            res[e + tag + "counts"] = _metric_counts(pred[0], qry_lab // 255)
+            res[e + tag + "logits_s3"] = logits[0, :, ::3, ::3].numpy()
+            res[e + tag + "resp_s3"] = resp[0, ::3, ::3].numpy().astype(np.uint8)
+        print("real episode", name, cn, "out", out_shape, "stage-1 loss", float(res[e + "s1_loss"]), "stage-2 loss", float(res[e + "s2_loss"]),
+              "fg share", float(gt.float().mean()), "stage-2 fg IoU",
+              float(res[e + "s2_counts"][1, 0] / max(res[e + "s2_counts"][1].sum(), 1)))
+    np.savez_compressed(OUT / "real_episodes.npz", **res)
+    print("wrote real_episodes")
+
+
 def gen_index_facts():
     """G8: index-map facts of the stock ops."""
     import torch.nn.functional as F
@@ -591,6 +659,10 @@ def main():
             if s1 is None:
                 s1 = gen_stage1(tmp, "resnet50", "stage1_rn50", {})
             gen_stage2(tmp, s1, {"full5": ([5678], 5, 401, [synth.QUERY_SIZES[5678 % 5]])})
+        if only in ("", "real"):               # the two real PASCAL episodes the reference ships (stage 1 -> prior -> stage 2)
+            if s1 is None:
+                s1 = gen_stage1(tmp, "resnet50", "stage1_rn50", {})
+            gen_real_episodes(tmp, s1)
         if only in ("", "trainbase"):
             gen_train_step_baseline(tmp)
         if only in ("", "trainvgg"):

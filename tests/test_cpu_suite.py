@@ -815,3 +815,48 @@ def test_oracle_dropout2d_reproduces_torch_given_its_noise():
         assert ref_cpu._dropout2d(x, "l") is x
     finally:
         ref_cpu.TRAIN, ref_cpu.DROPOUT2D = old
+
+
+def _real_episode_host_tensors(g, e):
+    """The reference's evaluation transform (data_kits/pascal_voc.py:200-229) on the fixture's decoded uint8 arrays, by the
+    integer oracle of the Pillow operations (oracle/pil_ops.py)."""
+    from oracle import pil_ops as P
+    from pemp_amd.data_kits.episode import MEAN, STD
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    sup = t(P.to_tensor_normalize(P.resize_bilinear(g[f"e{e}_sup_img_u8"], 401, 401), MEAN, STD))
+    qry = t(P.to_tensor_normalize(P.resize_bilinear(g[f"e{e}_qry_img_u8"], 401, 401), MEAN, STD))
+    msk = t(P.support_mask_planes(P.resize_nearest(g[f"e{e}_sup_lab_u8"], 401, 401)))
+    gt = t((g[f"e{e}_qry_lab_u8"] // 255).astype(np.int64))[None]
+    return sup[None, None], msk[None, None], qry[None, None], gt
+
+
+def test_oracle_on_the_real_episodes_the_reference_ships():
+    """Real PASCAL pictures at last: the two episodes the reference ships with its viewer (decoded by Pillow in the generator),
+    through the oracle's preprocessing, stage 1, arg-max prior and stage 2 -- bit-equal to what the reference's own classes
+    produced from the same files (tests/golden/make_golden.py --only real)."""
+    from oracle import ref_cpu
+    g = util.gold("real_episodes")
+    sd1 = util.wgen_state_dict("stage1_rn50")
+    sd2 = util.wgen_state_dict("stage2_rn50cm", seed=4321)
+    assert list(g["dirs"]) == ["000_01", "001_03"] and int(g["e0_cls"]) == 1 and int(g["e1_cls"]) == 3
+    for e in range(2):
+        sup, msk, qry, gt = _real_episode_host_tensors(g, e)
+        # the preprocessing itself: the integer oracle == Pillow + ToTensor + Normalize as the generator ran them
+        assert np.array_equal(sup[0, 0, :, ::5, ::5].numpy(), g[f"e{e}_sup_rgb_s5"])
+        assert np.array_equal(qry[0, 0, :, ::5, ::5].numpy(), g[f"e{e}_qry_rgb_s5"])
+        assert np.array_equal(np.packbits(msk[0, 0, 0].numpy().astype(np.uint8).reshape(-1)), g[f"e{e}_sup_fg_bits"])
+        hw = tuple(gt.shape[-2:])
+        assert hw == ((333, 500), (457, 500))[e] and 0.04 < float(gt.float().mean()) < 0.34
+        with torch.no_grad():
+            l1, r1 = ref_cpu.stage1_forward(sd1, sup, msk, qry, hw, ret_ind=True)
+            prior = ref_cpu.stage1_forward(sd1, sup, msk, qry, (401, 401)).argmax(dim=1, keepdim=True)
+            l2, r2 = ref_cpu.stage2_forward(sd2, sup, msk, qry, prior, hw, ret_ind=True)
+        assert np.array_equal(np.packbits(prior.numpy().astype(np.uint8).reshape(-1)), g[f"e{e}_prior_bits"])
+        for tag, logits, resp in (("s1_", l1, r1), ("s2_", l2, r2)):
+            k = f"e{e}_{tag}"
+            assert np.array_equal(logits[0, :, ::3, ::3].numpy(), g[k + "logits_s3"])
+            assert np.array_equal(resp[0, ::3, ::3].numpy().astype(np.uint8), g[k + "resp_s3"])
+            am = logits.argmax(1).numpy().astype(np.uint8)
+            assert np.array_equal(np.packbits(am.reshape(-1)), g[k + "argmax_bits"])
+            assert np.array_equal(util.counts(am[0], gt[0].numpy()), g[k + "counts"])
+            assert abs(float(ref_cpu.ce_loss(logits, gt)) - float(g[k + "loss"])) <= 1e-6

@@ -186,3 +186,64 @@ def test_stage2_evaluator_pipeline_with_graphs(hip_lib, dev):
     g = util.gold("stage2_rn50cm_small")
     ref_bits = np.unpackbits(g["e0_argmax_bits"])[: p_e.size].reshape(p_e.shape)
     assert (p_e == ref_bits).mean() > 0.995 and abs(l_e - float(g["e0_loss"])) < 5e-4
+
+
+def test_real_pascal_episodes_stage1_prior_stage2(hip_lib, dev):
+    """The two REAL PASCAL episodes the reference ships with its viewer (http/static/1005_pascal_1shot_pemp_stage2_s0: real
+    textures, real object outlines, fg shares 33 % and 5 %), from decoded uint8 pixels to the stage-2 prediction entirely on
+    the device: pemp_episode_preprocess (Pillow-exact resize / normalise / label planes) -> stage 1 -> arg-max prior -> stage 2,
+    against what the reference's own classes produced from the same files (tests/golden/real_episodes.npz).  Logits within
+    LOGIT_TOL, arg-max and response index exact outside the decision margin (margin shares printed), tp/fp/fn counts within the
+    pixels inside the margin, CE loss within 2e-4; and the production evaluator (device-side prior, hipGraph replay) gives the
+    same prediction."""
+    from pemp_amd.data_kits.episode import EpisodeTransform, test_samples
+    from pemp_amd.entry import pemp_stage2 as e2
+    from pemp_amd.networks import pemp_stage1 as m1, pemp_stage2 as m2
+    g = util.gold("real_episodes")
+    s1 = m1.ModelClass(None)
+    s1.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    s2 = m2.PEMPStage2(1, 1, None)
+    s2.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+    s1, s2 = s1.to(dev).eval(), s2.to(dev).eval()
+    tf = EpisodeTransform(401, 401, device=dev)
+    ev = e2.Evaluator(s1, s2, dev)
+    for e in range(2):
+        sup = [(g[f"e{e}_sup_img_u8"], g[f"e{e}_sup_lab_u8"])]
+        qry = [(g[f"e{e}_qry_img_u8"], g[f"e{e}_qry_lab_u8"])]
+        img, planes, labels = tf(test_samples(sup, qry, 401, 401))
+        gt = labels[0][None]
+        hw = tuple(gt.shape[-2:])
+        # the device-side preprocessing against the reference's tensors (Pillow + ToTensor + Normalize in the generator)
+        assert torch.equal(img[0, :, ::5, ::5].cpu(), torch.from_numpy(g[f"e{e}_sup_rgb_s5"]))
+        assert torch.equal(img[1, :, ::5, ::5].cpu(), torch.from_numpy(g[f"e{e}_qry_rgb_s5"]))
+        assert np.array_equal(np.packbits(planes[0, 0].cpu().numpy().astype(np.uint8).reshape(-1)), g[f"e{e}_sup_fg_bits"])
+        ins = (img[:1][None], planes[None], img[1:][None])
+        with torch.no_grad():
+            l1, r1 = s1(*ins, hw, ret_ind=True)
+            p_logits = s1(*ins)
+            prior = p_logits.argmax(dim=1, keepdim=True)
+            ref_prior = np.unpackbits(g[f"e{e}_prior_bits"])[: 401 * 401].reshape(1, 401, 401)
+            share_p = util.assert_argmax_exact(p_logits, ref_prior, what=f"real episode {e}: prior")
+            # stage 2 is compared on the REFERENCE's prior (its own input), then run end to end on ours
+            rp = torch.from_numpy(ref_prior.astype(np.int64))[:, None].to(dev)
+            l2, r2 = s2(*ins, rp, hw, ret_ind=True)
+            l2_own, _ = s2(*ins, prior, hw, ret_ind=True)
+        for tag, logits in (("s1_", l1), ("s2_", l2)):
+            k = f"e{e}_{tag}"
+            lc = logits.cpu()
+            lerr = (lc[0, :, ::3, ::3] - torch.from_numpy(g[k + "logits_s3"])).abs().max().item()
+            assert lerr < util.LOGIT_TOL, (k, lerr)
+            n = hw[0] * hw[1]
+            ref_am = np.unpackbits(g[k + "argmax_bits"])[:n].reshape(1, *hw)
+            share = util.assert_argmax_exact(lc, ref_am, what=k)
+            cnt = util.counts(lc.argmax(1)[0].numpy(), gt[0].cpu().numpy())
+            assert np.abs(cnt - g[k + "counts"]).max() <= share * n + 1e-9, (cnt, g[k + "counts"])
+            loss = torch.nn.functional.cross_entropy(lc, gt.cpu(), ignore_index=255).item()
+            assert abs(loss - float(g[k + "loss"])) < 2e-4
+            print(f"real episode {e} {tag}: |dlogit| {lerr:.2e}, arg-max pixels inside the margin {share:.5f}, "
+                  f"max count delta {int(np.abs(cnt - g[k + 'counts']).max())} of {n}, prior margin share {share_p:.5f}")
+        # end to end on our own prior: the two priors differ only inside the margin, so the stage-2 logits stay close
+        assert (l2_own - l2).abs().max().item() < 0.05 or share_p > 0
+        pred_ev, loss_ev = ev.test_step(ins, gt[None])
+        agree = (pred_ev[0] == l2_own.argmax(1)[0].cpu().numpy()).mean()
+        assert agree > 0.9995 and abs(loss_ev - torch.nn.functional.cross_entropy(l2_own.cpu(), gt.cpu()).item()) < 2e-4

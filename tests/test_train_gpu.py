@@ -143,8 +143,8 @@ def test_two_steps_reduce_loss_and_dropblock_runs(hip_lib, dev):
 def test_training_fits_a_fixed_batch(hip_lib, dev, rate, steps, loss_bound):
     """The step as a whole does what a training step is for: repeated on one batch of four episodes (Wgen weights, SGD lr 2e-3,
     momentum 0.9, clip 1.1) the loss falls from 0.58 to 0.025 in 120 steps and the evaluation of those episodes reaches a
-    foreground IoU of 0.98 (measured; bounds 0.06 / 0.9).  With DropBlock drawing (rate 0.1) the loss of the last ten of 150
-    steps stays under 0.6 x the first (measured 0.18 .. 0.21 against 0.64)."""
+    foreground IoU of 0.98 (measured; bounds 0.06 / 0.9).  With DropBlock drawing (rate 0.1) the median loss of the last twenty of
+    150 steps stays under 0.5 x the first (measured 0.17 .. 0.24 against 0.64; single steps spike up to 0.40)."""
     from pemp_amd import ops, synth
     from pemp_amd.networks import pemp_stage1 as m
     from pemp_amd.train_engine import Stage1Trainer
@@ -156,7 +156,9 @@ def test_training_fits_a_fixed_batch(hip_lib, dev, rate, steps, loss_bound):
     losses = [tr.train_step(sup, msk, qry, gt).item() for _ in range(steps)]
     assert all(np.isfinite(losses))
     if loss_bound is None:
-        assert max(losses[-10:]) < 0.6 * losses[0], (losses[0], losses[-10:])
+        # the trajectory is chaotic in its details (DropBlock draws, timing-based kernel picks change the rounding): single
+        # steps spike (seen: 0.17 .. 0.40 among the last ten), the level does not
+        assert float(np.median(losses[-20:])) < 0.5 * losses[0], (losses[0], losses[-20:])
         return
     assert losses[-1] < loss_bound, losses[::10]
     net.eval()
