@@ -159,6 +159,8 @@ def _group_max(t, dim, tag):
 def _bn(x, sd, p):
     """nn.BatchNorm2d (networks/backbones.py:48-52,90,111,328): eval -> running statistics;
     train (core/base_trainer.py:189) -> batch statistics, running stats updated in place."""
+    if TRAIN and (p + ".num_batches_tracked") in sd:
+        sd[p + ".num_batches_tracked"].add_(1)             # the module's own counter (nn.BatchNorm2d.forward in train mode)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
                         sd[p + ".weight"], sd[p + ".bias"], TRAIN, 0.1 if TRAIN else 0.0, BN_EPS)
 
@@ -555,13 +557,14 @@ def celoss_dt(logits, target, sigma=5.0):
 # one training step under autograd (the training cpu_baseline of bench.py; tests/golden/make_f64.py does the same in fp64)
 # ------------------------------------------------------------------------------------------
 def train_step(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", qry_prior=None, lr=1e-3, weight_decay=5e-4,
-               max_norm=1.1, dropblock=None):
+               max_norm=1.1, dropblock=None, momentum=0.0, buffers=None):
     """Trainer.train_step (entry/pemp_stage1.py:57-65; stage 2: entry/pemp_stage2.py:72-83): forward with the model in
     train() mode (batch-statistics BatchNorm; Dropout2d as identity; DropBlock as identity unless ``dropblock`` =
     DropBlock(...) gives its draws), CrossEntropyLoss(ignore 255),
-    backward by autograd, clip_grad_norm_(1.1) (stage 1 only, entry/pemp_stage1.py:63), one SGD step (momentum buffers empty:
-    first step, core/solver.py:87-91).  ``sd`` is updated in place (weights and BN running statistics).
-    Returns (loss, {name: gradient})."""
+    backward by autograd, clip_grad_norm_(1.1) (stage 1 only, entry/pemp_stage1.py:63), one SGD step (core/solver.py:87-91;
+    torch.optim.SGD's update: d = grad + wd * p; buf = d on a parameter's first step, momentum * buf + d afterwards; p -= lr *
+    buf).  ``buffers`` ({}, kept by the caller across steps) holds the momentum buffers; without it every call is a first
+    step.  ``sd`` is updated in place (weights and BN running statistics).  Returns (loss, {name: gradient})."""
     global TRAIN, DROPBLOCK
     frozen = lambda k: ("running" in k or "num_batches" in k or k.endswith("backbone.bn1.weight") or k.endswith("backbone.bn1.bias")
                         or ".downsample.1." in k)                      # freeze_bn: stem + downsample BN affines (backbones.py:93-95,113-117)
@@ -582,14 +585,18 @@ def train_step(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", qry_prio
     with torch.no_grad():
         live = [g for g in grads.values() if g is not None]
         if model == "stage1" and max_norm > 0:
-            total = torch.sqrt(sum((g.double() ** 2).sum() for g in live)).float()
+            # clip_grad_norm_'s own arithmetic (torch/nn/utils/clip_grad.py): float32 norm of the per-tensor float32 norms
+            total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g, 2.0) for g in live]), 2.0)
             coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
             for g in live:
                 g.mul_(coef)
         for k, g in grads.items():
             if g is not None:
                 sd[k].requires_grad_(False)
-                sd[k].add_(g + weight_decay * sd[k], alpha=-lr)
+                d = g.add(sd[k], alpha=weight_decay)                     # torch.optim.SGD's operations, in its order
+                if buffers is not None and momentum != 0.0:
+                    d = buffers[k].mul_(momentum).add_(d) if k in buffers else buffers.setdefault(k, d.clone())
+                sd[k].add_(d, alpha=-lr)
     for v in sd.values():
         if v.is_floating_point():
             v.requires_grad_(False)

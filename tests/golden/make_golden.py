@@ -303,6 +303,50 @@ def gen_train_step(tmp, seeds=(31, 32), H=97, out="stage1_rn50_trainstep"):
     print("wrote train step", out, "; loss", float(loss))
 
 
+TRAJ_STEPS = 5
+
+
+def traj_seeds(step):
+    return (31 + 2 * step, 32 + 2 * step)
+
+
+def gen_train_trajectory(tmp):
+    """G25: FIVE consecutive training steps of the reference (entry/pemp_stage1.py:57-65 repeated by core/base_trainer.py:194-200):
+    the imported PEMPStage1 in train() mode (DropBlock off), torch.optim.SGD as core/solver.py:87-91 builds it (lr 1e-3,
+    momentum 0.9, weight decay 5e-4), clip_grad_norm_(1.1), a different batch of two 97 x 97 episodes per step.  Stored: the
+    loss of every step, the gradient norm before clipping, and the weights / BatchNorm buffers after the last step."""
+    from networks import pemp_stage1 as m
+    cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3, drop_rate=0.0, block_size=4)
+    model = _build(m, "PEMPStage1", cfg, (), tmp)
+    _load_wgen(model)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), 1e-3, momentum=0.9, weight_decay=5e-4, nesterov=False)
+    losses, norms = [], []
+    for step in range(TRAJ_STEPS):
+        b = synth.make_batch(list(traj_seeds(step)), shot=1, height=97, width=97, out_hw=(97, 97))
+        opt.zero_grad()
+        logits = model(_t(b["sup_img"]), _t(b["sup_mask"]), _t(b["qry_img"]), (97, 97))
+        loss = torch.nn.functional.cross_entropy(logits, _t(b["qry_mask"][:, 0]), ignore_index=255)
+        loss.backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.1)))
+        opt.step()
+        losses.append(float(loss.detach()))
+    res = {"losses": np.array(losses, np.float64), "grad_norms": np.array(norms, np.float64), "steps": np.array(TRAJ_STEPS)}
+    sd = model.state_dict()
+    names = []
+    for k, v in sd.items():
+        if not v.is_floating_point():
+            res["buf__" + k] = v.numpy()
+            continue
+        names.append(k)
+        a = v.detach().reshape(-1)
+        res["w__" + k] = (a if a.numel() <= 4096 else a[::max(1, a.numel() // 2048)]).numpy()
+        res["norm__" + k] = np.array(float(v.detach().double().norm()), np.float64)
+    res["names"] = np.array(names)
+    np.savez_compressed(OUT / "stage1_rn50_trajectory.npz", **res)
+    print("wrote stage1_rn50_trajectory; losses", losses, "grad norms", norms)
+
+
 def gen_train_step_5shot(tmp):
     """G16: 5-shot training steps (mean over shots in the MPM / the PANet alignment branch's expansion over S):
     stage-1 ResNet-50 and PANet VGG-16, B = 2 episodes x (5 + 1) images, 97x97."""
@@ -647,6 +691,8 @@ def main():
             gen_stage2(tmp, s1, {"small": ([3], 1, 97, [(80, 120)]), "small5": ([5], 5, 97, [(64, 90)])})
         if only in ("", "train"):
             gen_train_step(tmp)
+        if only in ("", "traj"):
+            gen_train_trajectory(tmp)
         if only in ("", "trainfull"):
             gen_train_step(tmp, **TRAIN_FULL)
         if only in ("", "train2full"):

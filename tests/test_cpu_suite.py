@@ -860,3 +860,29 @@ def test_oracle_on_the_real_episodes_the_reference_ships():
             assert np.array_equal(np.packbits(am.reshape(-1)), g[k + "argmax_bits"])
             assert np.array_equal(util.counts(am[0], gt[0].numpy()), g[k + "counts"])
             assert abs(float(ref_cpu.ce_loss(logits, gt)) - float(g[k + "loss"])) <= 1e-6
+
+
+def test_oracle_training_trajectory_matches_the_reference():
+    """Five consecutive steps (entry/pemp_stage1.py:57-65 under core/base_trainer.py:194-200): oracle.train_step with its
+    momentum buffers carried across steps against the reference model stepped by torch.optim.SGD(lr 1e-3, momentum 0.9, wd 5e-4)
+    + clip_grad_norm_(1.1) (tests/golden/make_golden.py --only traj): every loss within 2e-6, every weight tensor after the
+    last step within 1e-6 relative, BatchNorm running statistics and counters included."""
+    from oracle import ref_cpu
+    from pemp_amd import synth
+    g = util.gold("stage1_rn50_trajectory")
+    sd = util.wgen_state_dict("stage1_rn50")
+    buffers = {}
+    t = lambda a: torch.from_numpy(a)
+    for step in range(int(g["steps"])):
+        b = synth.make_batch([31 + 2 * step, 32 + 2 * step], shot=1, height=97, width=97, out_hw=(97, 97))
+        loss, _ = ref_cpu.train_step(sd, t(b["sup_img"]), t(b["sup_mask"]), t(b["qry_img"]), t(b["qry_mask"][:, 0]), model="stage1",
+                                     lr=1e-3, weight_decay=5e-4, max_norm=1.1, momentum=0.9, buffers=buffers)
+        assert abs(loss - float(g["losses"][step])) <= 2e-6, (step, loss, float(g["losses"][step]))
+    worst = 0.0
+    for k in g["names"]:
+        a = sd[str(k)].detach().reshape(-1)
+        got = (a if a.numel() <= 4096 else a[::max(1, a.numel() // 2048)]).numpy()
+        ref = g["w__" + str(k)]
+        worst = max(worst, float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)))
+    assert worst <= 1e-6, worst
+    assert int(sd["encoder.backbone.bn1.num_batches_tracked"]) == int(g["buf__encoder.backbone.bn1.num_batches_tracked"]) == 5

@@ -323,3 +323,25 @@ def test_baseline_gradients_with_frozen_decisions(hip_lib, dev, backbone, tag):
     batch = _batch(dev)
     hip_loss, hip, dec = _run(tr, net, batch, "baseline", backbone, tail=False)
     _compare(tag, hip_loss, hip, sd, batch, dec, "baseline", backbone)
+
+
+def test_stage1_encoder_gradients_under_a_linear_probe_at_the_training_shape(hip_lib, dev):
+    """The same frozen-decision probe at BASELINE.json configs[2]'s per-rank shape -- FOUR episodes of 401 x 401 (8 images,
+    20 808 feature rows: the 128 x 128 / split-K conv variants, the split-M weight gradients with their second pass, the
+    statistics epilogues over 163 row tiles) -- instead of 2 x 97 x 97: every ReLU sign and the max-pool winners of the HIP
+    pass are replayed by the oracle in float64 and in float32 on the host (about a minute of CPU work), the same
+    max(1e-5, 3 x cpu32) rule per parameter tensor, cap 5e-5."""
+    from pemp_amd.networks import pemp_stage1 as m
+    from pemp_amd.train_engine import Stage1Trainer
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    sd = util.wgen_state_dict("stage1_rn50")
+    net = m.ModelClass(None)
+    net.load_state_dict(sd)
+    tr = Stage1Trainer(net, device=dev, drop_rate=0.0)
+    batch = _batch(dev, seeds=(1234, 1235, 1236, 1237), H=401)
+    hip_loss, hip, dec, R = _run(tr, net, batch, "stage1", "resnet50", tail=True, probe=True)
+    del tr
+    torch.cuda.empty_cache()
+    rows = _compare("stage1_rn50 encoder, probe, 4 x 401 x 401", hip_loss, hip, sd, batch, dec, "stage1", "resnet50",
+                    probe=R, loss_rtol=None)
+    assert rows[0][0] <= 5e-5

@@ -528,3 +528,38 @@ def test_full_size_graph_chain_equals_the_eager_step(hip_lib, dev):
             assert len(cap.main) >= 10 and sum(g is not None for g in cap.side) >= 10
         out.append((torch.stack(losses).cpu(), tr.eng.flat.data.clone().cpu()))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_five_step_trajectory_matches_the_reference(hip_lib, dev):
+    """FIVE consecutive training steps (the loop of core/base_trainer.py:194-200 around entry/pemp_stage1.py:57-65): fused
+    clip + momentum SGD on the flat buffers, BatchNorm running statistics, a different batch every step -- against the
+    reference model stepped by torch.optim.SGD(lr 1e-3, momentum 0.9, weight decay 5e-4) + clip_grad_norm_(1.1) on the CPU
+    (tests/golden/stage1_rn50_trajectory.npz; the oracle reproduces it to 2e-6 / 1e-6, test_cpu_suite.py).  Every step's loss
+    within 1e-4, the gradient norm before clipping within 1e-3 relative, every weight tensor after the last step within
+    WEIGHT_TOL of its reference in relative L-inf over the sampled entries, running statistics within 1e-4, counters equal."""
+    WEIGHT_TOL = 2e-5
+    g = util.gold("stage1_rn50_trajectory")
+    tr, net = _trainer(dev, lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.1)
+    dl, dn = 0.0, 0.0
+    for step in range(int(g["steps"])):
+        sup, msk, qry, gt = _batch(dev, seeds=(31 + 2 * step, 32 + 2 * step))
+        loss = tr.train_step(sup, msk, qry, gt).item()
+        dl = max(dl, abs(loss - float(g["losses"][step])))
+        dn = max(dn, abs(float(tr.last_grad_norm) - float(g["grad_norms"][step])) / float(g["grad_norms"][step]))
+    sd = net.state_dict()
+    worst, worst_run, where = 0.0, 0.0, ""
+    for k in g["names"]:
+        k = str(k)
+        a = sd[k].detach().cpu().contiguous().reshape(-1)
+        got = (a if a.numel() <= 4096 else a[::max(1, a.numel() // 2048)]).numpy()
+        ref = g["w__" + k]
+        err = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+        if "running" in k:
+            worst_run = max(worst_run, err)
+        elif err > worst:
+            worst, where = err, k
+    print(f"5-step trajectory: max |d loss| {dl:.2e}, max rel d grad-norm {dn:.2e}, weights rel L-inf {worst:.2e} ({where}), "
+          f"running statistics {worst_run:.2e}")
+    assert dl <= 1e-4 and dn <= 1e-3, (dl, dn)
+    assert worst <= WEIGHT_TOL and worst_run <= 1e-4, (worst, where, worst_run)
+    assert int(sd["encoder.backbone.bn1.num_batches_tracked"]) == 5
