@@ -1,7 +1,9 @@
 """What-if costing of the training step (timing only, numerics deliberately wrong): how much of the step goes away if
   A  the BatchNorm apply passes of bn1 / bn2 (single-consumer outputs) did not exist (their consumers read z),
   B  DropBlock's pixel_scale passes did not exist (drop_rate 0),
-  C  both.
+  C  both,
+  D  no weight-gradient launch at all: the main chain (forward, input gradients, BatchNorm, head, optimizer) alone,
+  E  the weight gradients on the main stream: the fully serialised step.
 Usage: python3 scratch/whatif_train.py [steps]"""
 import os
 import sys
@@ -30,9 +32,15 @@ def no_apply(self, x, conv, bn, relu, residual=None, img_bias=None):
     return z, dict(x=x, z=z, y=z, mean=mean, invstd=invstd, relu=relu, mask=mask)
 
 
-def run(tag, patch, drop):
+orig_enq = te._enqueue_wgrad
+
+
+def run(tag, patch, drop, wgrad="side"):
     te.Stage1TrainEngine._cbn_fwd = no_apply if patch else orig
+    te._enqueue_wgrad = (lambda *a, **k: None) if wgrad == "none" else orig_enq
     tr = bench.make_trainer("stage1", 1, dev, 0)
+    if wgrad == "serial":
+        tr.eng.flat.side_stream = tr.eng.buckets.side = None
     if drop is not None:
         tr.eng.drop_rate = drop
     pool = bench.train_pool(dev, 0, 1, 4)
@@ -46,4 +54,6 @@ run("baseline", False, None)
 run("A no bn1/bn2 apply", True, None)
 run("B no dropblock", False, 0.0)
 run("C both", True, 0.0)
+run("D no weight gradients at all (main chain alone)", False, None, wgrad="none")
+run("E weight gradients on the main stream (serialised)", False, None, wgrad="serial")
 run("baseline again", False, None)
