@@ -19,84 +19,132 @@ namespace pemp {
 constexpr int EDT_INF = 32767;        // "no boundary pixel in this column": larger than any real distance (H, W <= 16384), and
                                       // EDT_INF^2 + dx^2 still fits 32 bits
 constexpr int COLS = 64;              // columns per block of the column pass (halved for very tall label images)
+// exp(-d / sigma^2) + 1 rounds to 1.0f once exp(..) < 2^-24, i.e. beyond d = 16.64 sigma^2: the weight of a squared distance
+// k is looked up in a table of (16.64 sigma^2 + 1)^2 entries built per call (in double, like the reference), 1.0f beyond it
+constexpr int TABLE_MAX = 1 << 20;
 
-__global__ void boundary_kernel(const int64_t* __restrict__ target, uint8_t* __restrict__ bd, int H, int W) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * W) return;
-    const int y = i / W, x = i - y * W;
+// boundary = round((clamp(s,0,1) - mask) + (mask - clamp(s-8,0,1))) != 0 with s the zero-padded 3x3 box sum of mask.  One
+// block per 254-pixel piece of a row: every thread adds its column's three rows (3 loads instead of 9), neighbours meet in LDS.
+__global__ __launch_bounds__(256) void boundary_kernel(const int64_t* __restrict__ target, uint8_t* __restrict__ bd, int H, int W) {
+    __shared__ int cs[256];
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * 254 - 1 + (int)threadIdx.x;
     const int64_t* t = target + (size_t)b * H * W;
-    int s = 0;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = y + dy, xx = x + dx;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += t[yy * W + xx] == 1;
-        }
-    const int m = t[i] == 1;
-    const int dil = min(s, 1) - m;              // dilated - mask
-    const int ero = m - max(min(s - 8, 1), 0);  // mask - eroded
-    bd[(size_t)b * H * W + i] = (uint8_t)((dil + ero) != 0);
+    int m = 0, sum = 0;
+    if (x >= 0 && x < W) {
+        m = t[(size_t)y * W + x] == 1;
+        sum = m;
+        if (y > 0) sum += t[(size_t)(y - 1) * W + x] == 1;
+        if (y + 1 < H) sum += t[(size_t)(y + 1) * W + x] == 1;
+    }
+    cs[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == 255 || x >= W) return;
+    const int s9 = cs[threadIdx.x - 1] + sum + cs[threadIdx.x + 1];
+    const int dil = min(s9, 1) - m;             // dilated - mask
+    const int ero = m - max(min(s9 - 8, 1), 0); // mask - eroded
+    bd[((size_t)b * H + y) * W + x] = (uint8_t)((dil + ero) != 0);
 }
 
 // Vertical distance to the nearest boundary pixel in the same column (EDT_INF if the column has none).  One block per strip
-// of COLS columns: the strip's boundary bytes are staged in LDS (coalesced 64-byte row segments), then every thread sweeps ITS
-// column down and up out of LDS -- the two sweeps are chains of dependent min / add, but their loads do not depend on the
-// chain, so they pipeline; straight from global memory (the first version) every one of the 2 H steps waited out a full
-// memory latency: 216 us for 25 label images of 375 x 500, this form ~10.
-__global__ __launch_bounds__(COLS) void edt_col_kernel(const uint8_t* __restrict__ bd, uint16_t* __restrict__ g, int H, int W) {
+// of ``cols`` columns: the strip's boundary bytes are staged in LDS by all 256 threads, then the first ``cols`` threads sweep
+// their column down and up out of LDS, 16 rows at a time (16 independent LDS reads, the dependent min / add chain in
+// registers, 16 writes).  Straight from global memory (the first version) every one of the 2 H steps waited out a full memory
+// latency: 216 us for 25 label images of 375 x 500.
+__global__ __launch_bounds__(256) void edt_col_kernel(const uint8_t* __restrict__ bd, uint16_t* __restrict__ g, int H, int W,
+                                                      int cols) {
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];         // [H][cols] boundary bytes | [H][cols] uint16 distances
-    const int cols = blockDim.x;
-    uint16_t* down = (uint16_t*)(tile + (size_t)((H * cols + 15) & ~15));
-    const int b = blockIdx.y, x0 = blockIdx.x * cols, c = threadIdx.x;
+    uint16_t* __restrict__ down = (uint16_t*)(tile + (size_t)((H * cols + 15) & ~15));
+    const int b = blockIdx.y, x0 = blockIdx.x * cols;
     const uint8_t* bp = bd + (size_t)b * H * W;
     const int nc = min(cols, W - x0);
-#pragma unroll 8
-    for (int y = 0; y < H; ++y) tile[y * cols + c] = c < nc ? bp[(size_t)y * W + x0 + c] : 0;
+    for (int i = threadIdx.x; i < H * cols; i += 256) {
+        const int y = i / cols, c = i - y * cols;
+        tile[i] = c < nc ? bp[(size_t)y * W + x0 + c] : 0;
+    }
     __syncthreads();
+    const int c = threadIdx.x;
+    if (c >= cols) return;
     int d = EDT_INF;
-#pragma unroll 8
-    for (int y = 0; y < H; ++y) {
-        d = tile[y * cols + c] ? 0 : min(d + 1, EDT_INF);
-        down[y * cols + c] = (uint16_t)d;
+    for (int y0 = 0; y0 < H; y0 += 16) {
+        uint8_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = tile[min(y0 + k, H - 1) * cols + c];
+        uint16_t o[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            d = v[k] ? 0 : min(d + 1, EDT_INF);
+            o[k] = (uint16_t)d;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (y0 + k < H) down[(y0 + k) * cols + c] = o[k];
     }
     uint16_t* gp = g + (size_t)b * H * W;
     d = EDT_INF;
-#pragma unroll 8
-    for (int y = H - 1; y >= 0; --y) {
-        d = tile[y * cols + c] ? 0 : min(d + 1, EDT_INF);
-        if (c < nc) gp[(size_t)y * W + x0 + c] = (uint16_t)min(d, (int)down[y * cols + c]);
+    for (int y0 = H - 1; y0 >= 0; y0 -= 16) {
+        uint8_t v[16];
+        uint16_t dn[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int y = max(y0 - k, 0);
+            v[k] = tile[y * cols + c];
+            dn[k] = down[y * cols + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (y0 - k < 0) break;
+            d = v[k] ? 0 : min(d + 1, EDT_INF);
+            if (c < nc) gp[(size_t)(y0 - k) * W + x0 + c] = (uint16_t)min(d, (int)dn[k]);
+        }
     }
 }
 
-// D^2(y, x) = min_j ( g(y, j)^2 + (x - j)^2 ), exactly, in 32-bit integers.  The candidates are visited outwards from x
-// (j = x, x -+ 1, x -+ 2, ...) and the scan stops as soon as (x - j)^2 alone reaches the best value so far: a pixel at
-// distance d from the boundary looks at ~2 d columns instead of all W (the first version: all W, in 64-bit arithmetic).
-__global__ __launch_bounds__(256) void edt_row_kernel(const uint16_t* __restrict__ g, float* __restrict__ weight, int H,
-                                                      int W, double inv_sigma2) {
+// weight of every squared distance below the cut-off: (float)(exp(-sqrt(k) / sigma^2) + 1), evaluated in double
+__global__ void edt_table_kernel(float* __restrict__ table, int n, double inv_sigma2) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) table[k] = (float)(exp(-sqrt((double)k) * inv_sigma2) + 1.0);
+}
+
+// D^2(y, x) = min_j ( g(y, j)^2 + (x - j)^2 ), exactly, in 32-bit integers.  The candidates are visited outwards from x,
+// eight on either side per round (16 independent LDS reads), and the scan stops as soon as (x - j)^2 alone reaches the best
+// value so far: a pixel at distance d from the boundary looks at ~2 d columns instead of all W (the first version: all W, in
+// 64-bit arithmetic, and a double-precision exp + sqrt per pixel where a table lookup by the integer D^2 does).
+__global__ __launch_bounds__(256) void edt_row_kernel(const uint16_t* __restrict__ g, const float* __restrict__ table, int ntable,
+                                                      float* __restrict__ weight, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) uint8_t rowmem[];
-    uint32_t* g2 = (uint32_t*)rowmem;                                       // g(y, j)^2
+    uint32_t* g2 = (uint32_t*)rowmem;                                       // [8 | W | 8]: g(y, j)^2, "no candidate" beyond the row
+    constexpr uint32_t NONE = (uint32_t)EDT_INF * EDT_INF, FAR = 0xC0000000u;
     const int b = blockIdx.y, y = blockIdx.x;
     const uint16_t* gp = g + ((size_t)b * H + y) * W;
-    for (int j = threadIdx.x; j < W; j += 256) {
-        const uint32_t v = gp[j];
-        g2[j] = v * v;
+    for (int j = threadIdx.x; j < W + 16; j += 256) {
+        const int jj = j - 8;
+        const uint32_t v = (jj >= 0 && jj < W) ? gp[jj] : 0;
+        g2[j] = (jj >= 0 && jj < W) ? v * v : FAR;
     }
     __syncthreads();
-    constexpr uint32_t NONE = (uint32_t)EDT_INF * EDT_INF;
     for (int x = threadIdx.x; x < W; x += 256) {
-        uint32_t best = g2[x];
+        const uint32_t* c = g2 + 8 + x;
+        uint32_t best = c[0];
         const int reach = max(x, W - 1 - x);
-        for (int d = 1; d <= reach; ++d) {
-            const uint32_t d2 = (uint32_t)d * d;
-            if (d2 >= best) break;                     // every remaining candidate is at least d^2 away in x alone
-            const int jl = x - d, jr = x + d;
-            if (jl >= 0) best = min(best, g2[jl] + d2);
-            if (jr < W) best = min(best, g2[jr] + d2);
+        for (int d0 = 1; d0 <= reach; d0 += 8) {
+            if ((uint32_t)d0 * d0 >= best) break;      // every remaining candidate is at least d0^2 away in x alone
+            uint32_t l[8], r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {              // (x - d) >= -8 - ... is kept inside [0, W + 16) by the clamps
+                const int d = d0 + k;
+                l[k] = c[max(-d, -8 - x)];
+                r[k] = c[min(d, W + 7 - x)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t d2 = (uint32_t)(d0 + k) * (d0 + k);
+                best = min(best, min(l[k], r[k]) + d2);   // FAR + d2 < 2^32 (d <= 16384): never the minimum of a row with a candidate
+            }
         }
-        double dist;
-        if (best >= NONE) dist = sqrt((double)(y + 1) * (y + 1) + (double)x * x);   // no boundary at all
-        else dist = sqrt((double)best);
-        weight[((size_t)b * H + y) * W + x] = (float)(exp(-dist * inv_sigma2) + 1.0);
+        uint32_t key = best;
+        if (best >= NONE) key = (uint32_t)(y + 1) * (y + 1) + (uint32_t)x * x;       // no boundary at all: scipy's sqrt((y+1)^2 + x^2)
+        weight[((size_t)b * H + y) * W + x] = key < (uint32_t)ntable ? table[key] : 1.0f;
     }
 }
 
@@ -104,19 +152,31 @@ __global__ __launch_bounds__(256) void edt_row_kernel(const uint16_t* __restrict
 
 using namespace pemp;
 
+static int edt_table_len(float sigma) {
+    const double cut = 16.64 * (double)sigma * (double)sigma + 2.0;       // exp(-d / sigma^2) < 2^-24 beyond: the weight is 1.0f
+    const double n = cut * cut;
+    return n > (double)TABLE_MAX ? TABLE_MAX : (int)n;
+}
+
 extern "C" size_t pemp_cedt_workspace_bytes(int B, int H, int W) {
-    return (size_t)B * H * W * (sizeof(uint16_t) + 1) + 64;
+    return (size_t)B * H * W * (sizeof(uint16_t) + 1) + 64 + (size_t)TABLE_MAX * sizeof(float);
 }
 
 extern "C" int pemp_cedt_weight_f32(const int64_t* target, float* weight, void* ws, size_t ws_bytes, int B, int H, int W,
                                     float sigma, void* stream) {
     PEMP_REQUIRE(target && weight && ws && B > 0 && H > 0 && W > 0 && sigma > 0.f, "cedt_weight: bad arguments");
     PEMP_REQUIRE(ws_bytes >= pemp_cedt_workspace_bytes(B, H, W), "cedt_weight: workspace too small");
-    PEMP_REQUIRE(H <= 16384 && W <= 16384, "cedt_weight: label image too large (H, W <= 16384)");
+    PEMP_REQUIRE(H <= 16384 && W <= 16384 && B <= 65535, "cedt_weight: label images too large (H, W <= 16384, B <= 65535)");
+    const double inv_sigma2 = 1.0 / ((double)sigma * (double)sigma);
+    const int ntable = edt_table_len(sigma);
+    // a table that ends before the cut-off would turn real weights into 1.0f: sigma must stay below ~7.8 (the reference uses 5)
+    PEMP_REQUIRE(ntable < TABLE_MAX || 16.64 * sigma * sigma + 2.0 <= 1024.0, "cedt_weight: sigma too large for the weight table");
     hipStream_t st = (hipStream_t)stream;
-    uint16_t* g = (uint16_t*)ws;
+    float* table = (float*)ws;
+    uint16_t* g = (uint16_t*)(table + TABLE_MAX);
     uint8_t* bd = (uint8_t*)(g + (size_t)B * H * W);
-    hipLaunchKernelGGL(boundary_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, st, target, bd, H, W);
+    hipLaunchKernelGGL(edt_table_kernel, dim3(cdiv(ntable, 256)), dim3(256), 0, st, table, ntable, inv_sigma2);
+    hipLaunchKernelGGL(boundary_kernel, dim3(cdiv(W, 254), H, B), dim3(256), 0, st, target, bd, H, W);
     // column pass: H x cols boundary bytes + H x cols uint16 distances in LDS; 64 columns per block up to H = 800 (154 KB of
     // the CU's 160 KB), fewer for taller label images
     int cols = COLS;
@@ -130,8 +190,8 @@ extern "C" int pemp_cedt_weight_f32(const int64_t* target, float* weight, void* 
             return (int)e;
         }
     }
-    hipLaunchKernelGGL(edt_col_kernel, dim3(cdiv(W, cols), B), dim3(cols), col_lds, st, (const uint8_t*)bd, g, H, W);
-    hipLaunchKernelGGL(edt_row_kernel, dim3(H, B), dim3(256), W * sizeof(uint32_t), st, (const uint16_t*)g, weight, H, W,
-                       1.0 / ((double)sigma * (double)sigma));
+    hipLaunchKernelGGL(edt_col_kernel, dim3(cdiv(W, cols), B), dim3(256), col_lds, st, (const uint8_t*)bd, g, H, W, cols);
+    hipLaunchKernelGGL(edt_row_kernel, dim3(H, B), dim3(256), (W + 16) * sizeof(uint32_t), st, (const uint16_t*)g,
+                       (const float*)table, ntable, weight, H, W);
     return launch_status("cedt_weight");
 }
