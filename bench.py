@@ -1091,12 +1091,17 @@ def side_train(dev, model="stage1", shot=1, batch=4, steps=10, warmup=4, keep=No
     eff = r.get("step_effective_tflops", 0.0)
     if keep is not None:
         keep.update(trainer=tr, pool=pool, step_ms=step_ms)
+    r = attach_train_pmc(r, argparse.Namespace(model=model, batch=batch, shot=shot))
     return {"workload": "pemp_%s train_step, ResNet-50, %d-shot, 401x401, %d episodes/step (see --mode train)" % (model, shot, batch),
             "episodes_per_step": batch, "steps": steps, "warmup": warmup, "ms_per_step": round(step_ms, 3),
             "episodes_per_s": round(steps * batch / dt, 2), "host_enqueue_ms_per_step": round(host_ms, 2),
             "gflop_per_step": r["gflop_per_step"], "step_effective_tflops": eff,
             "frac": round(eff / PEAK_F32_MFMA_TFLOPS, 4), "kernel_frac": r["frac"],
             "kernel_ms_by_class": {k: v["ms_per_step"] for k, v in r["by_class"].items()},
+            "roofline": {"bound": "mfma", "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+                         "traffic": r.get("traffic"), "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                         "launches_per_step": r["launches_per_step"], "avg_launch_us": r["avg_launch_us"],
+                         "pmc_source": r.get("pmc_source")},
             "last_loss": round(float(ls[-1]), 5),
             "note": "frac = conv + weight-gradient flops of a step / timed step / fp32 MFMA peak; kernel_frac = the same flops / "
                     "the summed durations of those kernels in a single-stream pass"}

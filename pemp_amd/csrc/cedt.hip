@@ -47,29 +47,50 @@ __global__ __launch_bounds__(256) void boundary_kernel(const int64_t* __restrict
 }
 
 // Vertical distance to the nearest boundary pixel in the same column (EDT_INF if the column has none).  One block per strip
-// of ``cols`` columns: the strip's boundary bytes are staged in LDS by all 256 threads, then the first ``cols`` threads sweep
-// their column down and up out of LDS, 16 rows at a time (16 independent LDS reads, the dependent min / add chain in
-// registers, 16 writes).  Straight from global memory (the first version) every one of the 2 H steps waited out a full memory
-// latency: 216 us for 25 label images of 375 x 500.
+// of ``cols`` columns (a power of two <= 64): the strip's boundary bytes are staged in LDS by all 256 threads; the strip is
+// then cut into 256 / cols row SEGMENTS, one thread per (segment, column): a first look at the segment finds its first and
+// last boundary row, the distances carried INTO a segment from above and below follow from the other segments' answers, and
+// every thread sweeps its piece down and up out of LDS, 16 rows at a time (independent LDS reads, the dependent min / add
+// chain in registers).  Straight from global memory, one thread per whole column (the first version), every one of the 2 H
+// steps waited out a full memory latency: 216 us for 25 label images of 375 x 500.
 __global__ __launch_bounds__(256) void edt_col_kernel(const uint8_t* __restrict__ bd, uint16_t* __restrict__ g, int H, int W,
                                                       int cols) {
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];         // [H][cols] boundary bytes | [H][cols] uint16 distances
+    __shared__ int first_b[256], last_b[256];                              // [segment][column]
     uint16_t* __restrict__ down = (uint16_t*)(tile + (size_t)((H * cols + 15) & ~15));
     const int b = blockIdx.y, x0 = blockIdx.x * cols;
     const uint8_t* bp = bd + (size_t)b * H * W;
     const int nc = min(cols, W - x0);
-    for (int i = threadIdx.x; i < H * cols; i += 256) {
-        const int y = i / cols, c = i - y * cols;
-        tile[i] = c < nc ? bp[(size_t)y * W + x0 + c] : 0;
+    const int c = threadIdx.x & (cols - 1), seg = threadIdx.x / cols, nseg = 256 / cols;
+    {
+#pragma unroll 16
+        for (int y = seg; y < H; y += nseg) tile[y * cols + c] = c < nc ? bp[(size_t)y * W + x0 + c] : 0;
     }
     __syncthreads();
-    const int c = threadIdx.x;
-    if (c >= cols) return;
-    int d = EDT_INF;
-    for (int y0 = 0; y0 < H; y0 += 16) {
+    const int hs = (H + nseg - 1) / nseg, ya = min(seg * hs, H), yb = min(ya + hs, H);      // this thread's rows [ya, yb)
+    int fb = H, lb = -1;
+    for (int y0 = ya; y0 < yb; y0 += 16) {
         uint8_t v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = tile[min(y0 + k, H - 1) * cols + c];
+        for (int k = 0; k < 16; ++k) v[k] = tile[min(y0 + k, yb - 1) * cols + c];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (v[k] && y0 + k < yb) {
+                fb = min(fb, y0 + k);
+                lb = y0 + k;
+            }
+    }
+    first_b[threadIdx.x] = fb;
+    last_b[threadIdx.x] = lb;
+    __syncthreads();
+    int above = -1, below = H;                     // nearest boundary row in the segments above / below
+    for (int s2 = 0; s2 < seg; ++s2) above = max(above, last_b[s2 * cols + c]);
+    for (int s2 = nseg - 1; s2 > seg; --s2) below = min(below, first_b[s2 * cols + c]);
+    int d = above >= 0 ? min(ya - 1 - above, EDT_INF) : EDT_INF;       // the distance at row ya - 1
+    for (int y0 = ya; y0 < yb; y0 += 16) {
+        uint8_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = tile[min(y0 + k, yb - 1) * cols + c];
         uint16_t o[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -78,22 +99,22 @@ __global__ __launch_bounds__(256) void edt_col_kernel(const uint8_t* __restrict_
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            if (y0 + k < H) down[(y0 + k) * cols + c] = o[k];
+            if (y0 + k < yb) down[(y0 + k) * cols + c] = o[k];
     }
     uint16_t* gp = g + (size_t)b * H * W;
-    d = EDT_INF;
-    for (int y0 = H - 1; y0 >= 0; y0 -= 16) {
+    d = below < H ? min(below - yb, EDT_INF) : EDT_INF;                 // the distance at row yb
+    for (int y0 = yb - 1; y0 >= ya; y0 -= 16) {
         uint8_t v[16];
         uint16_t dn[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int y = max(y0 - k, 0);
+            const int y = max(y0 - k, ya);
             v[k] = tile[y * cols + c];
             dn[k] = down[y * cols + c];
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            if (y0 - k < 0) break;
+            if (y0 - k < ya) break;
             d = v[k] ? 0 : min(d + 1, EDT_INF);
             if (c < nc) gp[(size_t)(y0 - k) * W + x0 + c] = (uint16_t)min(d, (int)dn[k]);
         }
@@ -107,40 +128,51 @@ __global__ void edt_table_kernel(float* __restrict__ table, int n, double inv_si
 }
 
 // D^2(y, x) = min_j ( g(y, j)^2 + (x - j)^2 ), exactly, in 32-bit integers.  The candidates are visited outwards from x,
-// eight on either side per round (16 independent LDS reads), and the scan stops as soon as (x - j)^2 alone reaches the best
-// value so far: a pixel at distance d from the boundary looks at ~2 d columns instead of all W (the first version: all W, in
-// 64-bit arithmetic, and a double-precision exp + sqrt per pixel where a table lookup by the integer D^2 does).
+// eight on either side per round (16 independent LDS reads at immediate offsets from two pointers), and the scan stops as
+// soon as (x - j)^2 alone reaches the best value so far: a pixel at distance d from the boundary looks at ~2 d columns instead
+// of all W (the first version: all W, in 64-bit arithmetic, and a double-precision exp + sqrt per pixel where a table lookup
+// by the integer D^2 does).  The row sits in LDS between two margins of ``pad`` "no candidate" entries, so that no index needs
+// a clamp: pad = W + 8 (WIDE rows, W > 4096: pad = 8 and clamped indices).
+template <bool WIDE>
 __global__ __launch_bounds__(256) void edt_row_kernel(const uint16_t* __restrict__ g, const float* __restrict__ table, int ntable,
-                                                      float* __restrict__ weight, int H, int W) {
+                                                      float* __restrict__ weight, int H, int W, int pad) {
     extern __shared__ __attribute__((aligned(16))) uint8_t rowmem[];
-    uint32_t* g2 = (uint32_t*)rowmem;                                       // [8 | W | 8]: g(y, j)^2, "no candidate" beyond the row
+    uint32_t* g2 = (uint32_t*)rowmem;                                       // [pad | W | pad]: g(y, j)^2
     constexpr uint32_t NONE = (uint32_t)EDT_INF * EDT_INF, FAR = 0xC0000000u;
     const int b = blockIdx.y, y = blockIdx.x;
     const uint16_t* gp = g + ((size_t)b * H + y) * W;
-    for (int j = threadIdx.x; j < W + 16; j += 256) {
-        const int jj = j - 8;
+    for (int j = threadIdx.x; j < W + 2 * pad; j += 256) {
+        const int jj = j - pad;
         const uint32_t v = (jj >= 0 && jj < W) ? gp[jj] : 0;
         g2[j] = (jj >= 0 && jj < W) ? v * v : FAR;
     }
     __syncthreads();
     for (int x = threadIdx.x; x < W; x += 256) {
-        const uint32_t* c = g2 + 8 + x;
+        const uint32_t* c = g2 + pad + x;
         uint32_t best = c[0];
         const int reach = max(x, W - 1 - x);
         for (int d0 = 1; d0 <= reach; d0 += 8) {
-            if ((uint32_t)d0 * d0 >= best) break;      // every remaining candidate is at least d0^2 away in x alone
+            const uint32_t d2 = (uint32_t)d0 * d0, t = 2u * d0;
+            if (d2 >= best) break;                     // every remaining candidate is at least d0^2 away in x alone
             uint32_t l[8], r[8];
+            if constexpr (WIDE) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {              // (x - d) >= -8 - ... is kept inside [0, W + 16) by the clamps
-                const int d = d0 + k;
-                l[k] = c[max(-d, -8 - x)];
-                r[k] = c[min(d, W + 7 - x)];
+                for (int k = 0; k < 8; ++k) {
+                    l[k] = c[max(-(d0 + k), -pad - x)];
+                    r[k] = c[min(d0 + k, W + pad - 1 - x)];
+                }
+            } else {
+                const uint32_t* pl = c - d0;
+                const uint32_t* pr = c + d0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    l[k] = pl[-k];
+                    r[k] = pr[k];
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t d2 = (uint32_t)(d0 + k) * (d0 + k);
-                best = min(best, min(l[k], r[k]) + d2);   // FAR + d2 < 2^32 (d <= 16384): never the minimum of a row with a candidate
-            }
+            for (int k = 0; k < 8; ++k)                 // (d0 + k)^2 = d0^2 + 2 d0 k + k^2;  FAR + d^2 < 2^32: never the minimum
+                best = min(best, min(l[k], r[k]) + (d2 + (uint32_t)k * t + (uint32_t)(k * k)));
         }
         uint32_t key = best;
         if (best >= NONE) key = (uint32_t)(y + 1) * (y + 1) + (uint32_t)x * x;       // no boundary at all: scipy's sqrt((y+1)^2 + x^2)
@@ -191,7 +223,19 @@ extern "C" int pemp_cedt_weight_f32(const int64_t* target, float* weight, void* 
         }
     }
     hipLaunchKernelGGL(edt_col_kernel, dim3(cdiv(W, cols), B), dim3(256), col_lds, st, (const uint8_t*)bd, g, H, W, cols);
-    hipLaunchKernelGGL(edt_row_kernel, dim3(H, B), dim3(256), (W + 16) * sizeof(uint32_t), st, (const uint16_t*)g,
-                       (const float*)table, ntable, weight, H, W);
+    if (W <= 4096) {
+        const int pad = W + 8;
+        hipLaunchKernelGGL(edt_row_kernel<false>, dim3(H, B), dim3(256), (size_t)(W + 2 * pad) * sizeof(uint32_t), st,
+                           (const uint16_t*)g, (const float*)table, ntable, weight, H, W, pad);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void*)edt_row_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((W + 16) * sizeof(uint32_t)));
+        if (e != hipSuccess) {
+            set_error("cedt_weight: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        hipLaunchKernelGGL(edt_row_kernel<true>, dim3(H, B), dim3(256), (size_t)(W + 16) * sizeof(uint32_t), st,
+                           (const uint16_t*)g, (const float*)table, ntable, weight, H, W, 8);
+    }
     return launch_status("cedt_weight");
 }

@@ -43,14 +43,6 @@ def conv_params(conv, bn=None, relu=False, stem4=False, in_slice=None):
                       conv.kernel_size[1], conv.stride[0], conv.padding[0], conv.dilation[0], kpad, stem4, relu)
 
 
-#: Steps of at most this many feature rows (one or two episodes: 5202 rows per 1-shot episode) run their INDEPENDENT convs
-#: side by side -- a stage's downsample conv beside conv1 -> conv2, the four ASPP branches and the global branch beside each
-#: other -- on side streams forked from and joined back into the step's stream (inside a captured hipGraph: parallel
-#: branches).  A 5202-row conv is 41-82 tiles on 256 CUs; four of them together fill the chip without splitting K.  Same
-#: kernels on the same operands: results do not change.  PEMP_EVAL_FORK_ROWS=0 switches it off.
-FORK_MAX_ROWS = int(os.environ.get("PEMP_EVAL_FORK_ROWS", "12000"))
-
-
 class Arena:
     """Named activation buffers reused across calls (static addresses make hipGraph replay valid)."""
 
@@ -58,48 +50,6 @@ class Arena:
         self.device = device
         self.bufs = {}
         self.ws = {}
-        self._sides = []
-
-    def sides(self, k):
-        """``k`` side streams of this engine (created on first use, i.e. during the eager warm-up, never while capturing)."""
-        while len(self._sides) < k:
-            self._sides.append(torch.cuda.Stream(device=self.device))
-        return self._sides[:k]
-
-
-class _Fork:
-    """``with _Fork(arena, k) as f: f.run(i, fn)`` -- fn() is enqueued on side stream i behind everything the current stream
-    holds so far; leaving the block makes the current stream wait for all of them.  Convs issued through ``run`` never use the
-    split-K variants (one uncached workspace per scope: it must not serve two launches that run beside each other; what the
-    current stream itself enqueues inside the block may)."""
-
-    def __init__(self, arena, k):
-        self.streams = arena.sides(k)
-
-    def __enter__(self):
-        self.cur = torch.cuda.current_stream()
-        self.ev = torch.cuda.Event()
-        self.ev.record(self.cur)
-        self.used = set()
-        return self
-
-    def run(self, i, fn):
-        st = self.streams[i]
-        if i not in self.used:
-            st.wait_event(self.ev)
-            self.used.add(i)
-        with torch.cuda.stream(st), ops.eval_splitk(False):
-            return fn()
-
-    def __exit__(self, *exc):
-        for i in self.used:
-            self.cur.wait_stream(self.streams[i])
-        return False
-
-
-def fork_rows(x):
-    n, h, w, _ = x.shape
-    return 0 < n * h * w <= FORK_MAX_ROWS
 
     def get(self, name, shape, dtype=torch.float32, zero=False):
         """``zero``: cleared ONCE, when the buffer is created (for buffers with regions nobody writes afterwards)."""
@@ -144,22 +94,14 @@ class ResNetEngine:
         n, h, w, _ = x.shape
         ho = ops.conv_out_size(h, 1, bp.c1.stride, 0, 1)
         wo = ops.conv_out_size(w, 1, bp.c1.stride, 0, 1)
-        def main():
-            y1 = ops.conv2d(x, bp.c1, out=a.get("y1", (n, ho, wo, bp.c1.cout)),
-                            shift_override=c1_shift, per_image_shift=c1_shift is not None)
-            return ops.conv2d(y1, bp.c2, out=a.get("y2", (n, ho, wo, bp.c2.cout)))
-
-        def shortcut():
-            return ops.conv2d(x, bp.ds, out=a.get("res", (n, ho, wo, bp.ds.cout)),
-                              shift_override=ds_shift, per_image_shift=ds_shift is not None)
-
-        if bp.ds is not None and n * ho * wo <= FORK_MAX_ROWS:      # small step: the downsample conv runs beside conv1 -> conv2
-            with _Fork(a, 1) as f:
-                res = f.run(0, shortcut)
-                y2 = main()
+        y1 = ops.conv2d(x, bp.c1, out=a.get("y1", (n, ho, wo, bp.c1.cout)),
+                        shift_override=c1_shift, per_image_shift=c1_shift is not None)
+        y2 = ops.conv2d(y1, bp.c2, out=a.get("y2", (n, ho, wo, bp.c2.cout)))
+        if bp.ds is not None:
+            res = ops.conv2d(x, bp.ds, out=a.get("res", (n, ho, wo, bp.ds.cout)),
+                             shift_override=ds_shift, per_image_shift=ds_shift is not None)
         else:
-            y2 = main()
-            res = shortcut() if bp.ds is not None else x
+            res = x
         return ops.conv2d(y2, bp.c3, out=a.get(("blk", tag), (n, ho, wo, bp.c3.cout)), residual=res)
 
     def stem_forward(self, x4):
@@ -312,37 +254,22 @@ class ASPPV2Engine:
         a = self.arena
         n, h, w, c = x.shape
         midc = self.midc
+        g = ops.global_avgpool(x, out=a.get("gap", (n, c)))
         cat = a.get("aspp_cat", (n, h, w, 4 * midc))
         if self.folded is not None:
+            g2 = ops.conv2d(g.view(n, 1, 1, c), self.folded[0][0], out=a.get("gap_c", (n, 1, 1, midc)))
+            bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
             if tail is not None and tail.data_ptr() not in self._tails:
                 for i in range(4):
                     tail[i].copy_(self.folded[i + 1][1])
                 self._tails.add(tail.data_ptr())
-
-            def global_branch():
-                g = ops.global_avgpool(x, out=a.get("gap", (n, c)))
-                g2 = ops.conv2d(g.view(n, 1, 1, c), self.folded[0][0], out=a.get("gap_c", (n, 1, 1, midc)))
-                return ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
-
-            def branch(i):
+            for i in range(4):
                 q, padv = self.folded[i + 1]
                 if tail is not None:
                     padv = tail[i]
                 ops.conv2d(x, q, out=cat[..., i * midc:(i + 1) * midc], pad_value=padv if q.kh * q.kw > 1 else None)
-
-            if fork_rows(x):          # small step: the five branches side by side (the three dilated 3x3 convs first)
-                with _Fork(a, 4) as f:
-                    for i in (3, 2, 1):
-                        f.run(i, lambda i=i: branch(i))
-                    bias6 = f.run(0, global_branch)
-                    f.run(0, lambda: branch(0))
-            else:
-                bias6 = global_branch()
-                for i in range(4):
-                    branch(i)
             return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),
                               shift_override=bias6.view(n, -1), per_image_shift=True)
-        g = ops.global_avgpool(x, out=a.get("gap", (n, c)))
         gb = a.get("gap_bn", (n, c))
         ops.channel_affine_multi(g, [self.bn[0][0]], [self.bn[0][1]], [gb])
         g2 = ops.conv2d(gb.view(n, 1, 1, c), self.br[0], out=a.get("gap_c", (n, 1, 1, midc)))
@@ -371,26 +298,12 @@ class ASPPEngine:
         a = self.arena
         n, h, w, c = x.shape
         midc = self.midc
+        g = ops.global_avgpool(x, out=a.get("gap", (n, c)))
+        g2 = ops.conv2d(g.view(n, 1, 1, c), self.br[0], out=a.get("gap_c", (n, 1, 1, midc)))
+        bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
         cat = a.get("aspp_cat", (n, h, w, 4 * midc))
-
-        def global_branch():
-            g = ops.global_avgpool(x, out=a.get("gap", (n, c)))
-            g2 = ops.conv2d(g.view(n, 1, 1, c), self.br[0], out=a.get("gap_c", (n, 1, 1, midc)))
-            return ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
-
-        def branch(i):
+        for i in range(4):
             ops.conv2d(x, self.br[i + 1], out=cat[..., i * midc:(i + 1) * midc])
-
-        if fork_rows(x):              # small step: the five branches side by side (see ASPPV2Engine.forward)
-            with _Fork(a, 4) as f:
-                for i in (3, 2, 1):
-                    f.run(i, lambda i=i: branch(i))
-                bias6 = f.run(0, global_branch)
-                f.run(0, lambda: branch(0))
-        else:
-            bias6 = global_branch()
-            for i in range(4):
-                branch(i)
         return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),
                           shift_override=bias6.view(n, -1), per_image_shift=True)
 

@@ -1,5 +1,5 @@
 """Three rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, MfmaUtil; --kernel-trace only, CSV) of the eval bench ->
-r03_conv_traffic.json / r03_mfma_util.json with the kernel-source digest bench.py checks before quoting them.
+<round>_conv_traffic.json / <round>_mfma_util.json (PEMP_ROUND, default r04) with the kernel-source digest bench.py checks before quoting them.
 python scratch/pmc_summary.py <fetch dir> <write dir> <mfma dir> <out dir> <episodes per step>"""
 import csv, glob, json, os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +19,7 @@ def avg(d, counter):
 
 
 digest = build.conv_digest()
+RND = os.environ.get("PEMP_ROUND", "r04")
 key = f"stage1-eval-b{batch}-s1"
 fk, n = avg(fdir, "FETCH_SIZE")
 wk, _ = avg(wdir, "WRITE_SIZE")
@@ -27,7 +28,7 @@ json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes)
            "conv_digest": digest, "workload_key": key, "episodes_per_step": batch, "conv_launches": n,
            "FETCH_SIZE_KB_avg_per_launch": round(fk, 2), "WRITE_SIZE_KB_avg_per_launch": round(wk, 2),
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
-           "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}, open(os.path.join(out, "r03_conv_traffic.json"), "w"), indent=1)
+           "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}, open(os.path.join(out, RND + "_conv_traffic.json"), "w"), indent=1)
 # MfmaUtil: time-weight by the kernel's duration (same CSV: Start/End timestamps per dispatch)
 by = collections.OrderedDict()
 tot_w = tot = 0.0
@@ -49,5 +50,5 @@ json.dump({"command": "rocprofv3 --pmc MfmaUtil --kernel-trace --output-format c
            "conv_mfma_util_pct_time_weighted": round(tot_w / max(tot, 1e-9), 2),
            "by_kernel": {k: {"launches": a[0], "mfma_util_pct": round(a[1] / max(a[2], 1e-9), 1)} for k, a in by.items()},
            "cosine_mfma_kernel_mfma_util_pct": round(sum(cosine) / max(len(cosine), 1), 1)},
-          open(os.path.join(out, "r03_mfma_util.json"), "w"), indent=1)
-print(open(os.path.join(out, "r03_conv_traffic.json")).read()); print(open(os.path.join(out, "r03_mfma_util.json")).read())
+          open(os.path.join(out, RND + "_mfma_util.json"), "w"), indent=1)
+print(open(os.path.join(out, RND + "_conv_traffic.json")).read()); print(open(os.path.join(out, RND + "_mfma_util.json")).read())

@@ -1,4 +1,4 @@
-"""rocprofv3 --pmc MfmaUtil pass of the training bench -> r03_train_mfma_util.json (per implicit-GEMM kernel, weighted by launch
+"""rocprofv3 --pmc MfmaUtil pass of the training bench -> <round>_train_mfma_util.json (PEMP_ROUND, default r04) (per implicit-GEMM kernel, weighted by launch
 duration).  python scratch/pmc_train_summary.py <mfma dir> <out dir>"""
 import csv, glob, json, os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,5 +28,5 @@ json.dump({"command": "rocprofv3 --pmc MfmaUtil --kernel-trace --output-format c
            "by_class": {c: round(v[0] / max(v[1], 1e-9), 1) for c, v in agg.items()},
            "by_kernel": {k: {"launches": a[0], "mfma_util_pct": round(a[1] / max(a[2], 1e-9), 1), "share_of_gemm_time": round(a[2] / max(t, 1e-9), 3)}
                          for k, a in sorted(by.items(), key=lambda kv: -kv[1][2])}},
-          open(os.path.join(out, "r03_train_mfma_util.json"), "w"), indent=1)
-print(open(os.path.join(out, "r03_train_mfma_util.json")).read()[:1500])
+          open(os.path.join(out, os.environ.get("PEMP_ROUND", "r04") + "_train_mfma_util.json"), "w"), indent=1)
+print(open(os.path.join(out, os.environ.get("PEMP_ROUND", "r04") + "_train_mfma_util.json")).read()[:1500])

@@ -1,4 +1,4 @@
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the training bench -> r03_train_traffic.json: HBM bytes per step, by kernel class
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the training bench -> <round>_train_traffic.json (PEMP_ROUND, default r04): HBM bytes per step, by kernel class
 (the last 5 steps: everything from the first of the last 5 x 155 implicit-GEMM launches on).
 python scratch/pmc_train_traffic.py <fetch dir> <write dir> <out dir>"""
 import csv, glob, json, os, sys, collections
@@ -38,5 +38,9 @@ rec = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --k
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> x2; WRITE_SIZE exact",
        "hbm_MB_per_step": {k: {a: round(b, 1) for a, b in v.items()} for k, v in tot.items()},
        "hbm_GB_per_step_total": round(sum(v["read_MB"] + v["write_MB"] for v in tot.values()) / 1024, 3)}
-json.dump(rec, open(os.path.join(out, "r03_train_traffic.json"), "w"), indent=1)
+# what bench.py quotes as `train.roofline.traffic`: HBM bytes per implicit-GEMM launch (convs, weight gradients and their second pass)
+gemm_mb = sum(tot[k]["read_MB"] + tot[k]["write_MB"] for k in ("conv", "wgrad", "wgrad reduce") if k in tot)
+rec["gemm_launches_per_step"] = PER_STEP
+rec["gemm_hbm_bytes_per_launch"] = int(gemm_mb * 1024 * 1024 / PER_STEP)
+json.dump(rec, open(os.path.join(out, os.environ.get("PEMP_ROUND", "r04") + "_train_traffic.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))
