@@ -73,6 +73,17 @@ int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x, const flo
                               const float* scale, const float* shift, const float* residual,
                               const float* pad_value, void* stream);
 
+/* Up to 4 INDEPENDENT convolutions in ONE launch (arrays of n descriptors / operand pointers; scale, shift, residual,
+ * pad_value: NULL or arrays with NULL entries; pad_value for every member or for none; every descriptor names the same
+ * tile variant 21..27).  Each member is computed exactly as by pemp_conv2d_padv_nhwc_f32 on its own -- same tiles, same K
+ * order, bit-identical -- but the members' tiles share one grid: a one-episode evaluation step (5202 feature rows: 41-82
+ * tiles per conv on 256 CUs) runs the dilated ASPPV2 branches (networks/backbones.py:330-357, all reading the same
+ * activations) and a stage's downsample conv beside its conv1 (backbones.py:47,110) this way.  Members must not write
+ * memory another member reads or writes.                                                                            */
+int pemp_conv2d_group_nhwc_f32(int n, const pemp_conv_desc* d, const float* const* x, const float* const* w,
+                               float* const* y, const float* const* scale, const float* const* shift,
+                               const float* const* residual, const float* const* pad_value, void* stream);
+
 /* [N,3,H,W] image (+ optional [N,1,H,W] prior; NULL -> 0) -> NHWC4 [N,H,W,4].
  * Replaces torch.cat/view at networks/pemp_stage1.py:139, pemp_stage2.py:130-138.          */
 int pemp_pack_input_nhwc4_f32(const float* img, const float* prior, float* out,

@@ -32,6 +32,15 @@ struct ConvArgs {
     int M, HoWo, cin_steps, nk, ntaps;
 };
 
+// up to CONV_GROUP_MAX independent convs of one tile shape in one launch (conv_dma2.hip: conv_dma2_group_kernel)
+constexpr int CONV_GROUP_MAX = 4;
+struct ConvGroupArgs {
+    ConvArgs a[CONV_GROUP_MAX];
+    int first[CONV_GROUP_MAX + 1];   // first block of member i (multiples of 8); first[n] = grid size
+    int nblk[CONV_GROUP_MAX];        // tiles of member i
+    int n;
+};
+
 // XCD-aware tile order.  Hardware deals consecutive block ids round-robin over the 8 XCDs (each
 // with a private 4 MiB L2).  Tiles that share an A row-panel (same M tile, different N tiles) and
 // neighbouring M tiles (3x3 halos) should therefore get ids that are congruent mod 8.  This
@@ -189,6 +198,7 @@ int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st);
 // conv_dma2.hip
 bool conv_dma2_supported(const ConvArgs& a);
 int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st);
+int launch_conv_dma2_group(int tile, ConvGroupArgs& g, hipStream_t st);      // fills g.first / g.nblk
 int conv_dma2_tile_rows(int tile);
 // split-K plan of tile variant `tile` (1..7) for this geometry: number of unsplit tiles, split tiles, pieces per split tile
 // (pieces == 1: the variant runs unsplit) and the workspace the launch needs (counters first, then the partial tiles)

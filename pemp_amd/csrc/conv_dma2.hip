@@ -28,8 +28,10 @@ namespace pemp {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// The block's work: tile ``bid`` of the ``nblk`` blocks of one conv (the plain kernel passes blockIdx.x / gridDim.x; the
+// grouped kernel below the block's index inside its member conv).
 template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false>
-__global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid, const int nblk) {
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the launch stub (buffer-resource builtins / "s" asm operands are device-only)
     constexpr int WGN = NW / WGM;
     constexpr int RPI = NW * 8;                 // rows covered by one DMA instruction round of the block
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
     // block `piece` of them running K steps [kt0, kt0 + nkl)
     int tile_id, kt0 = 0, nkl = a.nk, sk_r = -1, piece = 0;
     if constexpr (SK) {
-        const int b = blockIdx.x;
+        const int b = bid;
         if (b < a.sk_full) {
             tile_id = xcd_tile_order(b, a.sk_full);
         } else {
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
             nkl = (int)((long long)(piece + 1) * a.nk / a.sk_S) - kt0;
         }
     } else {
-        tile_id = xcd_tile_order(blockIdx.x, gridDim.x);
+        tile_id = xcd_tile_order(bid, nblk);
     }
     const int bm = tile_id / ntn;
     const int bn = tile_id % ntn;
@@ -376,6 +378,60 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
         conv_stats_store<BN, WGM, NW, TN>(a, Rall, bm, n0, tid);
     }
 #endif
+}
+
+template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false>
+__global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
+    conv_dma2_body<BM, BN, WGM, NW, PADV, EPI, SK>(a, blockIdx.x, gridDim.x);
+}
+
+// Several INDEPENDENT convs of the same tile shape in ONE launch: member i owns the blocks [first[i], first[i] + nblk[i]) (the
+// first[] are multiples of 8, so that a block's XCD is the same function of its index inside the member as in a launch of its
+// own; the few blocks in between return at once).  A one-episode step has 5202 feature rows -- 41 to 82 tiles per conv on 256
+// CUs -- and convs that do not depend on each other (the dilated ASPP branches; a stage's downsample conv beside its conv1):
+// together they fill the chip without splitting K and without one launch + drain per member.  Same tiles, same K order: every
+// member's result is bit-identical to its own launch.
+template <int BM, int BN, int WGM, int NW, bool PADV>
+__global__ __launch_bounds__(NW * 64) void conv_dma2_group_kernel(ConvGroupArgs g) {
+    int which = 0;
+#pragma unroll
+    for (int i = 1; i < CONV_GROUP_MAX; ++i) which += (i < g.n && (int)blockIdx.x >= g.first[i]) ? 1 : 0;
+    const int bid = (int)blockIdx.x - g.first[which];
+    if (bid >= g.nblk[which]) return;
+    conv_dma2_body<BM, BN, WGM, NW, PADV, 0, false>(g.a[which], bid, g.nblk[which]);
+}
+
+template <int BM, int BN, int WGM, int NW>
+static int launch_dma2_group(ConvGroupArgs& g, bool padv, hipStream_t st) {
+    const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
+    auto kern = padv ? conv_dma2_group_kernel<BM, BN, WGM, NW, true> : conv_dma2_group_kernel<BM, BN, WGM, NW, false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    int grid = 0;
+    for (int i = 0; i < g.n; ++i) {
+        g.first[i] = grid;
+        g.nblk[i] = cdiv(g.a[i].M, BM) * (g.a[i].Cout / BN);
+        grid += (g.nblk[i] + 7) & ~7;
+    }
+    g.first[g.n] = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, g);
+    return launch_status("conv_dma2/group");
+}
+
+int launch_conv_dma2_group(int tile, ConvGroupArgs& g, hipStream_t st) {
+    const bool padv = g.a[0].padv != nullptr;
+    if (tile == 7) return launch_dma2_group<256, 256, 4, 8>(g, padv, st);
+    if (tile == 6) return launch_dma2_group<256, 128, 4, 8>(g, padv, st);
+    if (tile == 4) return launch_dma2_group<128, 128, 4, 8>(g, padv, st);
+    if (tile == 5) return launch_dma2_group<128, 64, 4, 8>(g, padv, st);
+    if (tile == 1) return launch_dma2_group<128, 128, 2, 4>(g, padv, st);
+    if (tile == 2) return launch_dma2_group<128, 64, 2, 4>(g, padv, st);
+    return launch_dma2_group<64, 64, 2, 4>(g, padv, st);
 }
 
 template <int BM, int BN, int WGM, int NW>

@@ -282,10 +282,11 @@ extern "C" int pemp_conv2d_padv_splitk_nhwc_f32(const pemp_conv_desc* d, const f
     return conv2d_impl(d, x, w, y, scale, shift, residual, pad_value, ws, ws_bytes, stream);
 }
 
-static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale, const float* shift,
-                       const float* residual, const float* pad_value, void* ws, size_t ws_bytes, void* stream) {
+// argument checks of one conv + its ConvArgs (``any_taps``: a padding value may accompany a 1x1 conv -- it is never read)
+static int conv_fill(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale, const float* shift,
+                     const float* residual, const float* pad_value, ConvArgs& a, bool any_taps = false) {
     PEMP_REQUIRE(d && x && w && y, "conv2d: null pointer");
-    PEMP_REQUIRE(!pad_value || (!(d->flags & PEMP_CONV_STEM4) && d->KH * d->KW > 1 && ((uintptr_t)pad_value & 15) == 0),
+    PEMP_REQUIRE(!pad_value || (!(d->flags & PEMP_CONV_STEM4) && (any_taps || d->KH * d->KW > 1) && ((uintptr_t)pad_value & 15) == 0),
                  "conv2d: pad_value needs a multi-tap non-stem conv and a 16-byte aligned [Cin] vector");
     PEMP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv2d: bad dims");
     PEMP_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
@@ -311,8 +312,8 @@ static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, 
     const long long out_elems = (long long)d->N * d->Ho * d->Wo * (long long)(d->ldy > d->ldr ? d->ldy : d->ldr);
     PEMP_REQUIRE(in_elems < (1ll << 31) && out_elems < (1ll << 31), "conv2d: tensor too large for 32-bit indexing");
 
-    ConvArgs a;
     a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual; a.padv = pad_value; a.stats = nullptr; a.bz = nullptr;
+    a.bmask = nullptr; a.bmean = nullptr; a.binvstd = nullptr; a.ldbz = 0;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cout = d->Cout; a.ldy = d->ldy; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.dil = d->dil; a.ldr = d->ldr; a.Kpad = d->Kpad; a.flags = d->flags;
@@ -322,7 +323,16 @@ static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, 
     a.cin_steps = stem ? 1 : d->Cin / 32;
     a.nk = d->Kpad / 32;
     if (residual) PEMP_REQUIRE(d->ldr >= d->Cout && d->ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0, "conv2d: ldr must be >= Cout and x4, residual 16-byte aligned");
+    a.sk_ws = nullptr; a.sk_cnt = nullptr; a.sk_full = 0; a.sk_S = 1;
+    return 0;
+}
 
+static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale, const float* shift,
+                       const float* residual, const float* pad_value, void* ws, size_t ws_bytes, void* stream) {
+    ConvArgs a;
+    const int rc = conv_fill(d, x, w, y, scale, shift, residual, pad_value, a);
+    if (rc) return rc;
+    const bool stem = d->flags & PEMP_CONV_STEM4;
     int tile = d->tile;
     if (tile == 0) {
         // Measured on MI355X (scratch/conv_tune.py): at these problem sizes (M <= ~80k rows) the 64x64
@@ -331,7 +341,6 @@ static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, 
         tile = 3;
     }
     hipStream_t st = (hipStream_t)stream;
-    a.sk_ws = nullptr; a.sk_cnt = nullptr; a.sk_full = 0; a.sk_S = 1;
     if (tile >= 31 && tile <= 37) {      // conv_dma2.hip with the last round of tiles split along K (pemp_hip.h)
         PEMP_REQUIRE(tile != 33, "conv2d: no split-K variant of the 64 x 64 tile");
         if (conv_dma2_supported(a)) {
@@ -364,6 +373,33 @@ static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, 
     if (tile == 3) return stem ? launch_conv<64, 64, 2, true>(a, st) : launch_conv<64, 64, 2, false>(a, st);
     set_error("conv2d: unknown tile id %d", tile);
     return -1;
+}
+
+
+extern "C" int pemp_conv2d_group_nhwc_f32(int n, const pemp_conv_desc* d, const float* const* x, const float* const* w,
+                                          float* const* y, const float* const* scale, const float* const* shift,
+                                          const float* const* residual, const float* const* pad_value, void* stream) {
+    PEMP_REQUIRE(n >= 1 && n <= CONV_GROUP_MAX && d && x && w && y, "conv2d_group: 1..%d member convs", CONV_GROUP_MAX);
+    ConvGroupArgs g;
+    g.n = n;
+    const int tile = d[0].tile;
+    PEMP_REQUIRE(tile >= 21 && tile <= 27, "conv2d_group: tile must be one of the buffer-addressed variants 21..27, got %d", tile);
+    const int t = tile - 20;
+    for (int i = 0; i < n; ++i) {
+        PEMP_REQUIRE(d[i].tile == tile, "conv2d_group: every member must name the same tile variant");
+        PEMP_REQUIRE(!pad_value || (pad_value[i] != nullptr) == (pad_value[0] != nullptr), "conv2d_group: pad_value for every member or for none");
+        const int rc = conv_fill(&d[i], x[i], w[i], y[i], scale ? scale[i] : nullptr, shift ? shift[i] : nullptr,
+                                 residual ? residual[i] : nullptr, pad_value ? pad_value[i] : nullptr, g.a[i], true);
+        if (rc) return rc;
+        PEMP_REQUIRE(conv_dma2_supported(g.a[i]), "conv2d_group: member %d lies outside the buffer-addressed kernels (stem / > 32 taps / 2 GiB operands / padding vector not behind the activations)", i);
+        PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || g.a[i].Cout % 128 == 0, "conv2d_group: tile N=128 needs Cout %% 128 == 0");
+        PEMP_REQUIRE(t != 7 || g.a[i].Cout % 256 == 0, "conv2d_group: tile 256x256 needs Cout %% 256 == 0");
+        for (int j = 0; j < i; ++j) {          // members run beside each other: no one may write what another one reads or writes
+            PEMP_REQUIRE(y[i] != y[j], "conv2d_group: members %d and %d write the same output", j, i);
+        }
+    }
+    for (int i = n; i < CONV_GROUP_MAX; ++i) g.a[i] = g.a[0];
+    return launch_conv_dma2_group(t, g, (hipStream_t)stream);
 }
 
 

@@ -43,6 +43,13 @@ def conv_params(conv, bn=None, relu=False, stem4=False, in_slice=None):
                       conv.kernel_size[1], conv.stride[0], conv.padding[0], conv.dilation[0], kpad, stem4, relu)
 
 
+#: Steps of at most this many feature rows (one or two episodes: 5202 rows per 1-shot episode) issue their INDEPENDENT convs
+#: as ONE grouped launch (ops.conv2d_group): the dilated ASPP branches, a stage's downsample conv beside its conv1.  A
+#: 5202-row conv is 41-82 tiles on 256 CUs; grouped, the members fill the chip without splitting K and without a launch +
+#: drain each.  Same tiles, same K order: results do not change.  PEMP_EVAL_GROUP_ROWS=0 switches it off.
+GROUP_MAX_ROWS = int(os.environ.get("PEMP_EVAL_GROUP_ROWS", "12000"))
+
+
 class Arena:
     """Named activation buffers reused across calls (static addresses make hipGraph replay valid)."""
 
@@ -94,6 +101,12 @@ class ResNetEngine:
         n, h, w, _ = x.shape
         ho = ops.conv_out_size(h, 1, bp.c1.stride, 0, 1)
         wo = ops.conv_out_size(w, 1, bp.c1.stride, 0, 1)
+        if bp.ds is not None and c1_shift is None and ds_shift is None and 0 < n * ho * wo <= GROUP_MAX_ROWS:
+            # small step: conv1 and the downsample conv read the same x -- one grouped launch
+            y1, res = ops.conv2d_group([x, x], [bp.c1, bp.ds], [a.get("y1", (n, ho, wo, bp.c1.cout)),
+                                                                a.get("res", (n, ho, wo, bp.ds.cout))])
+            y2 = ops.conv2d(y1, bp.c2, out=a.get("y2", (n, ho, wo, bp.c2.cout)))
+            return ops.conv2d(y2, bp.c3, out=a.get(("blk", tag), (n, ho, wo, bp.c3.cout)), residual=res)
         y1 = ops.conv2d(x, bp.c1, out=a.get("y1", (n, ho, wo, bp.c1.cout)),
                         shift_override=c1_shift, per_image_shift=c1_shift is not None)
         y2 = ops.conv2d(y1, bp.c2, out=a.get("y2", (n, ho, wo, bp.c2.cout)))
@@ -263,11 +276,17 @@ class ASPPV2Engine:
                 for i in range(4):
                     tail[i].copy_(self.folded[i + 1][1])
                 self._tails.add(tail.data_ptr())
-            for i in range(4):
-                q, padv = self.folded[i + 1]
-                if tail is not None:
-                    padv = tail[i]
-                ops.conv2d(x, q, out=cat[..., i * midc:(i + 1) * midc], pad_value=padv if q.kh * q.kw > 1 else None)
+            qs = [self.folded[i + 1][0] for i in range(4)]
+            pvs = [tail[i] if tail is not None else self.folded[i + 1][1] for i in range(4)]
+            outs = [cat[..., i * midc:(i + 1) * midc] for i in range(4)]
+            if tail is not None and 0 < n * h * w <= GROUP_MAX_ROWS:
+                # small step: the four branches read the same x -- one grouped launch, the dilated 3x3 convs first (their
+                # tiles are the long ones; the 1x1 branch's short tiles fill in behind them)
+                order = sorted(range(4), key=lambda i: -qs[i].kh * qs[i].kw)
+                ops.conv2d_group([x] * 4, [qs[i] for i in order], [outs[i] for i in order], pad_values=[pvs[i] for i in order])
+            else:
+                for i in range(4):
+                    ops.conv2d(x, qs[i], out=outs[i], pad_value=pvs[i] if qs[i].kh * qs[i].kw > 1 else None)
             return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),
                               shift_override=bias6.view(n, -1), per_image_shift=True)
         gb = a.get("gap_bn", (n, c))
@@ -302,8 +321,13 @@ class ASPPEngine:
         g2 = ops.conv2d(g.view(n, 1, 1, c), self.br[0], out=a.get("gap_c", (n, 1, 1, midc)))
         bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
         cat = a.get("aspp_cat", (n, h, w, 4 * midc))
-        for i in range(4):
-            ops.conv2d(x, self.br[i + 1], out=cat[..., i * midc:(i + 1) * midc])
+        outs = [cat[..., i * midc:(i + 1) * midc] for i in range(4)]
+        if 0 < n * h * w <= GROUP_MAX_ROWS:          # small step: one grouped launch (see ASPPV2Engine.forward)
+            order = sorted(range(4), key=lambda i: -self.br[i + 1].kh * self.br[i + 1].kw)
+            ops.conv2d_group([x] * 4, [self.br[i + 1] for i in order], [outs[i] for i in order])
+        else:
+            for i in range(4):
+                ops.conv2d(x, self.br[i + 1], out=outs[i])
         return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),
                           shift_override=bias6.view(n, -1), per_image_shift=True)
 

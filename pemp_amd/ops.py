@@ -268,6 +268,63 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
     return out
 
 
+#: tile variants a grouped launch may use (conv_dma2.hip only)
+GROUP_TILES = (23, 22, 25, 21, 24, 26, 27)
+GROUP_MAX = 4
+
+
+def conv2d_group(xs, ps, outs, pad_values=None, residuals=None, tile=0):
+    """Up to four INDEPENDENT convs in one launch (pemp_conv2d_group_nhwc_f32): member i computes ``outs[i] = act(scale *
+    conv(xs[i], ps[i].w) + shift (+ residuals[i]))`` exactly as ``conv2d`` would -- bit-identical -- but the members' tiles share
+    one grid.  ``pad_values``: per member or None (all or none).  The tile variant is timed once per group signature."""
+    lib = _lib.load()
+    n = len(ps)
+    if not 1 <= n <= GROUP_MAX or len(xs) != n or len(outs) != n:
+        raise ValueError(f"conv2d_group: 1..{GROUP_MAX} members with one input and one output each")
+    pad_values = list(pad_values) if pad_values is not None else [None] * n
+    residuals = list(residuals) if residuals is not None else [None] * n
+    descs, keys = [], []
+    for x, p, out, pv, res in zip(xs, ps, outs, pad_values, residuals):
+        _chk_dev(x, p.w, out, pv, res)
+        if p.stem:
+            raise ValueError("conv2d_group: no stem convs")
+        ldx, ldy = _nhwc(x, "x"), _nhwc(out, "out")
+        nb, h, w, cin = x.shape
+        if cin != p.cin:
+            raise ValueError(f"conv2d_group: input has {cin} channels, layer expects {p.cin}")
+        ho, wo = conv_out_size(h, p.kh, p.stride, p.pad, p.dil), conv_out_size(w, p.kw, p.stride, p.pad, p.dil)
+        if tuple(out.shape) != (nb, ho, wo, p.cout):
+            raise ValueError(f"conv2d_group: out shape {tuple(out.shape)} != {(nb, ho, wo, p.cout)}")
+        ldr = 0
+        if res is not None:
+            ldr = _nhwc(res, "residual")
+            if tuple(res.shape) != tuple(out.shape):
+                raise ValueError("conv2d_group: residual shape mismatch")
+        descs.append((nb, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, CONV_RELU if p.relu else 0))
+        keys += [p.cin, p.cout, p.kh, p.stride, p.pad, p.dil, nb, h, w, int(res is not None), int(pv is not None)]
+    arr = lambda ts: (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
+    xa, wa, ya = arr(xs), arr([p.w for p in ps]), arr(outs)
+    sa, ha, ra, pa = arr([p.scale for p in ps]), arr([p.shift for p in ps]), arr(residuals), arr(pad_values)
+    ptr = lambda a: C.cast(a, C.POINTER(C.c_void_p))
+
+    def launch(t):
+        da = (ConvDesc * n)(*[ConvDesc(*d, t) for d in descs])
+        _lib.check(lib.pemp_conv2d_group_nhwc_f32(n, da, ptr(xa), ptr(wa), ptr(ya), ptr(sa), ptr(ha), ptr(ra), ptr(pa), _stream()),
+                   "pemp_conv2d_group_nhwc_f32")
+
+    if tile == 0:
+        key = (-7,) + tuple(keys)               # -7: a grouped launch (the cache file stores keys as integer lists)
+        tile = _TILE_CACHE.get(key)
+        if tile is None:
+            if AUTOTUNE and max(d[0] * d[5] * d[6] for d in descs) >= 1024 and not torch.cuda.is_current_stream_capturing():
+                tile = _pick_tile(launch, None, key, min(p.cout for p in ps),
+                                  only=[t for t in GROUP_TILES if all(p.cout % TILE_VARIANTS[t][1] == 0 for p in ps)])
+            else:
+                tile = DEFAULT_TILE + 10
+    launch(tile)
+    return outs
+
+
 #: split-K variants (ids 31..37 = the shapes of 21..27; pemp_hip.h): NOT bit-identical to the others.  The training convs may pick
 #: them, and so may the evaluation path for SMALL row counts (one or two episodes per step: 5202 rows leave two thirds of the
 #: chip idle on the 3x3 layers otherwise) -- see EVAL_SPLITK

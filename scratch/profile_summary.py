@@ -16,7 +16,7 @@ for r in tail:
     a[0] += 1
     a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 conv_ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in gemm)
-rec = {"source": f"rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py {'--mode train ' if tag == 'train' else ''}--steps 20 --warmup 5 "
+rec = {"source": f"rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py {'--mode train ' if tag == 'train' else '--loss cedt ' if tag == 'evalcedt' else ''}--steps 20 --warmup 5 "
                  "--cpu-episodes 0 --no-e2e --no-single --no-roofline (the kernel trace itself is not committed)",
        "note": f"steady state = everything from the first of the last {steps} x {per_step} implicit-GEMM launches on (the {steps} timed steps)",
        "gemm_launches": len(gemm), "gemm_avg_launch_us": round(conv_ns / len(gemm) / 1e3, 2), "gemm_ms_per_step": round(conv_ns / steps / 1e6, 4),

@@ -365,3 +365,66 @@ def test_cm_statistics_and_their_adjoint(hip_lib, dev, N, C, h, w):
         dx2 = base.clone().to(dev)
         T.cm_bwd_add(xd, got_m, dstat.to(dev), dx2, argmax=arg)
         assert torch.equal(dx2, dx)
+
+
+def test_conv2d_group_equals_the_members_own_launches(hip_lib, dev):
+    """pemp_conv2d_group_nhwc_f32: up to four independent convs in one launch, every member bit-identical to its own launch,
+    for every group tile variant.  (a) the ASPPV2 branches of a small evaluation step: three dilated 3x3 convs with a folded
+    BatchNorm (padding VALUE behind the activations) + the 1x1 branch, all reading the same x and writing slices of one
+    concat buffer; (b) a stage's conv1 (ReLU, folded BN) beside its stride-2 downsample conv (no ReLU, different Cout);
+    (c) a single member; and the argument checks."""
+    from pemp_amd import ops, _lib
+    N, HW, C = 2, 21, 128
+    x = _rand(N, C, HW, HW, seed=11)
+    flat = torch.empty(N * HW * HW + 8, C, device=dev)
+    flat[:N * HW * HW].copy_(_nhwc(x).to(dev).view(-1, C))
+    xin = flat[:N * HW * HW].view(N, HW, HW, C)
+    qs, pvs = [], []
+    for i, (k, dil) in enumerate(((1, 1), (3, 2), (3, 6), (3, 18))):
+        w = _rand(C, C, k, k, seed=20 + i) * (1.0 / (C * k * k) ** 0.5)
+        packed, kpad = ops.pack_conv_weight(w.to(dev))
+        prm = ops.ConvParams(packed, None, _rand(C, seed=30 + i).to(dev), C, C, k, k, 1, dil if k == 3 else 0, dil, kpad, False, True)
+        s = _rand(C, seed=40 + i, lo=0.5, hi=1.5)
+        q, padv = ops.fold_input_affine(prm, s.to(dev), _rand(C, seed=50 + i).to(dev))
+        flat[N * HW * HW + i].copy_(padv)
+        qs.append(q)
+        pvs.append(flat[N * HW * HW + i])
+    ref = [ops.conv2d(xin, q, tile=23, pad_value=pv if q.kh > 1 else None) for q, pv in zip(qs, pvs)]
+    order = [1, 2, 3, 0]
+    for tile in ops.GROUP_TILES:
+        if C % ops.TILE_VARIANTS[tile][1]:
+            continue
+        cat = torch.full((N, HW, HW, 4 * C), -3.0, device=dev)
+        outs = [cat[..., i * C:(i + 1) * C] for i in range(4)]
+        ops.conv2d_group([xin] * 4, [qs[i] for i in order], [outs[i] for i in order], pad_values=[pvs[i] for i in order], tile=tile)
+        for i in range(4):
+            assert torch.equal(outs[i], ref[i]), (tile, i)
+    # (b) conv1 + downsample: different Cout, stride 2, ReLU on one member only, per-channel scale + shift on both
+    Cin = 64
+    xb = _nhwc(_rand(N, Cin, 33, 33, seed=60)).to(dev)
+    mem = []
+    for i, (co, relu) in enumerate(((64, True), (256, False))):
+        w = _rand(co, Cin, 1, 1, seed=61 + i) * 0.1
+        packed, kpad = ops.pack_conv_weight(w.to(dev))
+        mem.append(ops.ConvParams(packed, _rand(co, seed=63 + i, lo=0.5, hi=1.5).to(dev), _rand(co, seed=65 + i).to(dev), Cin, co, 1, 1, 2, 0, 1,
+                                  kpad, False, relu))
+    refb = [ops.conv2d(xb, p, tile=23) for p in mem]
+    for tile in (23, 22, 25):
+        got = ops.conv2d_group([xb, xb], mem, [torch.empty_like(r) for r in refb], tile=tile)
+        assert all(torch.equal(g, r) for g, r in zip(got, refb)), tile
+    assert bool((refb[0] >= 0).all()) and bool((refb[1] < 0).any())
+    # (c) one member; autotuned call (tile = 0) leaves its pick in the cache and repeats bit for bit
+    one = ops.conv2d_group([xb], [mem[1]], [torch.empty_like(refb[1])], tile=23)[0]
+    assert torch.equal(one, refb[1])
+    auto = ops.conv2d_group([xb, xb], mem, [torch.empty_like(r) for r in refb])
+    assert all(torch.equal(g, r) for g, r in zip(auto, refb))
+    # argument checks: five members, a shared output, mixed pad values, a tile the family does not have
+    with pytest.raises(ValueError):
+        ops.conv2d_group([xb] * 5, [mem[0]] * 5, [torch.empty_like(refb[0]) for _ in range(5)])
+    same = torch.empty_like(refb[0])
+    with pytest.raises(_lib.PempHipError, match="same output"):
+        ops.conv2d_group([xb, xb], [mem[0], mem[0]], [same, same], tile=23)
+    with pytest.raises(_lib.PempHipError, match="every member or for none"):
+        ops.conv2d_group([xin, xin], [qs[1], qs[2]], [torch.empty_like(ref[1]), torch.empty_like(ref[2])], pad_values=[pvs[1], None], tile=23)
+    with pytest.raises(_lib.PempHipError, match="21..27"):
+        ops.conv2d_group([xb], [mem[0]], [torch.empty_like(refb[0])], tile=13)
