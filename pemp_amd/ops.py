@@ -273,6 +273,23 @@ GROUP_TILES = (23, 22, 25, 21, 24, 26, 27)
 GROUP_MAX = 4
 
 
+def _group_member_ok(x, p, pad_value):
+    """What conv_dma2_supported (csrc/conv_dma2.hip) checks for one member of a grouped launch."""
+    n, h, w, _ = x.shape
+    ldx = _nhwc(x, "x")
+    taps = p.kh * p.kw
+    tapmax = (p.dil * (p.kh - 1) * w + p.dil * (p.kw - 1)) * ldx * 4
+    xbytes = (n * h * w + p.pad * w + p.pad) * ldx * 4 + tapmax
+    if p.stem or taps > 32 or xbytes >= 2 ** 31 or p.w.numel() * 4 >= 2 ** 31:
+        return False
+    if pad_value is not None:
+        off = pad_value.data_ptr() - x.data_ptr()
+        d = off + (p.pad * w + p.pad) * ldx * 4
+        if off < n * h * w * ldx * 4 or d < tapmax or d + p.cin * 4 >= 2 ** 31:
+            return False
+    return True
+
+
 def conv2d_group(xs, ps, outs, pad_values=None, residuals=None, tile=0):
     """Up to four INDEPENDENT convs in one launch (pemp_conv2d_group_nhwc_f32): member i computes ``outs[i] = act(scale *
     conv(xs[i], ps[i].w) + shift (+ residuals[i]))`` exactly as ``conv2d`` would -- bit-identical -- but the members' tiles share
@@ -302,6 +319,12 @@ def conv2d_group(xs, ps, outs, pad_values=None, residuals=None, tile=0):
                 raise ValueError("conv2d_group: residual shape mismatch")
         descs.append((nb, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, CONV_RELU if p.relu else 0))
         keys += [p.cin, p.cout, p.kh, p.stride, p.pad, p.dil, nb, h, w, int(res is not None), int(pv is not None)]
+    if not all(_group_member_ok(x, p, pv) for x, p, pv in zip(xs, ps, pad_values)):
+        # a member outside the buffer-addressed kernels (tiny maps under a large dilation: the padding vector is not far enough
+        # behind the activations; 2 GiB operands; > 32 taps): every member through its own launch -- same results
+        for x, p, out, pv, res in zip(xs, ps, outs, pad_values, residuals):
+            conv2d(x, p, out=out, residual=res, pad_value=pv if p.kh * p.kw > 1 else None)
+        return outs
     arr = lambda ts: (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
     xa, wa, ya = arr(xs), arr([p.w for p in ps]), arr(outs)
     sa, ha, ra, pa = arr([p.scale for p in ps]), arr([p.shift for p in ps]), arr(residuals), arr(pad_values)
