@@ -60,9 +60,10 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int nblk) {
 // ``pre`` (optional): the residual quads of the wave's tiles, loaded by the caller ahead of time in the order
 // [mi][ni][i] (row = (lane >> 3) + 8 i of tile (mi, ni), channels (lane & 7) * 4 ..) -- conv_dma2.hip issues those loads
 // under its last K step so that their latency is not exposed here.
-// EPI 1: per-channel sums of the stored values and of their squares over the wave's rows, left in R ([TN][2][32] floats of
-// LDS per wave; the kernel adds the waves of a block in a fixed order and writes one partial row per row tile: the batch
-// statistics of the BatchNorm behind the conv; fixed layout, fixed order -> deterministic).
+// EPI 1: per-channel sums of the stored values and of their squares over the wave's rows, left in R ([TN][2][8][32] floats of
+// LDS per wave: one row of 32 channel sums per lane group; the kernel adds the lane groups and the waves of a block in a fixed
+// order and writes one partial row per row tile: the batch statistics of the BatchNorm behind the conv; fixed layout, fixed
+// order -> deterministic).
 // EPI 2: the stored value is g = o masked by the sign bits of the BatchNorm output this gradient belongs to, the sums are
 // those of g and g * xhat (first half of that BatchNorm's backward; the expression of colsum_kernel<1> in train_ops.hip).
 template <int TM, int TN, int NPRE, int EPI = 0>
@@ -146,32 +147,25 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
                     }
                 }
             }
-            if constexpr (EPI != 0) {
-                // lanes that share the channel quad differ in lane bits 3..5 (the row inside the 8-row group): fixed butterfly
-#pragma unroll
-                for (int off = 8; off < 64; off <<= 1) {
-                    s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64);
-                    s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
-                    s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64);
-                    s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
-                }
+            if constexpr (EPI != 0) {       // per lane: its 4 rows of this row group, then the wave's row groups in ascending order
                 t1 += s1;
                 t2 += s2;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the patch is rewritten
         }
         if constexpr (EPI != 0) {
-            if (lane < 8) {
-                *(v4f*)(R + (ni * 2 + 0) * 32 + c4) = t1;
-                *(v4f*)(R + (ni * 2 + 1) * 32 + c4) = t2;
-            }
+            // The 8 lanes that share a channel quad (lane bits 3..5 = the row inside an 8-row group) leave their sums side by side
+            // in LDS; conv_stats_store adds them in a fixed order.  (Round 3 reduced them here with a three-level shuffle butterfly
+            // per 32 x 32 sub-tile: 24 cross-lane operations each, 20 us of a 105 us launch on the 256 -> 1024 layers.)
+            *(v4f*)(R + ((ni * 2 + 0) * 8 + rr) * 32 + c4) = t1;
+            *(v4f*)(R + ((ni * 2 + 1) * 8 + rr) * 32 + c4) = t2;
         }
     }
 }
 
 // Block-level finish of the EPI sums: the waves that cover the same columns (WGM of them, one per row band of the tile) are
 // added in ascending row order and the tile's partial row goes to a.stats[bm].  Rall: the R areas of all waves
-// ([NW][TN][2][32]); call after a block barrier.
+// ([NW][TN][2][8][32]); call after a block barrier.
 template <int BN, int WGM, int NW, int TN>
 __device__ __forceinline__ void conv_stats_store(const ConvArgs& a, const float* Rall, int bm, int n0, int tid) {
     constexpr int WGN = NW / WGM, WN = BN / WGN;
@@ -180,7 +174,9 @@ __device__ __forceinline__ void conv_stats_store(const ConvArgs& a, const float*
         const int wni = col / WN, ni = (col - wni * WN) >> 5, c = col & 31;
         float s = 0.f;
 #pragma unroll
-        for (int wmi = 0; wmi < WGM; ++wmi) s += Rall[(((wmi * WGN + wni) * TN + ni) * 2 + st) * 32 + c];
+        for (int wmi = 0; wmi < WGM; ++wmi)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += Rall[((((wmi * WGN + wni) * TN + ni) * 2 + st) * 8 + g) * 32 + c];
         a.stats[((size_t)bm * 2 + st) * a.Cout + n0 + col] = s;
     }
 }

@@ -366,12 +366,12 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     }
 
     // ---- epilogue: transpose through LDS.  No LDS read and no DMA is outstanding after the loop's last barrier. ----
-    float* Rall = (float*)smem + NW * 1024;          // EPI: [NW][TN][2][32] sums of the waves, behind their transpose patches
-    static_assert(EPI == 0 || NW * 1024 + NW * TN * 64 <= 64 * (BM + BN), "LDS: statistics area");
-    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre, Rall + wave * TN * 64);
+    float* Rall = (float*)smem + NW * 1024;          // EPI: [NW][TN][2][8][32] sums of the waves, behind their transpose patches
+    static_assert(EPI == 0 || NW * 1024 + NW * TN * 512 <= 64 * (BM + BN), "LDS: statistics area");
+    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre, Rall + wave * TN * 512);
     else if constexpr (EPI != 0) {
         const v4f none[1] = {{0.f, 0.f, 0.f, 0.f}};
-        conv_epilogue_lds_pre<TM, TN, 1, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, none, Rall + wave * TN * 64);
+        conv_epilogue_lds_pre<TM, TN, 1, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, none, Rall + wave * TN * 512);
     } else conv_epilogue_lds<TM, TN>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
     if constexpr (EPI != 0) {
         __syncthreads();
