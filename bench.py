@@ -25,6 +25,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                   checked against the sum of the rank shards (``miou`` is printed from the reduced table)
   cedt            (default line) the eval step and the train step with loss=cedt (CELossDT on the device), next to loss=ce
   protocol_5x1000 (default line) the reference's evaluation protocol: 5 rounds x 1000 episodes, one episode per test_step
+  bf16_variant    (default line; SIDE FIGURE, never `value` / `roofline`) the eval step with bf16 operands in the encoder: episodes/s,
+                  and the mIoU / arg-max pixels it moves on one round over the resident episodes
   cpu_baseline    the CPU oracle (oracle/ref_cpu.py, bit-equal to the reference here) timed on the host cores in child
                   processes: 1 thread and all cores of the box's share, bounded samples of the same workload
 """
@@ -847,6 +849,53 @@ def protocol_5x1000(net, pool, dev, args, rounds=5, test_n=1000, lanes=4):
                     "episodes (the mIoU says nothing about PASCAL accuracy)"}
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md, dense bf16 matrix peak (the figure below is priced against it, not the fp32 one)
+
+
+def bf16_variant(run, dev, args, steps=10, warmup=3):
+    """SIDE FIGURE, never `value`, never `roofline`: the same eval step with bf16 OPERANDS in the encoder (bf16 activations and
+    weights between the fp32 stem and the fp32 prototype head, fp32 accumulation on v_mfma_f32_32x32x16_bf16;
+    model.precision("bf16")) -- what the exact-fp32 arithmetic of the product path costs, and what giving it up would move: the
+    mIoU of one round over every resident episode of the run's pool on both precisions, and the arg-max pixels that flip."""
+    from pemp_amd.core.metrics import FewShotMetric
+    from pemp_amd import ops, synth
+    net, pool = run.net, run.pool
+    r = EvalRunner(dev, 0, "stage1", args.shot, args.batch, args.dataset, steps, net=net, pool=pool, precision="bf16")
+    dt, ml, _ = r.timed(steps, warmup, 1, dev)
+    ms = dt / steps * 1e3
+    nclass = 20 if args.dataset == "PASCAL" else 80
+    res, ws = {}, {}
+    for prec in ("f32", "bf16"):
+        m, ams, loss = FewShotMetric(nclass), [], []
+        for ep in pool:
+            with net.precision(prec), torch.no_grad():
+                pred, _ = net.lowres_graphed(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
+                am, st, _ = ops.eval_tail(pred, ep["qry_mask"], ws_cache=ws)
+            st = st.cpu().numpy()
+            m.update_counts(st[:, 2:], ep["cls"].tolist())
+            loss += list(st[:, 0] / st[:, 1])
+            ams.append(am.clone())
+        seen = [c for c in synth.val_labels(0, args.dataset) if m.stat[c].sum() > 0]
+        res[prec] = (float(m.mIoU(seen)[1]), float(m.mIoU(seen, binary=True)[1]), float(np.mean(loss)), ams)
+    flips = sum(int((a != b).sum()) for a, b in zip(res["f32"][3], res["bf16"][3]))
+    pixels = sum(a.numel() for a in res["f32"][3])
+    gflop = 129.87 * args.batch if args.shot == 1 else None
+    out = {"dtype": "bf16 operands / fp32 accumulate (encoder convs between the fp32 stem and the fp32 head)",
+           "what": "side figure only: never `value`, never `roofline` -- what the exact-fp32 MFMA arithmetic of the product path costs",
+           "episodes_per_step": args.batch, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
+           "episodes_per_s": round(args.batch / ms * 1e3, 2),
+           "round_episodes": sum(len(ep["cls"]) for ep in pool),
+           "miou_f32": round(res["f32"][0], 6), "miou_bf16": round(res["bf16"][0], 6), "delta_miou": round(abs(res["f32"][0] - res["bf16"][0]), 6),
+           "biou_f32": round(res["f32"][1], 6), "biou_bf16": round(res["bf16"][1], 6), "delta_biou": round(abs(res["f32"][1] - res["bf16"][1]), 6),
+           "mean_ce_loss_f32": round(res["f32"][2], 6), "mean_ce_loss_bf16": round(res["bf16"][2], 6),
+           "argmax_flips": flips, "pixels": pixels, "argmax_flip_share": round(flips / max(pixels, 1), 6),
+           "dataset": args.dataset}
+    if gflop:
+        out["effective_tflops"] = round(gflop / ms, 1)
+        out["frac_of_bf16_mfma_peak"] = round(gflop / ms / PEAK_BF16_MFMA_TFLOPS, 4)
+    return out
+
+
 def side_cedt_eval(run, dev, args, steps=10, warmup=3):
     """The eval step with loss = cedt (CELossDT: boundary + exact distance transform + weighted CE on the device, all inside the
     timed region; reference entry/pemp_stage1.py:51, core/losses.py:17-43) next to the same step with loss = ce, measured the
@@ -1117,7 +1166,7 @@ class EvalRunner:
     device inside the step and weights the fused tail's cross-entropy."""
 
     def __init__(self, dev, rank, model="stage1", shot=1, batch=25, dataset="PASCAL", steps=40, graph=True, loss="ce", net=None,
-                 pool=None):
+                 pool=None, precision="f32"):
         from pemp_amd import ops
         from pemp_amd.core import losses
         self.graph = graph
@@ -1127,6 +1176,7 @@ class EvalRunner:
         self.stage2 = build_model(dev, "stage2", shot)[0] if model == "stage2" else None
         self.pool = pool if pool is not None else episode_pool(dev, shot, batch, rank, dataset=dataset)
         self.loss = losses.get({"loss": loss, "sigma": 5.0})
+        self.precision = precision          # "bf16": the side-figure variant of the encoder (never the headline)
         self.ws, self.ws_align, self.aux_log = {}, {}, []
         self.stats_log = torch.zeros((steps, batch, 8), dtype=torch.float64, device=dev)
         self.cls_log = torch.stack([self.pool[i % len(self.pool)]["cls"] for i in range(steps)])      # [steps, batch]
@@ -1150,7 +1200,7 @@ class EvalRunner:
         if self.lanes > 1 and graph:
             k = i % self.lanes
             ep = self.pool[i % len(self.pool)]
-            with torch.cuda.stream(self.lane_streams[k]), self.net.lane(k), torch.no_grad():
+            with torch.cuda.stream(self.lane_streams[k]), self.net.lane(k), self.net.precision(self.precision), torch.no_grad():
                 pred, _ = self.net.lowres_graphed(ep["sup_img"], ep["sup_mask"], ep["qry_img"])
                 am, stats, _ = self._tail(pred, ep, self.lane_ws[k])
                 if log:
@@ -1159,7 +1209,7 @@ class EvalRunner:
         ops, net, stage2 = self.ops, self.net, self.stage2
         ep = self.pool[i % len(self.pool)]
         ins = (ep["sup_img"], ep["sup_mask"], ep["qry_img"])
-        with torch.no_grad():
+        with net.precision(self.precision), torch.no_grad():
             pred, _ = net.lowres_graphed(*ins) if graph else net.lowres(*ins)
             if stage2 is not None:
                 prior, _, _ = ops.eval_tail(pred, None, out_hw=ins[0].shape[-2:], ws_cache=self.ws)
@@ -1409,8 +1459,11 @@ def main():
             rows = {"episodes": out["cpu_baseline"].pop("episodes")}
             guarded("miou", lambda: miou_vs_cpu(net, dev, rows))
     # the other BASELINE.json configurations, measured in this process so that they sit under the driver's clock too
+    if headline and args.dataset == "COCO" and args.shot == 1 and not args.no_sides:
+        guarded("bf16_variant", lambda: bf16_variant(run, dev, args))       # the COCO-shaped round's delta mIoU
     if headline and args.dataset == "PASCAL" and args.shot == 1 and not args.no_sides:
         guarded("protocol_5x1000", lambda: protocol_5x1000(net, pool, dev, args))
+        guarded("bf16_variant", lambda: bf16_variant(run, dev, args))
         cedt = {}
         try:
             cedt["eval"] = side_cedt_eval(run, dev, args)

@@ -84,6 +84,16 @@ int pemp_conv2d_group_nhwc_f32(int n, const pemp_conv_desc* d, const float* cons
                                float* const* y, const float* const* scale, const float* const* shift,
                                const float* const* residual, const float* const* pad_value, void* stream);
 
+/* SIDE-FIGURE VARIANT, not the product path's arithmetic: the same convolution with bf16 OPERANDS (x, w, residual, pad_value:
+ * bf16 tensors; descriptor in bf16 elements, Cin % 64 == 0, ldx % 8 == 0) and fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16; y is bf16 (out_f32 == 0; a residual is then bf16 too) or fp32 (the encoder's last layer).  Tiles
+ * 21..27 (0 = 24).  Exists to show what exact fp32 costs (bench.py: `bf16_variant`, with the mIoU it moves); never the default. */
+int pemp_conv2d_bf16_nhwc(const pemp_conv_desc* d, const void* x, const void* w, void* y, const float* scale,
+                          const float* shift, const void* residual, const void* pad_value, int out_f32, void* stream);
+/* element-wise fp32 <-> bf16 (round to nearest even) for the boundaries of that variant (n % 4 == 0) */
+int pemp_convert_f32_bf16(const float* x, void* y, long long n, void* stream);
+int pemp_convert_bf16_f32(const void* x, float* y, long long n, void* stream);
+
 /* [N,3,H,W] image (+ optional [N,1,H,W] prior; NULL -> 0) -> NHWC4 [N,H,W,4].
  * Replaces torch.cat/view at networks/pemp_stage1.py:139, pemp_stage2.py:130-138.          */
 int pemp_pack_input_nhwc4_f32(const float* img, const float* prior, float* out,

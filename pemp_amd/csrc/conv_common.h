@@ -6,6 +6,37 @@ namespace pemp {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float v4f;   // first-class vector: loads/stores never become memcpy
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// internal flag (not part of pemp_hip.h's desc flags): y and the residual are bf16 tensors (strides in bf16 elements)
+#define PEMP_CONV_BF16_IO 0x100u
+
+// four consecutive channels at element offset ``off`` of a tensor that is fp32 or (bf16 != 0) bf16, as fp32
+__device__ __forceinline__ v4f load_quad(const float* base, size_t off, unsigned bf16) {
+    if (!bf16) return *(const v4f*)(base + off);
+    const u32x2 r = *(const u32x2*)((const unsigned short*)base + off);
+    return v4f{__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xFFFF0000u),
+               __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xFFFF0000u)};
+}
+
+// fp32 -> bf16, round to nearest even (NaN stays NaN: the quiet bit is forced)
+__device__ __forceinline__ unsigned int bf16_bits(float f) {
+    const unsigned int u = __builtin_bit_cast(unsigned int, f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ void store_quad(float* base, size_t off, const v4f& o, unsigned bf16) {
+    if (!bf16) {
+        *(v4f*)(base + off) = o;
+        return;
+    }
+    u32x2 r;
+    r.x = bf16_bits(o.x) | (bf16_bits(o.y) << 16);
+    r.y = bf16_bits(o.z) | (bf16_bits(o.w) << 16);
+    *(u32x2*)((unsigned short*)base + off) = r;
+}
 
 struct ConvArgs {
     const float* x;
@@ -116,7 +147,7 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
                     if (per_img) add += *(const v4f*)(a.shift + (size_t)(m / a.HoWo) * a.Cout + n);
                     if (a.res) {
                         if constexpr (PRE) add += pre[(mi * TN + ni) * 4 + i];
-                        else add += *(const v4f*)(a.res + (size_t)m * a.ldr + n);
+                        else add += load_quad(a.res, (size_t)m * a.ldr + n, a.flags & PEMP_CONV_BF16_IO);
                     }
                     v4f o;
                     o.x = __builtin_fmaf(v.x, sc.x, add.x);      // explicit: every epilogue variant must round identically
@@ -136,7 +167,7 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
                         o.z = (b & 4u) ? o.z : 0.f;
                         o.w = (b & 8u) ? o.w : 0.f;
                     }
-                    *(v4f*)(a.y + (size_t)m * a.ldy + n) = o;
+                    store_quad(a.y, (size_t)m * a.ldy + n, o, a.flags & PEMP_CONV_BF16_IO);
                     if constexpr (EPI == 1) {
                         s1 += o;
                         s2 += o * o;
@@ -195,6 +226,7 @@ int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st);
 bool conv_dma2_supported(const ConvArgs& a);
 int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st);
 int launch_conv_dma2_group(int tile, ConvGroupArgs& g, hipStream_t st);      // fills g.first / g.nblk
+int launch_conv_dma2_bf16(int tile, const ConvArgs& a, hipStream_t st);      // bf16 operands (Cin / ldx / Kpad in dwords)
 int conv_dma2_tile_rows(int tile);
 // split-K plan of tile variant `tile` (1..7) for this geometry: number of unsplit tiles, split tiles, pieces per split tile
 // (pieces == 1: the variant runs unsplit) and the workspace the launch needs (counters first, then the partial tiles)

@@ -30,7 +30,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // The block's work: tile ``bid`` of the ``nblk`` blocks of one conv (the plain kernel passes blockIdx.x / gridDim.x; the
 // grouped kernel below the block's index inside its member conv).
-template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false>
+// BF16 (the side-figure variant, pemp_conv2d_bf16_nhwc): the operands are bf16 in memory.  The kernel is the same down to the
+// byte -- a K step is still 128 bytes per row, staged, swizzled and read as 16-byte quads -- because the caller hands over
+// Cin / ldx / Kpad in DWORDS (two bf16 each): a quad then holds 8 bf16 = the 8 K values one lane feeds into
+// v_mfma_f32_32x32x16_bf16 (lanes 0-31: K 0..7, lanes 32-63: K 8..15 = quads 2j and 2j + 1, exactly the pair a fragment read
+// of step j fetches), so one MFMA does the work of the four v_mfma_f32_32x32x2_f32 of the fp32 kernel at 8 cycles instead of
+// 4 x 64.  Accumulation stays fp32; the epilogue writes bf16 (or fp32 for the last layer) -- PEMP_CONV_BF16_IO.
+template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false>
 __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid, const int nblk) {
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the launch stub (buffer-resource builtins / "s" asm operands are device-only)
     constexpr int WGN = NW / WGM;
@@ -38,7 +44,7 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int AL = BM / RPI, BL = BN / RPI; // DMA wave-instructions per thread per K step
-    constexpr int NMF = TM * TN * 4, NDS = TM + TN, NDMA = AL + BL;   // per quarter step: MFMAs, fragment reads; DMAs per step
+    constexpr int NMF = TM * TN * (BF16 ? 1 : 4), NDS = TM + TN, NDMA = AL + BL;   // per quarter step: MFMAs, fragment reads; DMAs per step
     constexpr int PER = (NDS + NDMA + NMF - 1) / NMF;
 
     extern __shared__ __attribute__((aligned(16))) v4f smem[];
@@ -219,6 +225,11 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     do {                                                                                                          \
         _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) {     \
             const v4f av = af[src_][mi], bv = bf[src_][ni];                                                       \
+            if constexpr (BF16) {                                                                                 \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),              \
+                                                                      __builtin_bit_cast(bf16x8, bv), acc[mi][ni], 0, 0, 0); \
+                continue;                                                                                         \
+            }                                                                                                     \
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[mi][ni], 0, 0, 0);                 \
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[mi][ni], 0, 0, 0);                 \
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[mi][ni], 0, 0, 0);                 \
@@ -294,7 +305,7 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int m = m0 + wm0 + mi * 32 + rr_ + 8 * i, n = n0 + wn0 + ni * 32 + c4_;
-                        rpre[(mi * TN + ni) * 4 + i] = m < a.M ? *(const v4f*)(a.res + (size_t)m * a.ldr + n) : v4f{0.f, 0.f, 0.f, 0.f};
+                        rpre[(mi * TN + ni) * 4 + i] = m < a.M ? load_quad(a.res, (size_t)m * a.ldr + n, a.flags & PEMP_CONV_BF16_IO) : v4f{0.f, 0.f, 0.f, 0.f};
                     }
         }
     }
@@ -380,9 +391,9 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
 #endif
 }
 
-template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false>
+template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
-    conv_dma2_body<BM, BN, WGM, NW, PADV, EPI, SK>(a, blockIdx.x, gridDim.x);
+    conv_dma2_body<BM, BN, WGM, NW, PADV, EPI, SK, BF16>(a, blockIdx.x, gridDim.x);
 }
 
 // Several INDEPENDENT convs of the same tile shape in ONE launch: member i owns the blocks [first[i], first[i] + nblk[i]) (the
@@ -449,6 +460,32 @@ static int launch_dma2(const ConvArgs& a, hipStream_t st) {
     const int grid = cdiv(a.M, BM) * (a.Cout / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
     return launch_status("conv_dma2");
+}
+
+template <int BM, int BN, int WGM, int NW>
+static int launch_dma2_bf16(const ConvArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
+    auto kern = a.padv ? conv_dma2_kernel<BM, BN, WGM, NW, true, 0, false, true> : conv_dma2_kernel<BM, BN, WGM, NW, false, 0, false, true>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    const int grid = cdiv(a.M, BM) * (a.Cout / BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    return launch_status("conv_dma2/bf16");
+}
+
+int launch_conv_dma2_bf16(int tile, const ConvArgs& a, hipStream_t st) {
+    if (tile == 7) return launch_dma2_bf16<256, 256, 4, 8>(a, st);
+    if (tile == 6) return launch_dma2_bf16<256, 128, 4, 8>(a, st);
+    if (tile == 4) return launch_dma2_bf16<128, 128, 4, 8>(a, st);
+    if (tile == 5) return launch_dma2_bf16<128, 64, 4, 8>(a, st);
+    if (tile == 1) return launch_dma2_bf16<128, 128, 2, 4>(a, st);
+    if (tile == 2) return launch_dma2_bf16<128, 64, 2, 4>(a, st);
+    return launch_dma2_bf16<64, 64, 2, 4>(a, st);
 }
 
 int conv_dma2_tile_rows(int tile) {        // BM of tile variant 1..7

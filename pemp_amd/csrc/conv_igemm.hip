@@ -403,6 +403,34 @@ extern "C" int pemp_conv2d_group_nhwc_f32(int n, const pemp_conv_desc* d, const 
 }
 
 
+// The side-figure variant: bf16 operands, fp32 accumulation (conv_dma2.hip, BF16).  The descriptor is in ELEMENTS like every
+// other; the kernel is handed Cin / ldx / Kpad in dwords (two bf16 each), which is all it needs to address bf16 rows.
+extern "C" int pemp_conv2d_bf16_nhwc(const pemp_conv_desc* d, const void* x, const void* w, void* y, const float* scale,
+                                     const float* shift, const void* residual, const void* pad_value, int out_f32, void* stream) {
+    PEMP_REQUIRE(d && x && w && y, "conv2d_bf16: null pointer");
+    PEMP_REQUIRE(!(d->flags & (PEMP_CONV_STEM4 | PEMP_CONV_BF16_IO)), "conv2d_bf16: no stem variant; unknown flags");
+    PEMP_REQUIRE(d->Cin % 64 == 0 && d->ldx % 8 == 0 && d->ldx >= d->Cin && d->Kpad == d->KH * d->KW * d->Cin,
+                 "conv2d_bf16: Cin must be a multiple of 64, ldx of 8 (bf16 elements), Kpad = KH*KW*Cin");
+    PEMP_REQUIRE(!residual || !out_f32, "conv2d_bf16: a residual comes with a bf16 output");
+    PEMP_REQUIRE(d->tile == 0 || (d->tile >= 21 && d->tile <= 27), "conv2d_bf16: tile must be 0 or 21..27");
+    pemp_conv_desc h = *d;
+    h.Cin = d->Cin / 2;
+    h.ldx = d->ldx / 2;
+    h.Kpad = d->Kpad / 2;
+    ConvArgs a;
+    // (the fp32 checks apply to the halved descriptor: Cin % 32, ldx % 4, 16-byte aligned operands; y / residual strides % 4)
+    const int rc = conv_fill(&h, (const float*)x, (const float*)w, (float*)y, scale, shift, (const float*)residual,
+                             (const float*)pad_value, a);
+    if (rc) return rc;
+    if (!out_f32) a.flags |= PEMP_CONV_BF16_IO;
+    PEMP_REQUIRE(conv_dma2_supported(a), "conv2d_bf16: geometry / operand size outside the buffer-addressed kernels");
+    const int t = d->tile == 0 ? 4 : d->tile - 20;
+    PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || a.Cout % 128 == 0, "conv2d_bf16: tile N=128 needs Cout %% 128 == 0");
+    PEMP_REQUIRE(t != 7 || a.Cout % 256 == 0, "conv2d_bf16: tile 256x256 needs Cout %% 256 == 0");
+    return launch_conv_dma2_bf16(t, a, (hipStream_t)stream);
+}
+
+
 static int conv_stats_fill(const char* what, const pemp_conv_desc* d, ConvArgs& a) {
     PEMP_REQUIRE(!(d->flags & (PEMP_CONV_STEM4 | PEMP_CONV_RELU | PEMP_CONV_SHIFT_PER_IMAGE)), "%s: plain conv only (no stem / ReLU / per-image shift)", what);
     PEMP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0,

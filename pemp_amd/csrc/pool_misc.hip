@@ -638,3 +638,51 @@ extern "C" int pemp_cm_bwd_add_f32(const float* x, int ldx, const float* mask, c
                            ldd, HW, C);
     return launch_status("cm_bwd_add");
 }
+
+
+// fp32 <-> bf16 copies for the bf16 side-figure variant of the eval engine (the stem and the head stay fp32)
+namespace pemp {
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long n4) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = *(const float4*)(x + 4 * i);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        unsigned int b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned int u = __builtin_bit_cast(unsigned int, f[k]);
+            b[k] = (u & 0x7FFFFFFFu) > 0x7F800000u ? ((u >> 16) | 0x40u) : ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        }
+        uint2 r;
+        r.x = b[0] | (b[1] << 16);
+        r.y = b[2] | (b[3] << 16);
+        *(uint2*)(y + 4 * i) = r;
+    }
+}
+__global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, long long n4) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const uint2 r = *(const uint2*)(x + 4 * i);
+        float4 o;
+        o.x = __builtin_bit_cast(float, r.x << 16);
+        o.y = __builtin_bit_cast(float, r.x & 0xFFFF0000u);
+        o.z = __builtin_bit_cast(float, r.y << 16);
+        o.w = __builtin_bit_cast(float, r.y & 0xFFFF0000u);
+        *(float4*)(y + 4 * i) = o;
+    }
+}
+}  // namespace pemp
+
+extern "C" int pemp_convert_f32_bf16(const float* x, void* y, long long n, void* stream) {
+    PEMP_REQUIRE(x && y && n > 0 && n % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 7) == 0, "convert_f32_bf16: n %% 4 == 0, aligned pointers");
+    const long long n4 = n / 4;
+    const int grid = (int)(n4 / 256 + 1 > 8192 ? 8192 : n4 / 256 + 1);
+    hipLaunchKernelGGL(pemp::f32_to_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, n4);
+    return pemp::launch_status("convert_f32_bf16");
+}
+
+extern "C" int pemp_convert_bf16_f32(const void* x, float* y, long long n, void* stream) {
+    PEMP_REQUIRE(x && y && n > 0 && n % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 7) == 0, "convert_bf16_f32: n %% 4 == 0, aligned pointers");
+    const long long n4 = n / 4;
+    const int grid = (int)(n4 / 256 + 1 > 8192 ? 8192 : n4 / 256 + 1);
+    hipLaunchKernelGGL(pemp::bf16_to_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, y, n4);
+    return pemp::launch_status("convert_bf16_f32");
+}

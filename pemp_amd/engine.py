@@ -25,8 +25,9 @@ def bn_affine(bn):
     return alpha.contiguous(), beta.contiguous()
 
 
-def conv_params(conv, bn=None, relu=False, stem4=False, in_slice=None):
-    """Pack one nn.Conv2d (+ following BN) for pemp_conv2d_nhwc_f32."""
+def conv_params(conv, bn=None, relu=False, stem4=False, in_slice=None, dtype=torch.float32):
+    """Pack one nn.Conv2d (+ following BN) for pemp_conv2d_nhwc_f32 (``dtype`` bfloat16: the weights of the bf16 side-figure
+    variant; the folded affine stays fp32)."""
     w = conv.weight.detach()
     if in_slice is not None:
         w = w[:, in_slice[0]:in_slice[1]]
@@ -39,7 +40,7 @@ def conv_params(conv, bn=None, relu=False, stem4=False, in_slice=None):
             shift = shift + conv.bias.detach().float() * scale
     elif conv.bias is not None:
         shift = conv.bias.detach().float().contiguous()
-    return ConvParams(packed.contiguous(), scale, shift, 4 if stem4 else cin, cout, conv.kernel_size[0],
+    return ConvParams(packed.contiguous().to(dtype), scale, shift, 4 if stem4 else cin, cout, conv.kernel_size[0],
                       conv.kernel_size[1], conv.stride[0], conv.padding[0], conv.dilation[0], kpad, stem4, relu)
 
 
@@ -53,13 +54,16 @@ GROUP_MAX_ROWS = int(os.environ.get("PEMP_EVAL_GROUP_ROWS", "12000"))
 class Arena:
     """Named activation buffers reused across calls (static addresses make hipGraph replay valid)."""
 
-    def __init__(self, device):
+    def __init__(self, device, dtype=torch.float32):
         self.device = device
+        self.dtype = dtype            # activations between the stem and the encoder's last layer (bfloat16: the side-figure variant)
         self.bufs = {}
         self.ws = {}
 
-    def get(self, name, shape, dtype=torch.float32, zero=False):
-        """``zero``: cleared ONCE, when the buffer is created (for buffers with regions nobody writes afterwards)."""
+    def get(self, name, shape, dtype=None, zero=False):
+        """``zero``: cleared ONCE, when the buffer is created (for buffers with regions nobody writes afterwards).
+        ``dtype`` None: the arena's activation dtype."""
+        dtype = self.dtype if dtype is None else dtype
         key = (name, tuple(shape), dtype)
         t = self.bufs.get(key)
         if t is None:
@@ -69,16 +73,16 @@ class Arena:
 
 
 class _BlockPlan:
-    def __init__(self, blk, extra_in=0):
+    def __init__(self, blk, extra_in=0, dtype=torch.float32):
         # extra_in: the CM variant's two spatially-constant channels are applied as a per-image
         # bias (see ResNetCMEngine), so the packed weights cover only the real channels.
         sl = None
         if extra_in:
             sl = (0, blk.conv1.weight.shape[1] - extra_in)
-        self.c1 = conv_params(blk.conv1, blk.bn1, relu=True, in_slice=sl)
-        self.c2 = conv_params(blk.conv2, blk.bn2, relu=True)
-        self.c3 = conv_params(blk.conv3, blk.bn3, relu=True)     # relu after the residual add
-        self.ds = conv_params(blk.downsample[0], blk.downsample[1], relu=False, in_slice=sl) \
+        self.c1 = conv_params(blk.conv1, blk.bn1, relu=True, in_slice=sl, dtype=dtype)
+        self.c2 = conv_params(blk.conv2, blk.bn2, relu=True, dtype=dtype)
+        self.c3 = conv_params(blk.conv3, blk.bn3, relu=True, dtype=dtype)     # relu after the residual add
+        self.ds = conv_params(blk.downsample[0], blk.downsample[1], relu=False, in_slice=sl, dtype=dtype) \
             if blk.downsample is not None else None
         if extra_in:
             # weights of the extra channels, pre-multiplied by the BN alpha: [Cout, extra]
@@ -94,14 +98,14 @@ class ResNetEngine:
         self.stem = conv_params(prm.conv1, prm.bn1, relu=True, stem4=True)
         self.stages = []
         for name in ("layer1", "layer2", "layer3"):
-            self.stages.append([_BlockPlan(b) for b in getattr(prm, name)])
+            self.stages.append([_BlockPlan(b, dtype=arena.dtype) for b in getattr(prm, name)])
 
     def _block(self, x, bp, tag, c1_shift=None, ds_shift=None):
         a = self.arena
         n, h, w, _ = x.shape
         ho = ops.conv_out_size(h, 1, bp.c1.stride, 0, 1)
         wo = ops.conv_out_size(w, 1, bp.c1.stride, 0, 1)
-        if bp.ds is not None and c1_shift is None and ds_shift is None and 0 < n * ho * wo <= GROUP_MAX_ROWS:
+        if bp.ds is not None and c1_shift is None and ds_shift is None and 0 < n * ho * wo <= GROUP_MAX_ROWS and x.dtype == torch.float32:
             # small step: conv1 and the downsample conv read the same x -- one grouped launch
             y1, res = ops.conv2d_group([x, x], [bp.c1, bp.ds], [a.get("y1", (n, ho, wo, bp.c1.cout)),
                                                                 a.get("res", (n, ho, wo, bp.ds.cout))])
@@ -121,9 +125,12 @@ class ResNetEngine:
         a = self.arena
         n, h, w, _ = x4.shape
         ho, wo = ops.conv_out_size(h, 7, 2, 3, 1), ops.conv_out_size(w, 7, 2, 3, 1)
-        y = ops.conv2d(x4, self.stem, out=a.get("stem", (n, ho, wo, 64)))
+        y = ops.conv2d(x4, self.stem, out=a.get("stem", (n, ho, wo, 64), torch.float32))
         hp, wp = ops._pool_out(ho, 3, 2, 1, True), ops._pool_out(wo, 3, 2, 1, True)
-        return ops.maxpool2d(y, 3, 2, 1, ceil_mode=True, out=a.get("pool", (n, hp, wp, 64)))
+        x = ops.maxpool2d(y, 3, 2, 1, ceil_mode=True, out=a.get("pool", (n, hp, wp, 64), torch.float32))
+        if a.dtype != torch.float32:       # bf16 variant: the fp32 stem + pool hand over a bf16 copy
+            x = ops.convert(x, a.get("pool16", (n, hp, wp, 64)))
+        return x
 
     def forward(self, x4):
         x = self.stem_forward(x4)
@@ -260,6 +267,14 @@ class ASPPV2Engine:
         folded = [ops.fold_input_affine(self.br[i], *self.bn[i]) for i in range(5)]
         self.folded = None if (os.environ.get("PEMP_ASPP_COPIES") or any(f is None for f in folded)) else folded
         self._tails = set()
+        if arena.dtype != torch.float32:
+            # bf16 variant: the four spatial branches and layer6's main part take bf16 operands (folded in fp32 first, then
+            # rounded once); the global branch works on [n, 1, 1, c] and stays fp32
+            if self.folded is None:
+                raise ValueError("the bf16 variant needs the folded ASPPV2 branches (non-zero BatchNorm scales)")
+            for q, _ in self.folded[1:]:
+                q.w = q.w.to(arena.dtype)
+            self.l6_main.w = self.l6_main.w.to(arena.dtype)
 
     def forward(self, x, tail=None):
         """``tail`` [>= 4, c]: spare rows right behind ``x`` in the same allocation; the padding vectors are parked there
@@ -267,11 +282,13 @@ class ASPPV2Engine:
         a = self.arena
         n, h, w, c = x.shape
         midc = self.midc
-        g = ops.global_avgpool(x, out=a.get("gap", (n, c)))
+        f32 = torch.float32
+        x32 = x if x.dtype == f32 else ops.convert(x, a.get("aspp_x32", (n, h, w, c), f32))     # bf16 variant: the pooling reads fp32
+        g = ops.global_avgpool(x32, out=a.get("gap", (n, c), f32))
         cat = a.get("aspp_cat", (n, h, w, 4 * midc))
         if self.folded is not None:
-            g2 = ops.conv2d(g.view(n, 1, 1, c), self.folded[0][0], out=a.get("gap_c", (n, 1, 1, midc)))
-            bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout)))
+            g2 = ops.conv2d(g.view(n, 1, 1, c), self.folded[0][0], out=a.get("gap_c", (n, 1, 1, midc), f32))
+            bias6 = ops.conv2d(g2, self.l6_global, out=a.get("bias6", (n, 1, 1, self.l6_global.cout), f32))
             if tail is not None and tail.data_ptr() not in self._tails:
                 for i in range(4):
                     tail[i].copy_(self.folded[i + 1][1])
@@ -279,7 +296,7 @@ class ASPPV2Engine:
             qs = [self.folded[i + 1][0] for i in range(4)]
             pvs = [tail[i] if tail is not None else self.folded[i + 1][1] for i in range(4)]
             outs = [cat[..., i * midc:(i + 1) * midc] for i in range(4)]
-            if tail is not None and 0 < n * h * w <= GROUP_MAX_ROWS:
+            if tail is not None and 0 < n * h * w <= GROUP_MAX_ROWS and x.dtype == f32:
                 # small step: the four branches read the same x -- one grouped launch, the dilated 3x3 convs first (their
                 # tiles are the long ones; the 1x1 branch's short tiles fill in behind them)
                 order = sorted(range(4), key=lambda i: -qs[i].kh * qs[i].kw)
@@ -287,7 +304,7 @@ class ASPPV2Engine:
             else:
                 for i in range(4):
                     ops.conv2d(x, qs[i], out=outs[i], pad_value=pvs[i] if qs[i].kh * qs[i].kw > 1 else None)
-            return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout)),
+            return ops.conv2d(cat, self.l6_main, out=a.get("feat", (n, h, w, self.l6_main.cout), f32),
                               shift_override=bias6.view(n, -1), per_image_shift=True)
         gb = a.get("gap_bn", (n, c))
         ops.channel_affine_multi(g, [self.bn[0][0]], [self.bn[0][1]], [gb])
@@ -335,8 +352,8 @@ class ASPPEngine:
 class PurifierEngine:
     def __init__(self, seq, arena):
         self.arena = arena
-        self.p0 = conv_params(seq[0], None, relu=True)
-        self.p3 = conv_params(seq[3], None, relu=True)
+        self.p0 = conv_params(seq[0], None, relu=True, dtype=arena.dtype)
+        self.p3 = conv_params(seq[3], None, relu=True, dtype=arena.dtype)
         aspp = seq[6]
         self.aspp = ASPPV2Engine(aspp, arena) if isinstance(aspp.aspp_0[0], nn.BatchNorm2d) else ASPPEngine(aspp, arena)
 

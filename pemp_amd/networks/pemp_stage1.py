@@ -81,16 +81,39 @@ class _HeadMixin:
         the default; ``with model.lane(k):`` selects replica k -- same weights, its own arena and graphs -- so that
         several single-episode steps can be in flight on different HIP streams (entry.pemp_stage1.Evaluator(lanes=K))."""
         lane = self.__dict__.get("_lane", 0)
+        prec = self.__dict__.get("_precision", "f32")
+        key = lane if prec == "f32" else (lane, prec)
         engines = self.__dict__.setdefault("_engines", {})
-        eng = engines.get(lane)
+        eng = engines.get(key)
         if eng is None or eng["device"] != device:
-            arena = engine.Arena(device)
+            arena = engine.Arena(device, torch.bfloat16 if prec == "bf16" else torch.float32)
             eng = {"device": device, "arena": arena}
             self._build_engine(eng, arena)
-            engines[lane] = eng
-        if lane == 0:
+            engines[key] = eng
+        if key == 0:
             self.__dict__["_engine"] = eng
         return eng
+
+    def precision(self, prec):
+        """Context manager: ``with model.precision("bf16"):`` runs the enclosed inference calls on the bf16-OPERAND variant of the
+        encoder (bf16 activations and weights between the fp32 stem and the fp32 head, fp32 accumulation) -- the side figure of
+        bench.py that shows what exact fp32 costs; stage-1 ResNet encoders only.  The default, and everything the parity
+        tests hold, is "f32"."""
+        if prec not in ("f32", "bf16"):
+            raise ValueError(f"precision must be 'f32' or 'bf16', got {prec!r}")
+        if prec == "bf16" and not (getattr(self, "_bf16_variant", False) and getattr(self, "backbone_name", "") != "vgg16"):
+            raise ValueError("the bf16 variant exists for the stage-1 ResNet encoders only")
+        model = self
+
+        class _Prec:
+            def __enter__(self_inner):
+                self_inner.prev = model.__dict__.get("_precision", "f32")
+                model.__dict__["_precision"] = prec
+
+            def __exit__(self_inner, *exc):
+                model.__dict__["_precision"] = self_inner.prev
+                return False
+        return _Prec()
 
     def lane(self, k):
         """Context manager: run the enclosed inference calls on engine replica ``k``."""
@@ -142,6 +165,7 @@ class _HeadMixin:
         self._require_eval_gpu(self, *inputs)
         eng = self._engine_for(inputs[0].device)
         key = tuple((tuple(t.shape), t.dtype) for t in inputs) + (ret_ind, ops.EVAL_SPLITK)    # the conv variants are baked in
+        # (the bf16 variant has its own engine, hence its own graphs)
         graphs = eng.setdefault("graphs", {})
         entry = graphs.get(key)
         if entry is None:
@@ -176,6 +200,7 @@ class _HeadMixin:
 
 class PEMPStage1(_HeadMixin, backbones.BaseModel):
     """Stage 1 of the Prior-Enhanced network with Meta-Prototypes (reference class of the same name)."""
+    _bf16_variant = True
 
     @net_ingredient.capture
     def __init__(self, logger, backbone, init_channels, out_channels, protos, drop_rate, block_size):
@@ -220,7 +245,7 @@ class PEMPStage1(_HeadMixin, backbones.BaseModel):
         eng = self._engine_for(dev)
         n = sum(g.shape[0] for g in image_groups)
         H, W = image_groups[0].shape[-2:]
-        x4 = eng["arena"].get("x4", (n, H, W, 4))
+        x4 = eng["arena"].get("x4", (n, H, W, 4), torch.float32)
         o = 0
         for g in image_groups:
             ops.pack_input(g.contiguous(), out=x4[o:o + g.shape[0]])

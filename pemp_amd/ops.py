@@ -29,9 +29,9 @@ def _chk_dev(*ts):
             raise _lib.PempHipError("pemp_amd ops need device (cuda/HIP) tensors; there is no CPU path")
 
 
-def _nhwc(t, name):
-    if t.dim() != 4 or t.dtype != torch.float32 or t.stride(3) != 1:
-        raise ValueError(f"{name}: expected fp32 NHWC view with unit channel stride, got {tuple(t.shape)} {t.dtype} {t.stride()}")
+def _nhwc(t, name, dtype=torch.float32):
+    if t.dim() != 4 or t.dtype != dtype or t.stride(3) != 1:
+        raise ValueError(f"{name}: expected {dtype} NHWC view with unit channel stride, got {tuple(t.shape)} {t.dtype} {t.stride()}")
     n, h, w, c = t.shape
     # strides of size-1 dims are arbitrary in torch: take the pixel stride from the first dim that moves
     if w > 1:
@@ -205,6 +205,8 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
     """y = act(scale * conv(x, w) + shift (+ residual)).  x: NHWC view, returns NHWC tensor/view ``out``.
     ``pad_value`` [Cin]: what out-of-image taps read instead of zero (multi-tap convs; see fold_input_affine).
     ``splitk``: the autotuner may also pick the split-K variants (training path: they are not bit-identical to the rest)."""
+    if x.dtype == torch.bfloat16:
+        return _conv2d_bf16(x, p, out, residual, shift_override, per_image_shift, relu, tile, pad_value)
     lib = _lib.load()
     _chk_dev(x, p.w, out, residual)
     ldx = _nhwc(x, "x")
@@ -265,6 +267,68 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
             else:
                 tile = DEFAULT_TILE
     launch(tile)
+    return out
+
+
+def _conv2d_bf16(x, p, out, residual, shift_override, per_image_shift, relu, tile, pad_value):
+    """The bf16-operand variant of ``conv2d`` (pemp_conv2d_bf16_nhwc; the side figure of bench.py, never the default path): x,
+    p.w, residual and pad_value are bf16, accumulation is fp32, ``out`` is bf16 -- or fp32 when an fp32 ``out`` is given (the
+    encoder's last layer)."""
+    lib = _lib.load()
+    _chk_dev(x, p.w, out, residual, pad_value)
+    if p.w.dtype != torch.bfloat16 or p.stem:
+        raise ValueError("conv2d (bf16 input): the layer's weights must be packed as bf16 (engine precision 'bf16'); no stem")
+    ldx = _nhwc(x, "x", torch.bfloat16)
+    n, h, w, cin = x.shape
+    if cin != p.cin:
+        raise ValueError(f"conv2d: input has {cin} channels, layer expects {p.cin}")
+    ho = conv_out_size(h, p.kh, p.stride, p.pad, p.dil)
+    wo = conv_out_size(w, p.kw, p.stride, p.pad, p.dil)
+    if out is None:
+        out = torch.empty((n, ho, wo, p.cout), dtype=torch.bfloat16, device=x.device)
+    out_f32 = out.dtype == torch.float32
+    ldy = _nhwc(out, "out", out.dtype)
+    if tuple(out.shape) != (n, ho, wo, p.cout):
+        raise ValueError(f"conv2d: out shape {tuple(out.shape)} != {(n, ho, wo, p.cout)}")
+    ldr = 0
+    if residual is not None:
+        ldr = _nhwc(residual, "residual", torch.bfloat16)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError("conv2d: residual shape mismatch")
+    if pad_value is not None and (pad_value.numel() != cin or pad_value.dtype != torch.bfloat16 or not pad_value.is_contiguous()):
+        raise ValueError(f"conv2d: pad_value must be a contiguous bf16 [{cin}] vector")
+    shift = p.shift if shift_override is None else shift_override
+    flags = (CONV_RELU if (p.relu if relu is None else relu) else 0) | (CONV_SHIFT_PER_IMAGE if per_image_shift else 0)
+
+    def launch(t):
+        d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, flags, t)
+        _lib.check(lib.pemp_conv2d_bf16_nhwc(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift), _p(residual), _p(pad_value),
+                                             1 if out_f32 else 0, _stream()), "pemp_conv2d_bf16_nhwc")
+
+    if tile == 0:
+        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 5, n, h, w, int(residual is not None), int(pad_value is not None))   # 5: bf16
+        tile = _TILE_CACHE.get(key)
+        if tile is None:
+            if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():
+                tile = _pick_tile(launch, p, key, p.cout, only=GROUP_TILES)
+            else:
+                tile = 24 if p.cout % 128 == 0 else 23
+    launch(tile)
+    return out
+
+
+def convert(x, out):
+    """Element-wise fp32 -> bf16 (round to nearest even) or bf16 -> fp32 between two contiguous tensors of one shape."""
+    lib = _lib.load()
+    _chk_dev(x, out)
+    if not x.is_contiguous() or not out.is_contiguous() or x.numel() != out.numel() or x.numel() % 4:
+        raise ValueError("convert: contiguous tensors of the same size (a multiple of 4 elements)")
+    if x.dtype == torch.float32 and out.dtype == torch.bfloat16:
+        _lib.check(lib.pemp_convert_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "convert_f32_bf16")
+    elif x.dtype == torch.bfloat16 and out.dtype == torch.float32:
+        _lib.check(lib.pemp_convert_bf16_f32(_p(x), _p(out), x.numel(), _stream()), "convert_bf16_f32")
+    else:
+        raise ValueError(f"convert: {x.dtype} -> {out.dtype} is not one of fp32 <-> bf16")
     return out
 
 
