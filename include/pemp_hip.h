@@ -94,6 +94,21 @@ int pemp_conv2d_bf16_nhwc(const pemp_conv_desc* d, const void* x, const void* w,
 int pemp_convert_f32_bf16(const float* x, void* y, long long n, void* stream);
 int pemp_convert_bf16_f32(const void* x, float* y, long long n, void* stream);
 
+/* The convolution above FOLLOWED BY DropBlock2D's scaling of its output (training; dropblock==0.3.0's two statements
+ * y * mask[None] ; y * numel / sum(mask), in that order and rounding): row m of the result is multiplied by rowmask[m] (fp32 {0,1}
+ * per output pixel, from pemp_dropblock_mask_f32) * M / *kept_count.  One launch instead of the conv + pemp_pixel_scale_f32 --
+ * the purifier's conv -> ReLU -> DropBlock (networks/pemp_stage1.py:74-79) and, in the backward pass, the input-gradient convs
+ * whose result DropBlock's backward scales the same way.  Tiles 21..27, or 31..37 with a split-K workspace (ws may be NULL
+ * otherwise).                                                                                                              */
+int pemp_conv2d_dropblock_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale,
+                                   const float* shift, const float* residual, const float* rowmask, const int* kept_count,
+                                   void* ws, size_t ws_bytes, void* stream);
+/* train-mode BatchNorm apply (batch statistics given) + the DropBlock2D behind it in one pass: ASPPV2's BatchNorm -> DropBlock ->
+ * conv branches (networks/backbones.py:329-353).                                                                           */
+int pemp_bn_apply_dropblock_f32(const float* z, int ldz, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, float* y, int ldy, int M, int C, const float* rowmask,
+                                const int* kept_count, void* stream);
+
 /* [N,3,H,W] image (+ optional [N,1,H,W] prior; NULL -> 0) -> NHWC4 [N,H,W,4].
  * Replaces torch.cat/view at networks/pemp_stage1.py:139, pemp_stage2.py:130-138.          */
 int pemp_pack_input_nhwc4_f32(const float* img, const float* prior, float* out,

@@ -46,6 +46,8 @@ SYMBOLS = {
     "pemp_conv2d_bf16_nhwc": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "pemp_convert_f32_bf16": (c_int, [c_fp, c_fp, C.c_longlong, c_fp]),
     "pemp_convert_bf16_f32": (c_int, [c_fp, c_fp, C.c_longlong, c_fp]),
+    "pemp_conv2d_dropblock_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size, c_fp]),
+    "pemp_bn_apply_dropblock_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp]),
     "pemp_pack_input_nhwc4_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "pemp_maxpool2d_nhwc_f32": (c_int, [c_fp, c_fp] + [c_int] * 11 + [c_fp]),
     "pemp_global_avgpool_nhwc_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),

@@ -53,6 +53,10 @@ struct ConvArgs {
     const float* bmean;
     const float* binvstd;
     int ldbz;
+    // DropBlock2D behind the conv (pemp_conv2d_dropblock_nhwc_f32): every output row m is multiplied by rowmask[m] * M / *rowcnt
+    // (the layer's two statements, in its order and rounding: ((y * mask) * numel) / sum(mask)); NULL: none
+    const float* rowmask;
+    const int* rowcnt;
     // split-K of the remainder tiles (conv_dma2.hip, SK kernels): tiles >= sk_full are computed by sk_S blocks each, every block
     // over 1/sk_S of the K steps; partial accumulators go to sk_ws, the last block to arrive adds them in piece order
     float* sk_ws;
@@ -103,6 +107,7 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
     constexpr bool PRE = NPRE == TM * TN * 4;       // (an array of 1 = "no prefetched residual": registers, never scratch)
     const bool relu = a.flags & PEMP_CONV_RELU;
     const bool per_img = a.flags & PEMP_CONV_SHIFT_PER_IMAGE;
+    const float db_sum = a.rowmask ? (float)*a.rowcnt : 1.f, db_numel = (float)a.M;
     const int lr = lane & 31, lh = lane >> 5;
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
@@ -159,6 +164,13 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
                         o.y = fmaxf(o.y, 0.f);
                         o.z = fmaxf(o.z, 0.f);
                         o.w = fmaxf(o.w, 0.f);
+                    }
+                    if (a.rowmask) {                              // DropBlock2D.forward / its backward, fused (dropout.hip: pixel_scale_kernel)
+                        const float k = a.rowmask[m];
+                        o.x = __fdiv_rn(__fmul_rn(__fmul_rn(o.x, k), db_numel), db_sum);
+                        o.y = __fdiv_rn(__fmul_rn(__fmul_rn(o.y, k), db_numel), db_sum);
+                        o.z = __fdiv_rn(__fmul_rn(__fmul_rn(o.z, k), db_numel), db_sum);
+                        o.w = __fdiv_rn(__fmul_rn(__fmul_rn(o.w, k), db_numel), db_sum);
                     }
                     if constexpr (EPI == 2) {
                         const uint32_t b = mw[i] >> c4;

@@ -314,6 +314,7 @@ static int conv_fill(const pemp_conv_desc* d, const float* x, const float* w, fl
 
     a.x = x; a.w = w; a.y = y; a.scale = scale; a.shift = shift; a.res = residual; a.padv = pad_value; a.stats = nullptr; a.bz = nullptr;
     a.bmask = nullptr; a.bmean = nullptr; a.binvstd = nullptr; a.ldbz = 0;
+    a.rowmask = nullptr; a.rowcnt = nullptr;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cout = d->Cout; a.ldy = d->ldy; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.dil = d->dil; a.ldr = d->ldr; a.Kpad = d->Kpad; a.flags = d->flags;
@@ -403,6 +404,28 @@ extern "C" int pemp_conv2d_group_nhwc_f32(int n, const pemp_conv_desc* d, const 
 }
 
 
+// conv (+ affine, residual, ReLU) followed by DropBlock2D's scaling of the output rows, in one launch: the buffer-addressed
+// kernels only (tiles 21..27, or 31..37 with a split-K workspace)
+extern "C" int pemp_conv2d_dropblock_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* scale,
+                                              const float* shift, const float* residual, const float* rowmask, const int* kept_count,
+                                              void* ws, size_t ws_bytes, void* stream) {
+    PEMP_REQUIRE(rowmask && kept_count, "conv2d_dropblock: null mask / count");
+    ConvArgs a;
+    const int rc = conv_fill(d, x, w, y, scale, shift, residual, nullptr, a);
+    if (rc) return rc;
+    PEMP_REQUIRE(d->tile >= 21 && d->tile <= 37 && d->tile != 33 && !(d->tile >= 28 && d->tile <= 30),
+                 "conv2d_dropblock: tile must be 21..27 or 31..37 (no 33), got %d", d->tile);
+    PEMP_REQUIRE(conv_dma2_supported(a), "conv2d_dropblock: geometry / operand size outside the buffer-addressed kernels");
+    a.rowmask = rowmask;
+    a.rowcnt = kept_count;
+    const int t = d->tile > 30 ? d->tile - 30 : d->tile - 20;
+    PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || a.Cout % 128 == 0, "conv2d_dropblock: tile N=128 needs Cout %% 128 == 0");
+    PEMP_REQUIRE(t != 7 || a.Cout % 256 == 0, "conv2d_dropblock: tile 256x256 needs Cout %% 256 == 0");
+    if (d->tile > 30) return launch_conv_dma2_splitk(t, a, ws, ws_bytes, (hipStream_t)stream);
+    return launch_conv_dma2(t, a, (hipStream_t)stream);
+}
+
+
 // The side-figure variant: bf16 operands, fp32 accumulation (conv_dma2.hip, BF16).  The descriptor is in ELEMENTS like every
 // other; the kernel is handed Cin / ldx / Kpad in dwords (two bf16 each), which is all it needs to address bf16 rows.
 extern "C" int pemp_conv2d_bf16_nhwc(const pemp_conv_desc* d, const void* x, const void* w, void* y, const float* scale,
@@ -441,7 +464,7 @@ static int conv_stats_fill(const char* what, const pemp_conv_desc* d, ConvArgs& 
     PEMP_REQUIRE(d->Cout % 64 == 0 && d->Cin % 32 == 0 && d->ldx >= d->Cin && d->ldx % 4 == 0 && d->ldy >= d->Cout && d->ldy % 4 == 0,
                  "%s: Cout %% 64, Cin %% 32, strides %% 4", what);
     PEMP_REQUIRE(d->Kpad == d->KH * d->KW * d->Cin, "%s: Kpad must equal KH*KW*Cin", what);
-    a.scale = nullptr; a.shift = nullptr; a.padv = nullptr;
+    a.scale = nullptr; a.shift = nullptr; a.padv = nullptr; a.rowmask = nullptr; a.rowcnt = nullptr;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Ho = d->Ho; a.Wo = d->Wo;
     a.Cout = d->Cout; a.ldy = d->ldy; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.dil = d->dil; a.ldr = d->ldr; a.Kpad = d->Kpad; a.flags = d->flags;

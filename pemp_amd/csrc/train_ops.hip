@@ -328,8 +328,11 @@ __global__ __launch_bounds__(256) void bn_apply_rows_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ res, int ldr, float* __restrict__ y,
-                                                            int ldy, int M, int C4, int relu, uint32_t* __restrict__ mask) {
+                                                            int ldy, int M, int C4, int relu, uint32_t* __restrict__ mask,
+                                                            const float* __restrict__ rowmask = nullptr,
+                                                            const int* __restrict__ rowcnt = nullptr) {
     const int c = (threadIdx.x % C4) * 4, rpb = 256 / C4;
+    const float db_sum = rowmask ? (float)*rowcnt : 1.f, db_numel = (float)M;
     float alpha[4], bt[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -361,6 +364,11 @@ __global__ __launch_bounds__(256) void bn_apply_rows_kernel(const float* __restr
             if (relu) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+            if (rowmask) {          // DropBlock2D behind the BatchNorm: ((y * mask) * numel) / sum(mask), the layer's order and rounding
+                const float k = rowmask[m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __fdiv_rn(__fmul_rn(__fmul_rn(o[e], k), db_numel), db_sum);
             }
             *(float4*)(y + (size_t)m * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
@@ -726,6 +734,19 @@ extern "C" int pemp_bn_apply_mask_f32(const float* z, int ldz, const float* mean
         hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz, mean,
                            invstd, gamma, beta, residual, ldr, y, ldy, (long long)M, C / 4, relu);
     return launch_status("bn_apply");
+}
+
+// BatchNorm apply (no residual, no ReLU) + the DropBlock2D behind it in one pass (ASPPV2's BN -> DropBlock -> conv branches)
+extern "C" int pemp_bn_apply_dropblock_f32(const float* z, int ldz, const float* mean, const float* invstd, const float* gamma,
+                                           const float* beta, float* y, int ldy, int M, int C, const float* rowmask,
+                                           const int* kept_count, void* stream) {
+    CHK_VEC(z, ldz, C, "bn_apply_dropblock");
+    CHK_VEC(y, ldy, C, "bn_apply_dropblock");
+    PEMP_REQUIRE(M > 0 && mean && invstd && gamma && beta && rowmask && kept_count, "bn_apply_dropblock: null pointer");
+    PEMP_REQUIRE(rows_form(C), "bn_apply_dropblock: C must be one of the row-kernel widths (32 .. 1024, a power of two)");
+    hipLaunchKernelGGL(bn_apply_rows_kernel, dim3(rows_grid(M, C)), dim3(256), 0, (hipStream_t)stream, z, ldz, mean, invstd,
+                       gamma, beta, (const float*)nullptr, 0, y, ldy, M, C / 4, 0, (uint32_t*)nullptr, rowmask, kept_count);
+    return launch_status("bn_apply_dropblock");
 }
 
 extern "C" int pemp_bn_bwd_f32(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,

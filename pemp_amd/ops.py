@@ -201,10 +201,13 @@ def pack_conv_weight(w_oihw, stem4=False):
 
 
 def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=False, relu=None, tile=0,
-           pad_value=None, splitk=False):
+           pad_value=None, splitk=False, dropblock=None):
     """y = act(scale * conv(x, w) + shift (+ residual)).  x: NHWC view, returns NHWC tensor/view ``out``.
     ``pad_value`` [Cin]: what out-of-image taps read instead of zero (multi-tap convs; see fold_input_affine).
-    ``splitk``: the autotuner may also pick the split-K variants (training path: they are not bit-identical to the rest)."""
+    ``splitk``: the autotuner may also pick the split-K variants (training path: they are not bit-identical to the rest).
+    ``dropblock`` (mask fp32 [N,Ho,Wo], kept count int32 [1]) -- a DropBlock2D record of train_ops.dropblock_mask: the layer's
+    scaling of the output rows happens in the conv's epilogue (pemp_conv2d_dropblock_nhwc_f32; same arithmetic as
+    train_ops.pixel_scale on the conv's result)."""
     if x.dtype == torch.bfloat16:
         return _conv2d_bf16(x, p, out, residual, shift_override, per_image_shift, relu, tile, pad_value)
     lib = _lib.load()
@@ -239,8 +242,25 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
         flags |= CONV_STEM4
     splitk = ((splitk and SPLITK) or (EVAL_SPLITK and n * ho * wo <= EVAL_SPLITK_MAX_ROWS)) and not p.stem
 
+    if dropblock is not None:
+        dmask, dcnt = dropblock
+        _chk_dev(dmask, dcnt)
+        if (pad_value is not None or p.stem or dmask.dtype != torch.float32 or not dmask.is_contiguous() or dmask.numel() != n * ho * wo
+                or dcnt.dtype != torch.int32 or not dma2_supported(x, p)):
+            # outside the buffer-addressed kernels: conv, then the layer's own pass
+            from . import train_ops
+            y = conv2d(x, p, out=out, residual=residual, shift_override=shift_override, per_image_shift=per_image_shift, relu=relu,
+                       tile=tile, pad_value=pad_value, splitk=splitk)
+            return train_ops.pixel_scale(y, dmask, dcnt, out=y)
+
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, flags, t)
+        if dropblock is not None:
+            ws, ws_bytes = _splitk_ws(lib, d, x.device) if t > 30 else (None, 0)
+            _check_sk(lib, lib.pemp_conv2d_dropblock_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift), _p(residual),
+                                                              _p(dropblock[0]), _p(dropblock[1]), C.c_void_p(ws), ws_bytes, _stream()),
+                      ws, "pemp_conv2d_dropblock_nhwc_f32")
+            return
         if t > 30 and pad_value is not None:
             ws, ws_bytes = _splitk_ws(lib, d, x.device)
             _check_sk(lib, lib.pemp_conv2d_padv_splitk_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(p.scale), _p(shift), _p(residual),
@@ -258,14 +278,18 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
                                                      _p(residual), _p(pad_value), _stream()), "pemp_conv2d_padv_nhwc_f32")
 
     if tile == 0:
-        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 4 if splitk else int(p.stem), n, h, w, int(residual is not None),
-               int(pad_value is not None))
+        key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, (6 if dropblock is not None else 4) if splitk else int(p.stem) + (7 if dropblock is not None else 0),
+               n, h, w, int(residual is not None), int(pad_value is not None))
         tile = _TILE_CACHE.get(key)
         if tile is None:
-            if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():
-                tile = _pick_tile(launch, p, key, p.cout, only=list(TILE_VARIANTS) + list(SPLITK_TILES) if splitk else None)
+            if dropblock is not None:
+                only = list(GROUP_TILES) + (list(SPLITK_TILES) if splitk else [])
             else:
-                tile = DEFAULT_TILE
+                only = list(TILE_VARIANTS) + list(SPLITK_TILES) if splitk else None
+            if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():
+                tile = _pick_tile(launch, p, key, p.cout, only=only)
+            else:
+                tile = DEFAULT_TILE + (10 if dropblock is not None else 0)
     launch(tile)
     return out
 
@@ -579,11 +603,17 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
     return out, part[:_stats_rows(m, tile)]
 
 
-def stats_supported(x, p):
-    """Whether conv2d_stats applies to this (input, layer): what conv_dma2_supported checks in csrc/conv_dma2.hip."""
+def dma2_supported(x, p):
+    """Whether the buffer-addressed conv kernels apply to this (input, layer): what conv_dma2_supported checks in
+    csrc/conv_dma2.hip (no padding value involved)."""
     n, h, w, cin = x.shape
-    return (not p.stem and p.scale is None and p.kh * p.kw <= 32 and cin % 32 == 0 and p.cout % 64 == 0
+    return (not p.stem and p.kh * p.kw <= 32 and cin % 32 == 0 and p.cout % 64 == 0
             and x.numel() * 4 < 2 ** 31 - (1 << 20) and p.w.numel() * 4 < 2 ** 31)
+
+
+def stats_supported(x, p):
+    """Whether conv2d_stats applies to this (input, layer)."""
+    return p.scale is None and dma2_supported(x, p)
 
 
 def fold_input_affine(p, s, t):

@@ -33,6 +33,9 @@ def conv2d(x, p, **kw):
     others, which the evaluation path relies on)."""
     return ops.conv2d(x, p, splitk=True, **kw)
 
+
+FUSE_DROPBLOCK = os.environ.get("PEMP_FUSE_DROPBLOCK", "1") != "0"    # DropBlock's scaling inside the neighbouring kernel (A/B switch)
+
 BN_MOM = 0.1
 FUSE_BN_STATS = os.environ.get("PEMP_FUSE_BN_STATS", "1") != "0"   # conv epilogue starts the batch statistics (A/B switch)
 FUSE_BN_BWD = os.environ.get("PEMP_FUSE_BN_BWD", "1") != "0"       # input-gradient epilogue starts the BatchNorm backward
@@ -426,15 +429,20 @@ class Stage1TrainEngine:
         """DropBlock2D(drop_rate, block_size) in train(): -> (y, record for the backward) (identity at rate 0).  ``layer`` is
         the module's name in the reference model; ``self.draws`` ({layer: uniforms [n,h,w]}) replaces the Philox stream by
         given draws (parity tests: the same draws go to the oracle's restatement of the layer)."""
+        rec = self._dropblock_rec(n, h, w, layer)
+        return (x, None) if rec is None else (T.pixel_scale(x, *rec), rec)
+
+    def _dropblock_rec(self, n, h, w, layer):
+        """The mask + kept count of one DropBlock2D call (None at rate 0): what ``_dropblock`` applies, and what the fused
+        forms (conv epilogue, BatchNorm apply) take instead of a pass of their own."""
         if self.drop_rate <= 0.0:
-            return x, None
+            return None
         u = None
         if self.draws is not None:
             u = self.draws[layer]
-            if tuple(u.shape) != (n, h, w) or u.dtype != torch.float32 or u.device != x.device or not u.is_contiguous():
-                raise ValueError(f"dropblock draws of {layer}: want contiguous float32 {(n, h, w)} on {x.device}")
-        rec = T.dropblock_mask(n, h, w, self.drop_rate, self.block_size, self.rng, self.device, uniforms=u)
-        return T.pixel_scale(x, *rec), rec
+            if tuple(u.shape) != (n, h, w) or u.dtype != torch.float32 or u.device != self.flat.data.device or not u.is_contiguous():
+                raise ValueError(f"dropblock draws of {layer}: want contiguous float32 {(n, h, w)} on {self.flat.data.device}")
+        return T.dropblock_mask(n, h, w, self.drop_rate, self.block_size, self.rng, self.device, uniforms=u)
 
     @staticmethod
     def _dropblock_bwd(dy, rec):
@@ -561,10 +569,19 @@ class Stage1TrainEngine:
     def _tail_forward(self, x, tape):
         # purifier: conv+bias+ReLU (+DropBlock) twice
         nimg, h, w, _ = x.shape
-        ya = conv2d(x, self.p0.fwd_params(relu=True))
-        xa, da = self._dropblock(ya, nimg, h, w, "encoder.purifier.2")
-        yb = conv2d(xa, self.p3.fwd_params(relu=True))
-        xb, db = self._dropblock(yb, nimg, h, w, "encoder.purifier.5")
+        if FUSE_DROPBLOCK:
+            # conv -> bias -> ReLU -> DropBlock in ONE launch each (the layer's scaling in the conv's epilogue).  The backward pass
+            # needs ReLU's sign of the conv output only where the DropBlock kept the pixel, and there sign(xa) = sign(ya) (the
+            # scale is positive): xa / xb stand in for ya / yb on the tape.
+            da = self._dropblock_rec(nimg, h, w, "encoder.purifier.2")
+            ya = xa = conv2d(x, self.p0.fwd_params(relu=True), dropblock=da)
+            db = self._dropblock_rec(nimg, h, w, "encoder.purifier.5")
+            yb = xb = conv2d(xa, self.p3.fwd_params(relu=True), dropblock=db)
+        else:
+            ya = conv2d(x, self.p0.fwd_params(relu=True))
+            xa, da = self._dropblock(ya, nimg, h, w, "encoder.purifier.2")
+            yb = conv2d(xa, self.p3.fwd_params(relu=True))
+            xb, db = self._dropblock(yb, nimg, h, w, "encoder.purifier.5")
         tape.update(p0_in=x, ya=ya, da=da, xa=xa, yb=yb, db=db, xb=xb)
         # ASPPV2: five BNs share the statistics of xb (branch 0: of its global average)
         midc = self.midc
@@ -585,8 +602,12 @@ class Stage1TrainEngine:
             # the four BNs see the same input, hence the same batch statistics; each call also moves
             # that BN's own running statistics
             mean_x, invstd_x = bn.stats(xb, self.ws)
-            t = T.bn_apply(xb, mean_x, invstd_x, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(xb), relu=False)
-            td, d = self._dropblock(t, nimg, h, w, f"encoder.purifier.6.aspp_{i}.1")
+            d = self._dropblock_rec(nimg, h, w, f"encoder.purifier.6.aspp_{i}.1") if FUSE_DROPBLOCK else None
+            if d is not None and T.mask_supported(xb.shape[-1]):           # BatchNorm apply + DropBlock in one pass
+                td = T.bn_apply_dropblock(xb, mean_x, invstd_x, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(xb), d)
+            else:
+                t = T.bn_apply(xb, mean_x, invstd_x, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(xb), relu=False)
+                td, d = (T.pixel_scale(t, *d), d) if d is not None else self._dropblock(t, nimg, h, w, f"encoder.purifier.6.aspp_{i}.1")
             conv2d(td, self.aspp_conv[i].fwd_params(relu=True), out=cat[..., (i - 1) * midc:i * midc])
             ts.append(td)
             ds_.append(d)
@@ -623,8 +644,10 @@ class Stage1TrainEngine:
             g = self._new(nimg, h, w, midc)
             T.relu_bias_bwd(dcat[..., (i - 1) * midc:i * midc], u, g, relu=True, ws_cache=self.ws, out=conv.conv.bias.grad)
             conv.wgrad(tp["ts"][i - 1], g, self.ws)
-            dt = conv2d(g, conv.dgrad_params())
-            dt = self._dropblock_bwd(dt, tp["ds"][i - 1])
+            if FUSE_DROPBLOCK and tp["ds"][i - 1] is not None:          # DropBlock's backward in the input-gradient conv's epilogue
+                dt = conv2d(g, conv.dgrad_params(), dropblock=tp["ds"][i - 1])
+            else:
+                dt = self._dropblock_bwd(conv2d(g, conv.dgrad_params()), tp["ds"][i - 1])
             dz = self._new(nimg, h, w, dt.shape[-1])
             T.bn_bwd(dt, None, tp["xb"], tp["mean_x"], tp["invstd_x"], bn.bn.weight.data, dz, relu=False, ws_cache=self.ws,
                      out=bn.grad_out())                  # dgamma / dbeta straight into the flat gradient buffer
@@ -647,8 +670,10 @@ class Stage1TrainEngine:
         g = torch.empty_like(tp["yb"])
         T.relu_bias_bwd(dxb, tp["yb"], g, relu=True, ws_cache=self.ws, out=self.p3.conv.bias.grad)
         self.p3.wgrad(tp["xa"], g, self.ws)
-        dxa = conv2d(g, self.p3.dgrad_params())
-        dxa = self._dropblock_bwd(dxa, tp["da"])
+        if FUSE_DROPBLOCK and tp["da"] is not None:
+            dxa = conv2d(g, self.p3.dgrad_params(), dropblock=tp["da"])
+        else:
+            dxa = self._dropblock_bwd(conv2d(g, self.p3.dgrad_params()), tp["da"])
         g = torch.empty_like(tp["ya"])
         T.relu_bias_bwd(dxa, tp["ya"], g, relu=True, ws_cache=self.ws, out=self.p0.conv.bias.grad)
         self.p0.wgrad(tp["p0_in"], g, self.ws)

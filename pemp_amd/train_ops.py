@@ -90,6 +90,21 @@ def bn_apply(z, mean, invstd, gamma, beta, out, residual=None, relu=True, mask=N
     return out
 
 
+def bn_apply_dropblock(z, mean, invstd, gamma, beta, out, dropblock):
+    """BatchNorm apply (no residual, no ReLU) + the DropBlock2D behind it, one pass (pemp_bn_apply_dropblock_f32).
+    ``dropblock`` = (mask fp32 [pixels], kept count int32 [1]) of ``dropblock_mask``; same arithmetic as bn_apply + pixel_scale."""
+    lib = _lib.load()
+    dmask, dcnt = dropblock
+    _chk_dev(z, out, dmask, dcnt)
+    m, c, ldz = _rows(z, "z")
+    _, _, ldy = _rows(out, "out")
+    if dmask.numel() != m or dmask.dtype != torch.float32 or not dmask.is_contiguous() or dcnt.dtype != torch.int32:
+        raise ValueError("bn_apply_dropblock: mask must be a contiguous fp32 tensor with one entry per pixel, the count int32")
+    _lib.check(lib.pemp_bn_apply_dropblock_f32(_p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out), ldy, m, c,
+                                               _p(dmask), _p(dcnt), _stream()), "bn_apply_dropblock")
+    return out
+
+
 def mask_supported(c):
     return c in (32, 64, 128, 256, 512, 1024)
 

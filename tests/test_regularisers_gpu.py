@@ -76,3 +76,68 @@ def test_philox_stream_properties(hip_lib, dev):
     m1 = static["m"].clone()
     g.replay()
     assert not torch.equal(m1, static["m"])
+
+
+def test_dropblock_fused_into_its_neighbours_is_the_same_arithmetic(hip_lib, dev):
+    """Round 4: DropBlock2D's scaling inside the kernel in front of it -- the conv epilogue (pemp_conv2d_dropblock_nhwc_f32:
+    purifier conv -> bias -> ReLU -> DropBlock, and the input-gradient convs whose result DropBlock's backward scales) and the
+    BatchNorm apply (pemp_bn_apply_dropblock_f32: ASPPV2's BN -> DropBlock -> conv) -- equals the separate pass bit for bit, for
+    every tile variant the fused form runs on, split-K variants included."""
+    from pemp_amd import ops, train_ops as T
+    g = torch.Generator().manual_seed(3)
+    n, hw, cin, cout = 2, 31, 64, 128
+    x = torch.randn(n, hw, hw, cin, generator=g).to(dev)
+    w = (torch.randn(cout, 9 * cin, generator=g) * 0.05).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    p = ops.ConvParams(w, None, b, cin, cout, 3, 3, 1, 2, 2, 9 * cin, False, True)
+    u = torch.rand((n, hw, hw), generator=g).to(dev)
+    rec = T.dropblock_mask(n, hw, hw, 0.3, 4, T.RandomStream(1), dev, uniforms=u)
+    assert 0 < int(rec[1].item()) < n * hw * hw
+    for tile in (23, 22, 25, 21, 24, 26, 31, 32, 34, 35, 36):
+        ref = T.pixel_scale(ops.conv2d(x, p, tile=tile), *rec)
+        got = ops.conv2d(x, p, tile=tile, dropblock=rec)
+        assert torch.equal(got, ref), tile
+    auto = ops.conv2d(x, p, dropblock=rec, splitk=True)               # autotuned pick among the fused variants
+    assert torch.allclose(auto, ref, rtol=1e-5, atol=1e-6)            # (a split-K pick differs from the unsplit ones in rounding)
+    # a geometry outside the buffer-addressed kernels (Cin = 16): conv + the layer's own pass, same result
+    x16 = torch.randn(n, hw, hw, 16, generator=g).to(dev)
+    # BatchNorm apply + DropBlock
+    z = torch.randn(n, hw, hw, 256, generator=g).to(dev)
+    mean, invstd = z.view(-1, 256).mean(0), 1.0 / (z.view(-1, 256).var(0, unbiased=False) + 1e-5).sqrt()
+    gamma, beta = torch.rand(256, generator=g).to(dev) + 0.5, torch.randn(256, generator=g).to(dev)
+    ref = T.pixel_scale(T.bn_apply(z, mean, invstd, gamma, beta, torch.empty_like(z), relu=False), *rec)
+    got = T.bn_apply_dropblock(z, mean, invstd, gamma, beta, torch.empty_like(z), rec)
+    assert torch.equal(got, ref)
+    del x16
+
+
+def test_training_step_with_fused_dropblock_equals_the_unfused_step(hip_lib, dev, monkeypatch):
+    """The whole stage-1 training step with DropBlock active and GIVEN draws: fused (default) against PEMP_FUSE_DROPBLOCK=0 --
+    same loss, same gradients (bit for bit with the kernel variants pinned to one pick per layer)."""
+    from pemp_amd import ops, synth, train_engine as te
+    from pemp_amd.networks import pemp_stage1 as m
+    from tests import util
+    b = synth.make_batch([31, 32], shot=1, height=97, width=97, out_hw=(97, 97))
+    t = lambda k: torch.from_numpy(b[k]).to(dev)
+    batch = (t("sup_img"), t("sup_mask"), t("qry_img"), t("qry_mask")[:, 0])
+    h = w = 13
+    gen = torch.Generator().manual_seed(77)
+    layers = {"encoder.purifier.2": (h, w), "encoder.purifier.5": (h, w), "encoder.purifier.6.aspp_0.1": (1, 1)}
+    layers.update({f"encoder.purifier.6.aspp_{i}.1": (h, w) for i in range(1, 5)})
+    draws = {k: torch.rand((4,) + hw, generator=gen).to(dev) for k, hw in layers.items()}
+    monkeypatch.setattr(ops, "AUTOTUNE", False)                        # one fixed variant per layer on both sides
+    res = []
+    for fuse in (True, False):
+        monkeypatch.setattr(te, "FUSE_DROPBLOCK", fuse)
+        net = m.ModelClass(None)
+        net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+        tr = te.Stage1Trainer(net, device=dev, drop_rate=0.3, block_size=4)
+        tr.eng.draws = draws
+        loss, _ = tr.forward_backward(*batch)
+        torch.cuda.synchronize()
+        res.append((float(loss), tr.eng.flat.grad.clone()))
+    (l0, g0), (l1, g1) = res
+    assert l0 == l1
+    rel = ((g0 - g1).norm() / g1.norm()).item()
+    print(f"fused vs unfused DropBlock: loss {l0:.6f}, relative gradient difference {rel:.2e}")
+    assert rel < 1e-6
