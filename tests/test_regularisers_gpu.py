@@ -98,7 +98,7 @@ def test_dropblock_fused_into_its_neighbours_is_the_same_arithmetic(hip_lib, dev
         got = ops.conv2d(x, p, tile=tile, dropblock=rec)
         assert torch.equal(got, ref), tile
     auto = ops.conv2d(x, p, dropblock=rec, splitk=True)               # autotuned pick among the fused variants
-    assert torch.allclose(auto, ref, rtol=1e-5, atol=1e-6)            # (a split-K pick differs from the unsplit ones in rounding)
+    assert torch.allclose(auto, ref, rtol=1e-4, atol=1e-4)            # (a split-K pick differs from the unsplit ones in rounding)
     # a geometry outside the buffer-addressed kernels (Cin = 16): conv + the layer's own pass, same result
     x16 = torch.randn(n, hw, hw, 16, generator=g).to(dev)
     # BatchNorm apply + DropBlock
