@@ -328,30 +328,28 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        part[((mi * TN + ni) * 4 + q) * 64] = v4f{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-            // sk_ws is UNCACHED device memory (pemp_uncached_alloc: hipDeviceMallocUncached, MTYPE UC): stores complete in memory,
-            // loads come from memory, whichever XCD issues them -- no L2 write-back / invalidate (measured: agent-scope fences here
-            // cost the 128 x 128 variant 118 -> 94 TFLOP/s, every fence flushing and emptying an XCD's L2 under the other tiles).
-            // What the hand-off relies on, stated: (1) UC lines are never allocated in an XCD's L2 or a CU's L1, so there is no
-            // stale copy for the reading block to hit -- the pieces are read exactly once, by non-temporal loads, after the counter
-            // said so; (2) `s_waitcnt vmcnt(0)` returns only when the fabric has acknowledged this wave's UC stores (write-through
-            // to memory); every storing wave executes it BEFORE the block barrier, and the ONE counter add of the block comes
-            // after that barrier -- the order MI355X_MICROARCH.md gives for a drained write-through publish ("every storing wave's
-            // vmcnt(0), the workgroup's barrier, then the flag / counter"); (3) the counter add is a returning agent-scope atomic,
-            // executed at the memory side, and the reader's loads are issued only after its value came back and after a block
-            // barrier.  Not an architectural guarantee of the HIP memory model: tests/test_train_ops_gpu.py
-            // (test_split_k_hand_off_is_complete_and_stable_under_uneven_load) holds every word of every launch to it, for
-            // every variant and 1 .. 128 remainder tiles, with a second stream loading the memory system unevenly.
+                    for (int q = 0; q < 4; ++q) {
+                        const v4f v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(part + ((mi * TN + ni) * 4 + q) * 64), "v"(v) : "memory");
+                    }
+            // The hand-off, in the form MI355X_MICROARCH.md lists as valid for a last-arriver combine (round 4; rounds 2-3 used plain
+            // stores and non-temporal loads on uncached memory, which held in every test until one launch of one run returned a
+            // different tile -- `nt` is not a coherent access): EVERY store of the handed-off bytes is a device-scope write-through
+            // store (`sc0 sc1`, 16 B), every storing wave drains them (`s_waitcnt vmcnt(0)`), the workgroup's barrier, then ONE
+            // lane's returning agent-scope atomic add; the workgroup whose add came last -- told by the returned value -- reads
+            // after a workgroup barrier that lane joins, EVERY load of those bytes a `global_load_dwordx4 sc0 sc1` to registers.
+            // The workspace stays uncached device memory (pemp_uncached_alloc) on top of that.  An agent-scope release / acquire
+            // fence pair would be the C++-model form; it writes back and invalidates an XCD's whole L2 under the other tiles
+            // (measured: 118 -> 94 TFLOP/s on the 128 x 128 variant).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's partial stores have been acknowledged
             __syncthreads();                                               // ... everybody's
             int* flag = (int*)smem;
-            if (tid == 0) *flag = atomicAdd(a.sk_cnt + sk_r, 1);       // only now this block counts as arrived
+            if (tid == 0) *flag = __hip_atomic_fetch_add(a.sk_cnt + sk_r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // only now this block counts as arrived
             __syncthreads();
             const int arrived = *flag;
             __syncthreads();
             if (arrived != a.sk_S - 1) return;        // not the last piece of this tile: done
-            if (tid == 0) a.sk_cnt[sk_r] = 0;         // the counter is ready for the next launch
+            if (tid == 0) __hip_atomic_store(a.sk_cnt + sk_r, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -360,18 +358,48 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
                     for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
             for (int pc = 0; pc < a.sk_S; ++pc) {     // pieces in ascending order, whichever arrived last: deterministic
                 const v4f* src = (const v4f*)a.sk_ws + ((size_t)(sk_r * a.sk_S + pc) * NW + wave) * (TM * TN * 4 * 64) + lane;
+                // two 32 x 32 sub-tiles (8 coherent 16-byte loads) in flight per wait; a lane's quads of one sub-tile lie 1 KB apart
+                constexpr int NST = TM * TN;
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
+                for (int st = 0; st < NST; st += 2) {
+                    v4f t[8];
+                    const v4f* q0 = src + (st * 4) * 64;
+                    if constexpr (NST >= 2) {
+                        const v4f* q1 = q0 + 4 * 64;
+                        asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+                                     "global_load_dwordx4 %1, %8, off offset:1024 sc0 sc1\n\t"
+                                     "global_load_dwordx4 %2, %8, off offset:2048 sc0 sc1\n\t"
+                                     "global_load_dwordx4 %3, %8, off offset:3072 sc0 sc1\n\t"
+                                     "global_load_dwordx4 %4, %9, off sc0 sc1\n\t"
+                                     "global_load_dwordx4 %5, %9, off offset:1024 sc0 sc1\n\t"
+                                     "global_load_dwordx4 %6, %9, off offset:2048 sc0 sc1\n\t"
+                                     "global_load_dwordx4 %7, %9, off offset:3072 sc0 sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                                     : "v"(q0), "v"(q1)
+                                     : "memory");
+                    } else {
+                        asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+                                     "global_load_dwordx4 %1, %4, off offset:1024 sc0 sc1\n\t"
+                                     "global_load_dwordx4 %2, %4, off offset:2048 sc0 sc1\n\t"
+                                     "global_load_dwordx4 %3, %4, off offset:3072 sc0 sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                                     : "v"(q0)
+                                     : "memory");
+                    }
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
+                    for (int u = 0; u < (NST >= 2 ? 2 : 1); ++u) {
+                        const int mi = (st + u) / TN, ni = (st + u) % TN;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const v4f v = __builtin_nontemporal_load(src + ((mi * TN + ni) * 4 + q) * 64);
-                            acc[mi][ni][4 * q] += v.x;
-                            acc[mi][ni][4 * q + 1] += v.y;
-                            acc[mi][ni][4 * q + 2] += v.z;
-                            acc[mi][ni][4 * q + 3] += v.w;
+                            acc[mi][ni][4 * q] += t[4 * u + q].x;
+                            acc[mi][ni][4 * q + 1] += t[4 * u + q].y;
+                            acc[mi][ni][4 * q + 2] += t[4 * u + q].z;
+                            acc[mi][ni][4 * q + 3] += t[4 * u + q].w;
                         }
+                    }
+                }
             }
         }
     }
