@@ -444,8 +444,8 @@ SPLITK_TILES = (31, 32, 34, 35, 36, 37)
 #: variant is then bit-identical, a one-episode step equals the batched step bit for bit, and metrics cannot differ between
 #: processes or ranks through the (timing-based) variant pick.  ON (PEMP_EVAL_SPLITK=1, ``with ops.eval_splitk():``,
 #: ``Evaluator(splitk=True)``): one-episode steps are ~1.15x faster and agree with the exact path to rounding
-#: (tests/test_eval_protocol_gpu.py states the bounds); the split-K hand-off rests on the behaviour of uncached device memory
-#: described in csrc/conv_dma2.hip, not on the HIP memory model.  Multi-rank jobs broadcast rank 0's picks (tuned_by_rank0).
+#: (tests/test_eval_protocol_gpu.py states the bounds); the split-K hand-off uses device-scope write-through stores and sc1 loads
+#: (csrc/conv_dma2.hip), not the fence pair of the HIP memory model.  Multi-rank jobs broadcast rank 0's picks (tuned_by_rank0).
 EVAL_SPLITK = os.environ.get("PEMP_EVAL_SPLITK", "0") == "1"
 EVAL_SPLITK_MAX_ROWS = int(os.environ.get("PEMP_EVAL_SPLITK_MAX_ROWS", "12000"))
 #: Uncached split-K workspaces, one per (device, scope).  A workspace must never serve two launches that can run beside each
