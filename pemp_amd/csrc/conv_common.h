@@ -101,13 +101,21 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int nblk) {
 // order -> deterministic).
 // EPI 2: the stored value is g = o masked by the sign bits of the BatchNorm output this gradient belongs to, the sums are
 // those of g and g * xhat (first half of that BatchNorm's backward; the expression of colsum_kernel<1> in train_ops.hip).
-template <int TM, int TN, int NPRE, int EPI = 0>
+// DB: DropBlock2D's scaling of the output rows (a.rowmask / a.rowcnt) -- a compile-time variant, instantiated for the kernels of
+// pemp_conv2d_dropblock_nhwc_f32 only.  (As a run-time branch in every epilogue it changed the code generated for the
+// padding-value split-K 128 x 128 kernel into one that returned wrong tiles with rowmask == NULL; the other kernels were not
+// affected in any test, but none of them carries the code any more.)
+template <int TM, int TN, int NPRE, int EPI = 0, bool DB = false>
 __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
                                                       int n_base, int lane, const v4f (&pre)[NPRE], float* R = nullptr) {
     constexpr bool PRE = NPRE == TM * TN * 4;       // (an array of 1 = "no prefetched residual": registers, never scratch)
     const bool relu = a.flags & PEMP_CONV_RELU;
     const bool per_img = a.flags & PEMP_CONV_SHIFT_PER_IMAGE;
-    const float db_sum = a.rowmask ? (float)*a.rowcnt : 1.f, db_numel = (float)a.M;
+    float db_sum = 1.f, db_numel = 1.f;
+    if constexpr (DB) {
+        db_sum = (float)*a.rowcnt;
+        db_numel = (float)a.M;
+    }
     const int lr = lane & 31, lh = lane >> 5;
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
@@ -165,7 +173,7 @@ __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 
                         o.z = fmaxf(o.z, 0.f);
                         o.w = fmaxf(o.w, 0.f);
                     }
-                    if (a.rowmask) {                              // DropBlock2D.forward / its backward, fused (dropout.hip: pixel_scale_kernel)
+                    if constexpr (DB) {                           // DropBlock2D.forward / its backward, fused (dropout.hip: pixel_scale_kernel)
                         const float k = a.rowmask[m];
                         o.x = __fdiv_rn(__fmul_rn(__fmul_rn(o.x, k), db_numel), db_sum);
                         o.y = __fdiv_rn(__fmul_rn(__fmul_rn(o.y, k), db_numel), db_sum);
@@ -224,12 +232,12 @@ __device__ __forceinline__ void conv_stats_store(const ConvArgs& a, const float*
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool DB = false>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
                                                   int n_base, int lane) {
     const v4f none[1] = {{0.f, 0.f, 0.f, 0.f}};
     static_assert(TM * TN * 4 != 1, "tile");
-    conv_epilogue_lds_pre<TM, TN, 1>(a, acc, S, m_base, n_base, lane, none);
+    conv_epilogue_lds_pre<TM, TN, 1, 0, DB>(a, acc, S, m_base, n_base, lane, none);
 }
 
 // conv_dma.hip
@@ -239,6 +247,7 @@ bool conv_dma2_supported(const ConvArgs& a);
 int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st);
 int launch_conv_dma2_group(int tile, ConvGroupArgs& g, hipStream_t st);      // fills g.first / g.nblk
 int launch_conv_dma2_bf16(int tile, const ConvArgs& a, hipStream_t st);      // bf16 operands (Cin / ldx / Kpad in dwords)
+int launch_conv_dma2_db(int tile, ConvArgs a, void* ws, size_t ws_bytes, bool split, hipStream_t st);   // + DropBlock row scaling
 int conv_dma2_tile_rows(int tile);
 // split-K plan of tile variant `tile` (1..7) for this geometry: number of unsplit tiles, split tiles, pieces per split tile
 // (pieces == 1: the variant runs unsplit) and the workspace the launch needs (counters first, then the partial tiles)

@@ -36,7 +36,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // v_mfma_f32_32x32x16_bf16 (lanes 0-31: K 0..7, lanes 32-63: K 8..15 = quads 2j and 2j + 1, exactly the pair a fragment read
 // of step j fetches), so one MFMA does the work of the four v_mfma_f32_32x32x2_f32 of the fp32 kernel at 8 cycles instead of
 // 4 x 64.  Accumulation stays fp32; the epilogue writes bf16 (or fp32 for the last layer) -- PEMP_CONV_BF16_IO.
-template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false>
+template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false, bool DB = false>
 __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid, const int nblk) {
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the launch stub (buffer-resource builtins / "s" asm operands are device-only)
     constexpr int WGN = NW / WGM;
@@ -407,11 +407,11 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     // ---- epilogue: transpose through LDS.  No LDS read and no DMA is outstanding after the loop's last barrier. ----
     float* Rall = (float*)smem + NW * 1024;          // EPI: [NW][TN][2][8][32] sums of the waves, behind their transpose patches
     static_assert(EPI == 0 || NW * 1024 + NW * TN * 512 <= 64 * (BM + BN), "LDS: statistics area");
-    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre, Rall + wave * TN * 512);
+    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI, DB>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre, Rall + wave * TN * 512);
     else if constexpr (EPI != 0) {
         const v4f none[1] = {{0.f, 0.f, 0.f, 0.f}};
         conv_epilogue_lds_pre<TM, TN, 1, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, none, Rall + wave * TN * 512);
-    } else conv_epilogue_lds<TM, TN>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
+    } else conv_epilogue_lds<TM, TN, DB>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
     if constexpr (EPI != 0) {
         __syncthreads();
         conv_stats_store<BN, WGM, NW, TN>(a, Rall, bm, n0, tid);
@@ -419,9 +419,9 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
 #endif
 }
 
-template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false>
+template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false, bool DB = false>
 __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
-    conv_dma2_body<BM, BN, WGM, NW, PADV, EPI, SK, BF16>(a, blockIdx.x, gridDim.x);
+    conv_dma2_body<BM, BN, WGM, NW, PADV, EPI, SK, BF16, DB>(a, blockIdx.x, gridDim.x);
 }
 
 // Several INDEPENDENT convs of the same tile shape in ONE launch: member i owns the blocks [first[i], first[i] + nblk[i]) (the
@@ -514,6 +514,55 @@ int launch_conv_dma2_bf16(int tile, const ConvArgs& a, hipStream_t st) {
     if (tile == 1) return launch_dma2_bf16<128, 128, 2, 4>(a, st);
     if (tile == 2) return launch_dma2_bf16<128, 64, 2, 4>(a, st);
     return launch_dma2_bf16<64, 64, 2, 4>(a, st);
+}
+
+// conv + DropBlock2D's row scaling in the epilogue (pemp_conv2d_dropblock_nhwc_f32): DB instantiations, unsplit and split-K
+template <int BM, int BN, int WGM, int NW, bool SK>
+static int launch_dma2_db(const ConvArgs& a, int grid, hipStream_t st) {
+    const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
+    auto kern = conv_dma2_kernel<BM, BN, WGM, NW, false, 0, SK, false, true>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    return launch_status("conv_dma2/dropblock");
+}
+
+template <bool SK>
+static int launch_db_tile(int tile, const ConvArgs& a, int grid, hipStream_t st) {
+    if (tile == 7) return launch_dma2_db<256, 256, 4, 8, SK>(a, grid, st);
+    if (tile == 6) return launch_dma2_db<256, 128, 4, 8, SK>(a, grid, st);
+    if (tile == 4) return launch_dma2_db<128, 128, 4, 8, SK>(a, grid, st);
+    if (tile == 5) return launch_dma2_db<128, 64, 4, 8, SK>(a, grid, st);
+    if (tile == 1) return launch_dma2_db<128, 128, 2, 4, SK>(a, grid, st);
+    if (tile == 2) return launch_dma2_db<128, 64, 2, 4, SK>(a, grid, st);
+    return launch_dma2_db<64, 64, 2, 4, SK>(a, grid, st);
+}
+
+static void tile_shape(int tile, int& bm, int& bn);
+
+int launch_conv_dma2_db(int tile, ConvArgs a, void* ws, size_t ws_bytes, bool split, hipStream_t st) {
+    int bm, bn;
+    tile_shape(tile, bm, bn);
+    if (split) {
+        const SplitKPlan p = conv_dma2_splitk_plan(tile, a);
+        if (p.pieces >= 2) {
+            if (!ws || ws_bytes < p.ws_bytes || ((uintptr_t)ws & 15)) {
+                set_error("conv split-K: workspace of %zu bytes needed (16-byte aligned), got %zu", p.ws_bytes, ws_bytes);
+                return -1;
+            }
+            a.sk_cnt = (int*)ws;
+            a.sk_ws = (float*)((char*)ws + 1024);
+            a.sk_full = p.full;
+            a.sk_S = p.pieces;
+            return launch_db_tile<true>(tile, a, p.full + p.split * p.pieces, st);
+        }
+    }
+    return launch_db_tile<false>(tile, a, cdiv(a.M, bm) * (a.Cout / bn), st);
 }
 
 int conv_dma2_tile_rows(int tile) {        // BM of tile variant 1..7

@@ -421,8 +421,8 @@ extern "C" int pemp_conv2d_dropblock_nhwc_f32(const pemp_conv_desc* d, const flo
     const int t = d->tile > 30 ? d->tile - 30 : d->tile - 20;
     PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || a.Cout % 128 == 0, "conv2d_dropblock: tile N=128 needs Cout %% 128 == 0");
     PEMP_REQUIRE(t != 7 || a.Cout % 256 == 0, "conv2d_dropblock: tile 256x256 needs Cout %% 256 == 0");
-    if (d->tile > 30) return launch_conv_dma2_splitk(t, a, ws, ws_bytes, (hipStream_t)stream);
-    return launch_conv_dma2(t, a, (hipStream_t)stream);
+    PEMP_REQUIRE(d->tile != 33, "conv2d_dropblock: no split-K variant of the 64 x 64 tile");
+    return launch_conv_dma2_db(t, a, ws, ws_bytes, d->tile > 30, (hipStream_t)stream);
 }
 
 
