@@ -392,8 +392,13 @@ CLASS_OF = {
     "pemp_mpm_protos_f32": "head", "pemp_masked_avg_pool_f32": "head", "pemp_cosine_proto_max_f32": "head",
     "pemp_eval_tail_f32": "head", "pemp_eval_tail_weighted_f32": "head", "pemp_head_bwd_f32": "head",
     "pemp_head_bwd_dlogits_f32": "head", "pemp_upsample_bilinear_ac_f32": "head", "pemp_argmax_masks_f32": "head",
-    "pemp_sgd_clip_step_f32": "optimizer",
+    "pemp_sgd_clip_step_f32": "optimizer", "pemp_adam_clip_step_f32": "optimizer",
+    # round 4: the DropBlock-fused forms, the grouped launch of small evaluation steps, the side figure's bf16 conv
+    "pemp_conv2d_dropblock_nhwc_f32": "conv", "pemp_bn_apply_dropblock_f32": "batchnorm", "pemp_conv2d_group_nhwc_f32": "conv",
+    "pemp_conv2d_bf16_nhwc": "conv",
 }
+_RESIDUAL_AT_6 = ("pemp_conv2d_nhwc_f32", "pemp_conv2d_padv_nhwc_f32", "pemp_conv2d_splitk_nhwc_f32", "pemp_conv2d_padv_splitk_nhwc_f32",
+                  "pemp_conv2d_dropblock_nhwc_f32", "pemp_conv2d_bf16_nhwc")
 
 
 class TimedLib:
@@ -423,13 +428,24 @@ class TimedLib:
 
 def _conv_work(name, a):
     """(flops, algorithmic bytes, (M, N, K, shortcut)) of one conv / weight-gradient launch from its descriptor."""
+    if name == "pemp_conv2d_group_nhwc_f32":       # (n, descriptors, pointer arrays ...): the members' work added up
+        fl = nb = 0.0
+        m_all, n_max, k_max = 0, 0, 0
+        for i in range(int(a[0])):
+            d = a[1][i]
+            m = d.N * d.Ho * d.Wo
+            k = d.KH * d.KW * d.Cin
+            fl += 2.0 * m * d.Cout * k
+            nb += 4.0 * (d.N * d.H * d.W * d.Cin + m * d.Cout + d.Cout * k)
+            m_all, n_max, k_max = m_all + m, max(n_max, d.Cout), max(k_max, k)
+        return fl, nb, (m_all, n_max, k_max, False)
     d = a[0]._obj if hasattr(a[0], "_obj") else a[0].contents
     stem = bool(d.flags & 4)
     cin = 3 if stem else d.Cin
     m = d.N * d.Ho * d.Wo
     k = d.KH * d.KW * cin
     flops = 2.0 * m * d.Cout * k
-    res = (name in ("pemp_conv2d_nhwc_f32", "pemp_conv2d_padv_nhwc_f32", "pemp_conv2d_splitk_nhwc_f32", "pemp_conv2d_padv_splitk_nhwc_f32") and bool(a[6])) or (name == "pemp_conv2d_bnbwd_nhwc_f32" and bool(a[4]))
+    res = (name in _RESIDUAL_AT_6 and bool(a[6])) or (name == "pemp_conv2d_bnbwd_nhwc_f32" and bool(a[4]))
     outs = (2 if res else 1) + (1 if name == "pemp_conv2d_bnbwd_nhwc_f32" else 0)       # bnbwd also reads the BatchNorm's input z
     nbytes = 4.0 * (d.N * d.H * d.W * d.Cin + m * d.Cout * outs + d.Cout * d.KH * d.KW * d.Cin)
     return flops, nbytes, (m, d.Cout, k, res)

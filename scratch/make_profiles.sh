@@ -1,6 +1,6 @@
 #!/bin/bash
 # Produces the round's measurement artefacts under gpurun_out/$R/ on the GPU box (copy into profiles/ afterwards, prefixed with $R_):
-#   [R=r04] bash scratch/make_profiles.sh [part]        part = bench | trace | head | pmc | pmctrain | all (default)
+#   [R=r04] bash scratch/make_profiles.sh [part]        part = bench | trace | b1 | head | pmc | pmctrain | all (default)
 # rocprofv3 is always given the program itself after `--` (python3 bench.py ...), never a wrapper.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -40,6 +40,15 @@ for tag in eval train evalcedt; do
   rm -rf $O/kt_$tag
 done
 unset PEMP_BENCH_LANES
+fi
+if [ $PART = b1 ] || [ $PART = all ]; then
+# 2b. the one-episode step (split-K variants allowed, one lane) kernel by kernel
+export PEMP_BENCH_LANES=1 PEMP_EVAL_SPLITK=1
+rm -rf $O/kt_b1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_b1 -- python3 bench.py --batch 1 --steps 20 --warmup 5 $B --no-roofline > $O/kt_b1.log 2>&1 || echo "kt b1 failed"
+find $O/kt_b1 -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 scratch/profile_summary.py {} $O/eval_b1_steady.json eval 46
+rm -rf $O/kt_b1
+unset PEMP_BENCH_LANES PEMP_EVAL_SPLITK
 fi
 if [ $PART = head ] || [ $PART = all ]; then
 # 4. prototype-head kernels alone at 133 / 320 / 533 MB per launch (the last two beyond the 256 MB Infinity Cache); CELossDT kernels

@@ -886,3 +886,24 @@ def test_oracle_training_trajectory_matches_the_reference():
         worst = max(worst, float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)))
     assert worst <= 1e-6, worst
     assert int(sd["encoder.backbone.bn1.num_batches_tracked"]) == int(g["buf__encoder.backbone.bn1.num_batches_tracked"]) == 5
+
+
+def test_bench_counts_the_work_of_every_gemm_entry_point():
+    """bench.py's live roofline adds up FLOPs per C-ABI entry point: an implicit-GEMM entry it does not know lands in class
+    `other` with no work, and the step's TFLOP/s is quoted too low (round 4: the DropBlock-fused conv and the grouped launch
+    were missing for a while).  Every launching `pemp_conv2d*` symbol of the library must have a class, and the grouped
+    launch's work is the sum of its members'."""
+    import ctypes as C
+    import bench
+    from pemp_amd import _lib, ops
+    launching = [n for n in _lib.SYMBOLS if n.startswith("pemp_conv2d") and not n.endswith("_bytes") and n != "pemp_conv2d_stats_rows"]
+    assert len(launching) >= 10
+    for n in launching:
+        assert bench.CLASS_OF.get(n) in ("conv", "wgrad"), n
+    d = [(2, 51, 51, 256, 256, 51, 51, 256, 1024, 3, 3, 1, 6, 6, 0, 2304, 0), (2, 51, 51, 256, 256, 51, 51, 128, 1024, 1, 1, 1, 0, 1, 0, 256, 0)]
+    da = (ops.ConvDesc * 2)(*[ops.ConvDesc(*t, 23) for t in d])
+    fl, nb, shape = bench._conv_work("pemp_conv2d_group_nhwc_f32", (2, da, None, None, None, None, None, None, None, None))
+    m = 2 * 51 * 51
+    assert fl == 2.0 * m * 256 * 2304 + 2.0 * m * 128 * 256 and shape == (2 * m, 256, 2304, False) and nb > 0
+    one = bench._conv_work("pemp_conv2d_dropblock_nhwc_f32", (C.byref(da[0]), 1, 1, 1, None, None, 5, 1, 1, None, 0, None))
+    assert one[0] == 2.0 * m * 256 * 2304 and one[2] == (m, 256, 2304, True)
