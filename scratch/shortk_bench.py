@@ -44,7 +44,7 @@ for cin, cout in ((256, 1024), (128, 512), (1024, 256), (512, 128)):
                          ("bnbwd+res", lambda: ops.conv2d_bnbwd(x, p, bn, residual=res, out=out, tile=tile))):
             try:
                 us = timeit(fn)
-                row.append("%s %6.1f us %5.1f TF" % (name, us, gf / us * 1e-3 * 1e6 / 1e3))
+                row.append("%s %6.1f us %5.1f TF" % (name, us, gf / us * 1e3))
             except Exception as e:  # noqa: BLE001
                 row.append("%s  n/a" % name)
         print("   tile %2d: " % tile + " | ".join(row), flush=True)
