@@ -392,6 +392,66 @@ def test_overlapped_gradient_buckets_on_one_rank_match_the_plain_step(hip_lib, d
         dist.destroy_process_group()
 
 
+def test_bench_collectives_run_on_rccl_with_one_rank(hip_lib, dev):
+    """Every collective call pattern of the N > 1 bench lines and of the evaluation loop, on RCCL itself with one rank (the
+    collectives are identities; what is checked is that RCCL on this platform takes these dtypes and call forms, that the
+    results come back on the device, and that the device is usable after the group is destroyed, as bench.py's rank 0
+    needs it): the round table's float64 all-reduce, float64 all-gather and MAX all-reduce of the timing scalars, broadcasts of
+    the fp32 flat buffer and of an int64 BatchNorm counter, the tile picks' object broadcast, barrier."""
+    import socket
+    import torch.distributed as dist
+    import bench
+    from pemp_amd import ops
+    from pemp_amd.entry.pemp_stage1 import DeviceRoundTable
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    except Exception as e:
+        pytest.skip(f"RCCL process group unavailable: {e}")
+    try:
+        dist.barrier()
+        table = DeviceRoundTable(20, dev)
+        table.reset()
+        rows = torch.tensor([[5.0, 2.0, 1.0, 7.0, 3.0, 2.0, 4.0, 1.0]] * 3, dtype=torch.float64, device=dev)
+        table.add(rows, torch.tensor([1, 4, 4], device=dev))
+        before = table.pack.clone()
+        assert before.dtype == torch.float64
+        dist.all_reduce(table.pack, op=dist.ReduceOp.SUM)
+        assert torch.equal(table.pack, before)
+        got = [torch.zeros_like(before)]
+        dist.all_gather(got, before)
+        assert torch.equal(got[0], before)
+        assert bench.gather_rank_ms(0.5, 10, 1, dev) == [50.0]
+        tmax = torch.tensor([1.25], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        assert float(tmax.item()) == 1.25
+        flat = torch.randn(1 << 20, device=dev)
+        keep = flat.clone()
+        dist.broadcast(flat, 0)
+        counter = torch.tensor(7, dtype=torch.int64, device=dev)
+        dist.broadcast(counter, 0)
+        assert torch.equal(flat, keep) and int(counter.item()) == 7
+        box = [{"picks": {"(1, 2, 3)": 27}, "wgrad": [[2, 512]]}]
+        dist.broadcast_object_list(box, src=0)
+        assert box[0]["picks"]["(1, 2, 3)"] == 27
+        assert bench.rccl_version() is not None
+        assert bench.comm_object(1, [50.0])["rank_ms_per_step"]["max"] == 50.0
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    # the device after the group is gone (bench.py's rank 0 measures its roofline then)
+    x = torch.randn(1, 13, 13, 64, device=dev)
+    w = torch.randn(64, 64, 1, 1, device=dev)
+    pk, kp = ops.pack_conv_weight(w)
+    y = ops.conv2d(x, ops.ConvParams(pk, None, None, 64, 64, 1, 1, 1, 0, 1, kp, False, False))
+    assert torch.isfinite(y).all()
+
+
 def test_train_command_writes_a_fresh_run_and_test_command_loads_it(hip_lib, dev, tmp_path):
     """The command layer end to end (reference entry/pemp_stage1.py:68-113,116-167): ``train`` writes checkpoints into a
     FRESH run directory (never into an existing one), ``test with exp_id=<run>`` finds that checkpoint with the
