@@ -74,3 +74,34 @@ def test_the_probe_sees_a_displaced_tap(hip_lib, dev):
     w_one[:, :, 1, 2] = w[:, :, 1, 2]
     off = ref - _reference(x, w_one, pv, d) + _reference(shifted, w_one, pv, d)
     assert (off != ref).float().mean().item() > 0.5
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, k, pad, dilation (stride 1): training shapes of the buffer-addressed weight-gradient kernels
+    (8, 51, 51, 128, 128, 3, 2, 2), (8, 51, 51, 128, 256, 1, 0, 1), (2, 101, 101, 64, 64, 3, 1, 1), (3, 37, 45, 128, 128, 3, 6, 6)],
+    ids=lambda c: "x".join(str(v) for v in c))
+def test_every_weight_gradient_variant_is_exact_on_integer_probes(hip_lib, dev, case):
+    """The same idea for dW = sum over pixels of g^T x_col: small integers on both sides keep every partial sum below 2^24, so
+    both kernel generations, both tile kinds and every block count (= every regrouping of the sum over pixels) must give the
+    float64 result exactly."""
+    from pemp_amd import ops, train_ops as T
+    N, H, W, Cin, Cout, k, p, d = case
+    M = N * H * W
+    m = torch.arange(M, dtype=torch.int64)
+    x = ((m[:, None] * 5 + torch.arange(Cin)[None, :] * 3) % 16).view(N, H, W, Cin).double()            # 0..15
+    g = ((m[:, None] * 11 + torch.arange(Cout)[None, :] * 7) % 13 % 4).view(N, H, W, Cout).double()    # 0..3, H == Ho (same-size conv)
+    assert 15 * 3 * M < 2 ** 24
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (Cout, Cin, k, k), g.permute(0, 3, 1, 2), 1, p, d)
+    ref = ref.permute(0, 2, 3, 1).reshape(Cout, -1).float().to(dev)                                     # KRSC rows, as the kernels write them
+    prm = ops.ConvParams(None, None, None, Cin, Cout, k, k, 1, p, d, k * k * Cin, False, False)
+    xd, gd = x.float().to(dev), g.float().to(dev)
+    picks = [(1, 0), (0, 0)] + [((kind, nb) if kind else nb, None) for kind in ((2, 3) if Cin % 128 == 0 and Cout % 128 == 0 else (0,))
+                                for nb in T.WGRAD_BLOCK_CHOICES]
+    for a, b in picks:
+        dw = torch.full((Cout, k * k * Cin), float("nan"), device=dev)
+        if b is None:
+            T.conv_wgrad(xd, gd, prm, dw, blocks=a)
+        else:
+            T.conv_wgrad(xd, gd, prm, dw, variant=a, blocks=b)
+        bad = dw != ref
+        assert not bool(bad.any()), (case, a, b, int(bad.sum()), (dw - ref)[bad][:4].tolist())
