@@ -1,4 +1,4 @@
-"""Integer probes of the buffer-addressed conv kernels (csrc/conv_dma2.hip): inputs, weights and padding values are small
+"""Integer probes of the conv kernels (csrc/conv_dma2.hip and its fall-backs): inputs, weights and padding values are small
 integers, so every partial sum is an integer below 2^24 and fp32 addition is exact IN ANY ORDER -- every tile variant, the
 split-K ones included, must equal the float64 CPU convolution EXACTLY, on tiles that are computed whole and on tiles that are
 split.  What this catches that a comparison between variants on random data does not: a wrong tap displacement, a wrong
@@ -11,7 +11,9 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TILE_N = {21: 128, 22: 64, 23: 64, 24: 128, 25: 64, 26: 128, 27: 256, 31: 128, 32: 64, 34: 128, 35: 64, 36: 128, 37: 256}
+TILE_N = {21: 128, 22: 64, 23: 64, 24: 128, 25: 64, 26: 128, 27: 256, 31: 128, 32: 64, 34: 128, 35: 64, 36: 128, 37: 256,
+          # the pointer-addressed LDS-DMA kernels (conv_dma.hip) and the first-generation kernel (conv_igemm.hip): the fall-backs
+          11: 128, 12: 64, 13: 64, 14: 128, 15: 64, 16: 128, 17: 256, 1: 128, 2: 64, 3: 64}
 
 # (N, H, W, Cin, dilation): 5202 rows = 82 tiles of 128 x 128 (every tile split); 20 808 rows = whole AND split tiles in one launch
 # (326 tiles on 256 CUs); a non-square map under another dilation; a small map with dilation 1
