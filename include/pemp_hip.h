@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PEMP_ABI_VERSION 1
+#define PEMP_ABI_VERSION 2   /* 2: pemp_adam_clip_step_f32 takes its hyper-parameters as doubles (round 5) */
 
 /* flags for pemp_conv_desc.flags */
 #define PEMP_CONV_RELU 1u          /* y = max(y, 0) after affine (+ residual)            */
@@ -415,9 +415,11 @@ int pemp_sgd_clip_step_f32(float* params, const float* grads, float* momentum_bu
                            void* stream);
 /* clip_grad_norm_(max_norm) + torch.optim.Adam(lr, betas, eps, weight_decay).step() (reference core/solver.py:92-96,
  * tr.opt = adam; ATen's operation order, L2 weight decay, no amsgrad).  exp_avg / exp_avg_sq: the optimizer state, zero before
- * the first update; step: 1-based number of this update.  Workspace: pemp_sgd_workspace_bytes().                          */
+ * the first update; step: 1-based number of this update.  Workspace: pemp_sgd_workspace_bytes().  lr / betas / eps /
+ * weight_decay are doubles because torch.optim.Adam holds them as Python floats and forms 1 - beta, lr / bias1 and
+ * sqrt(bias2) in double before narrowing each to float once (float(1 - 0.999) != 1.f - 0.999f by 1.3e-5 relative).        */
 int pemp_adam_clip_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
-                            float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
                             long long step, float grad_scale, float* grad_norm_out, void* ws, size_t ws_bytes, void* stream);
 
 /* Train-time regularisers.  Random numbers: counter-based Philox4x32-10, element i of stream (seed, offset)

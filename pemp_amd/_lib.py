@@ -130,10 +130,11 @@ SYMBOLS = {
     "pemp_sgd_clip_step_f32": (c_int, [c_fp, c_fp, c_fp, C.c_longlong, C.c_float, C.c_float, C.c_float,
                                        C.c_float, c_int, C.c_float, c_int, c_fp, c_fp, c_size, c_fp]),
     "pemp_dgrad_mirror_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
-    "pemp_adam_clip_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, C.c_longlong] + [C.c_float] * 6 + [C.c_longlong, C.c_float, c_fp, c_fp,
+    "pemp_adam_clip_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, C.c_longlong, C.c_float] + [C.c_double] * 5 + [C.c_longlong, C.c_float, c_fp, c_fp,
                                                                                                   c_size, c_fp]),
 }
 
+ABI_VERSION = 2          # include/pemp_hip.h: PEMP_ABI_VERSION
 _lib = None
 
 
@@ -155,8 +156,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.pemp_abi_version() != 1:
-        raise PempHipError(f"ABI version mismatch: library {lib.pemp_abi_version()}, binding 1")
+    if lib.pemp_abi_version() != ABI_VERSION:
+        raise PempHipError(f"ABI version mismatch: library {lib.pemp_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -645,25 +645,28 @@ __global__ void sgd_clip_kernel(float* __restrict__ p, const float* __restrict__
 }
 
 // torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (L2 weight decay added to the gradient, no amsgrad) in one pass, in the
-// operation order of ATen's single-tensor Adam:  g = coef * g + wd * p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;
-// p -= step_size * m / (sqrt(v) / sqrt(bias2) + eps)   with step_size = lr / bias1 (the bias corrections come from the host).
+// operation order of ATen's Adam (torch/optim/adam.py, _single_tensor_adam / _multi_tensor_adam -- the same arithmetic):
+//   g = coef * g + wd * p;  m.lerp_(g, 1 - b1);  v = b2 v + (1 - b2) g g;  p -= step_size * m / (sqrt(v) / sqrt(bias2) + eps)
+// with step_size = lr / bias1.  The hyper-parameters reach ATen as Python floats (doubles) and are narrowed to float once
+// per scalar -- 1 - beta in double FIRST: float(1 - 0.999) and 1.f - 0.999f differ by 1.3e-5 relative -- so the host does
+// exactly that (omb1 / omb2 below) instead of subtracting in float.
 __global__ void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, long long n, const float* __restrict__ norm, float max_norm,
-                                 float step_size, float bias2_sqrt, float b1, float b2, float eps, float wd,
+                                 float step_size, float bias2_sqrt, float omb1, float b2, float omb2, float eps, float wd,
                                  float grad_scale) {
     float coef = 1.f;
     if (max_norm > 0.f) coef = fminf(max_norm / (norm[0] * grad_scale + 1e-6f), 1.f);
     coef *= grad_scale;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float w = p[i];
-        const float d = __fmaf_rn(wd, w, g[i] * coef);
+        const float d = __fmaf_rn(wd, w, g[i] * coef);                      // grad.add(param, alpha = wd) on the clipped gradient
         const float m0 = m[i];
-        const float mi = __fmaf_rn(1.f - b1, d - m0, m0);                    // exp_avg.lerp_(grad, 1 - beta1): m + (1 - b1)(g - m)
-        const float vi = __fmaf_rn((1.f - b2) * d, d, b2 * v[i]);
+        const float mi = __fmaf_rn(omb1, d - m0, m0);                       // exp_avg.lerp_(grad, 1 - beta1): m + (1 - b1)(g - m)
+        const float vi = __fmaf_rn(omb2 * d, d, b2 * v[i]);                 // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / bias2_sqrt + eps;
-        p[i] = w - step_size * (mi / denom);
+        p[i] = w - step_size * (mi / denom);                                // param.addcdiv_(exp_avg, denom, value = -step_size)
     }
 }
 
@@ -906,19 +909,20 @@ extern "C" int pemp_sgd_clip_step_f32(float* params, const float* grads, float* 
 // clip_grad_norm_(max_norm) + torch.optim.Adam(lr, betas, eps, weight_decay).step() on the flat buffers (reference
 // core/solver.py:92-96: tr.opt = adam).  step = the 1-based number of this update (bias corrections 1 - beta^step).
 extern "C" int pemp_adam_clip_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
-                                       float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                       float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay,
                                        long long step, float grad_scale, float* grad_norm_out, void* ws, size_t ws_bytes,
                                        void* stream) {
     PEMP_REQUIRE(params && grads && exp_avg && exp_avg_sq && grad_norm_out && ws && n > 0 && step >= 1, "adam_clip_step: bad arguments");
     PEMP_REQUIRE(ws_bytes >= pemp_sgd_workspace_bytes(), "adam_clip_step: workspace too small");
-    PEMP_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "adam_clip_step: betas in [0, 1), eps >= 0");
+    PEMP_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "adam_clip_step: betas in [0, 1), eps >= 0");
     hipStream_t st = (hipStream_t)stream;
     const int nb = 1024;
     hipLaunchKernelGGL(sqsum_partial_kernel, dim3(nb), dim3(256), 0, st, grads, n, (double*)ws);
     hipLaunchKernelGGL(sqsum_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, grad_norm_out);
-    const double bias1 = 1.0 - pow((double)beta1, (double)step), bias2 = 1.0 - pow((double)beta2, (double)step);
+    // torch/optim/adam.py: bias corrections, step_size and sqrt(bias2) are Python-float (double) arithmetic on the host
+    const double bias1 = 1.0 - pow(beta1, (double)step), bias2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_clip_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n,
-                       (const float*)grad_norm_out, max_norm, (float)((double)lr / bias1), (float)sqrt(bias2), beta1, beta2, eps,
-                       weight_decay, grad_scale);
+                       (const float*)grad_norm_out, max_norm, (float)(lr / bias1), (float)sqrt(bias2), (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, grad_scale);
     return launch_status("adam_clip_step");
 }

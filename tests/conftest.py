@@ -12,6 +12,35 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order of the GPU suite.  The driver runs `pytest -m gpu -x`: whatever fails first hides everything behind it, so
+# the suite runs from the sharpest evidence to the bluntest -- (0) single kernels against torch / float64 on the CPU (conv
+# variants, training ops, split-K hand-off, optimizer kernels), (1) the one-rank RCCL choreography, (2) whole models against
+# the reference-made fixtures and the oracle, (3) whole training steps against fixtures, (4) multi-step / statistical
+# behaviour (fits a batch, trajectories, loops).  Inside a tier the file / definition order is kept.
+_FILE_TIER = {
+    "test_ops_gpu.py": 0, "test_conv_probe_gpu.py": 0, "test_conv_fuzz_gpu.py": 0, "test_train_ops_gpu.py": 0,
+    "test_cedt_gpu.py": 0, "test_episode_io_gpu.py": 0, "test_regularisers_gpu.py": 0, "test_properties_gpu.py": 0,
+    "test_bf16_variant_gpu.py": 0,
+    "test_stage1_gpu.py": 2, "test_models_gpu.py": 2, "test_panet_gpu.py": 2, "test_eval_protocol_gpu.py": 2,
+    "test_autograd_bridge_gpu.py": 2, "test_grad_frozen_gpu.py": 3, "test_train_gpu.py": 3,
+}
+_TEST_TIER = {
+    "test_optimizer_step_matches_torch_sgd": 0, "test_fused_adam_step_matches_torch_adam": 0,
+    "test_overlapped_gradient_buckets_on_one_rank_match_the_plain_step": 1, "test_bench_collectives_run_on_rccl_with_one_rank": 1,
+    "test_two_steps_reduce_loss_and_dropblock_runs": 4, "test_training_fits_a_fixed_batch": 4,
+    "test_training_loop_epochs_eval_and_checkpoints": 4, "test_five_step_trajectory_matches_the_reference": 4,
+    "test_train_command_writes_a_fresh_run_and_test_command_loads_it": 4,
+}
+
+
+def pytest_collection_modifyitems(config, items):
+    def tier(item):
+        name = getattr(item, "originalname", None) or item.name.split("[")[0]
+        return _TEST_TIER.get(name, _FILE_TIER.get(os.path.basename(str(item.fspath)), 2))
+    order = {id(it): i for i, it in enumerate(items)}
+    items.sort(key=lambda it: (tier(it), order[id(it)]))
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     """The C-ABI library; built on demand (hipcc cross-compiles without a GPU)."""

@@ -398,7 +398,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert hip_lib.pemp_abi_version() == 1
+    assert hip_lib.pemp_abi_version() == 2
     assert ctypes.sizeof(_lib.ConvDesc) == 18 * 4
     # argument validation happens before any device work
     d = _lib.ConvDesc()

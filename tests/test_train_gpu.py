@@ -95,35 +95,96 @@ def test_optimizer_step_matches_torch_sgd(hip_lib, dev):
     fresh.load_state_dict({k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()})
 
 
+def _adam_f64_with_bound(w, g, m0, v0, coef, hp, step):
+    """ATen's Adam update (torch/optim/adam.py: _single_tensor_adam == _multi_tensor_adam arithmetic) evaluated in float64
+    on float32 inputs, with the float-narrowed scalars ATen uses, and a FORWARD ERROR BOUND per element for any float32
+    evaluation of the same expression (u = 2^-24, one rounding per operation, first order):
+        d  = coef g + wd w                         dd = u (2 |coef g| + |d|)
+        m  = m0 + (1 - b1)(d - m0)                 dm = (1 - b1) dd + u ((1 - b1) |d - m0| + |m|)
+        v  = b2 v0 + (1 - b2) d^2                  dv = (1 - b2)(2 |d| + dd) dd + u (b2 v0 + 2 (1 - b2) d^2 + v) + 2^-148
+        q  = sqrt(v) / sqrt(bias2) + eps           dq = (sqrt(v + dv) - sqrt(max(v - dv, 0))) / sqrt(bias2) + 3 u q
+        p  = w - s m / q                           dp = s (dm / q + (|m| + dm) dq / q^2) + 3 u |s m / q| + u |p|
+    (dd can exceed |d| where the two terms of d cancel completely: the dd^2 and dm dq terms are kept for that.)
+    For an element whose clipped gradient and weight-decay term cancel (|d| <~ eps) the step is lr d / (|d| + eps), slope
+    lr / eps = 2e5: dd is a few ulp of |coef g|, not of |d|, and the bound carries exactly that amplification -- it is
+    the reason a fixed rtol / atol cannot hold for every element of a 12 M-element gradient."""
+    b1, b2 = hp["betas"]
+    f32 = lambda x: float(np.float32(x))
+    bias1, bias2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+    s, c = f32(hp["lr"] / bias1), f32(bias2 ** 0.5)
+    omb1, b2f, omb2, eps, wd = f32(1.0 - b1), f32(b2), f32(1.0 - b2), f32(hp["eps"]), f32(hp["weight_decay"])
+    u = 2.0 ** -24
+    w, g, m0, v0 = (t.double() for t in (w, g, m0, v0))
+    gc = coef * g
+    d = gc + wd * w
+    dd = u * (2 * gc.abs() + d.abs())
+    m = m0 + omb1 * (d - m0)
+    dm = omb1 * dd + u * (omb1 * (d - m0).abs() + m.abs())
+    v = b2f * v0 + omb2 * d * d
+    dv = omb2 * (2 * d.abs() + dd) * dd + u * (b2f * v0 + 2 * omb2 * d * d + v) + 2.0 ** -148
+    q = v.sqrt() / c + eps
+    dq = ((v + dv).sqrt() - (v - dv).clamp_min(0).sqrt()) / c + 3 * u * q
+    upd = s * m / q
+    p = w - upd
+    dp = s * (dm / q + (m.abs() + dm) * dq / (q * q)) + 3 * u * upd.abs() + u * p.abs()
+    return p, m, v, dp, dm, dv
+
+
 def test_fused_adam_step_matches_torch_adam(hip_lib, dev):
-    """tr.opt = adam (reference core/solver.py:92-96): three updates by the fused clip + Adam kernel on the flat buffers ==
-    clip_grad_norm_ + torch.optim.Adam(betas, eps, weight_decay) on copies of the same parameters fed the same gradients."""
+    """tr.opt = adam (reference core/solver.py:92-96): three updates by the fused clip + Adam kernel on the flat buffers
+    against (a) ATen's update evaluated in float64 from the same float32 parameters, gradients and moments, EVERY element
+    inside the derived forward-error bound of `_adam_f64_with_bound` (x 4: first-order terms, ATen's scalar division by
+    reciprocal), no allowance for outliers; (b) torch.optim.Adam itself on a copy of the flat buffer, fed the gradient clipped
+    by the kernel's own coefficient, held to the same bound -- which pins the float64 model to torch's semantics; (c)
+    clip_grad_norm_'s total norm within 1e-5 relative (float32 sum of per-tensor norms against the kernel's double sum).
+    Rounds 3-4 counted elements outside rtol 2e-6 / atol 2e-7 and allowed 12, then 40; a fresh box saw 80 -- the count of
+    near-cancelling elements is a property of the gradient, not a constant (and the reference side clipped with torch's
+    norm, 1e-5 away from the kernel's: another 1e-5 |g| of dd)."""
     tr, net = _trainer(dev)
     plist = [p for p in net.parameters() if p.requires_grad]
-    ref = [torch.nn.Parameter(p.detach().clone().contiguous()) for p in plist]
     hp = dict(lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
-    opt_ref = torch.optim.Adam(ref, **hp)
     tr.attach_optimizer(torch.optim.Adam(plist, **hp))
-    for step, seeds in enumerate(((31, 32), (33, 34), (35, 36))):
+    f = tr.eng.flat
+    assert f.data.numel() == sum(p.numel() for p in plist)
+    ref = torch.nn.Parameter(f.data.detach().clone())
+    opt_ref = torch.optim.Adam([ref], **hp)
+    worst = 0.0
+    for step, seeds in enumerate(((31, 32), (33, 34), (35, 36)), start=1):
         sup, msk, qry, gt = _batch(dev, seeds)
         tr.forward_backward(sup, msk, qry, gt)
-        for r, p in zip(ref, plist):
-            r.grad = p.grad.detach().clone().contiguous()
-        total = torch.nn.utils.clip_grad_norm_(ref, 1.1)
-        opt_ref.step()
+        w0, g = f.data.detach().clone(), f.grad.detach().clone()
+        if step == 1:
+            m0, v0 = torch.zeros_like(w0), torch.zeros_like(w0)
+        else:
+            m0, v0 = f.exp_avg.clone(), f.exp_avg_sq.clone()
+        total = torch.nn.utils.get_total_norm([p.grad for p in plist])        # what clip_grad_norm_ computes and returns
         tr.optimizer_step()
-        assert abs(tr.last_grad_norm.item() - total.item()) <= 1e-5 * total.item()
-        # Adam's update is lr * m / (sqrt(v) + eps): for an element whose clipped gradient and weight-decay term cancel to
-        # within rounding (|g'| ~ eps = 1e-8) the update is a sign function of the last bit -- a handful of the 12 M elements
-        # may land on the other side (by at most 2 lr); all others must agree to rounding
-        bad = 0
-        for r, p in zip(ref, plist):
-            off = ~torch.isclose(p.detach(), r.detach(), rtol=2e-6, atol=2e-7)
-            bad += int(off.sum())
-            if off.any():
-                assert (p.detach() - r.detach())[off].abs().max().item() <= 2 * hp["lr"] * 1.001, step
-            r.data.copy_(p.detach())           # same starting point for the next step: rounding does not accumulate into the comparison
-        assert bad <= 40, (step, bad)          # seen: 0 .. 14 of 11 955 392, varying with the autotuned kernel picks (rounding)
+        norm = np.float32(tr.last_grad_norm.item())
+        assert abs(float(norm) - total.item()) <= 1e-5 * total.item()
+        # the kernel's clip coefficient, in its own float32 arithmetic (train_ops.hip: adam_clip_kernel)
+        coef = np.minimum(np.float32(tr.max_norm) / (norm * np.float32(1.0) + np.float32(1e-6)), np.float32(1.0))
+        assert coef < 1.0 or total.item() <= tr.max_norm
+        p64, m64, v64, dp, dm, dv = _adam_f64_with_bound(w0, g, m0, v0, float(coef), hp, step)
+        for name, got, want, tol in (("param", f.data, p64, dp), ("exp_avg", f.exp_avg, m64, dm), ("exp_avg_sq", f.exp_avg_sq, v64, dv)):
+            ratio = ((got.double() - want).abs() / tol.clamp_min(1e-300)).max().item()
+            worst = max(worst, ratio)
+            assert ratio <= 4.0, (step, name, ratio)
+        # torch.optim.Adam from the same state, gradient clipped by the same coefficient
+        with torch.no_grad():
+            ref.copy_(w0)
+            if step > 1:
+                opt_ref.state[ref]["exp_avg"].copy_(m0)
+                opt_ref.state[ref]["exp_avg_sq"].copy_(v0)
+        ref.grad = g * float(coef)
+        opt_ref.step()
+        st = opt_ref.state[ref]
+        assert int(st["step"]) == step
+        for name, got, want, tol in (("param", ref.detach(), p64, dp), ("exp_avg", st["exp_avg"], m64, dm), ("exp_avg_sq", st["exp_avg_sq"], v64, dv)):
+            ratio = ((got.double() - want).abs() / tol.clamp_min(1e-300)).max().item()
+            assert ratio <= 4.0, (step, "torch " + name, ratio)
+        # and the parameters the model sees are the flat buffer (reference-shaped views)
+        assert all(p.data_ptr() >= f.data.data_ptr() and p.data_ptr() < f.data.data_ptr() + f.data.numel() * 4 for p in plist)
+    print("adam: worst |hip - f64| / bound = %.3f" % worst)
     assert tr.eng.flat.adam_step == 3 and not tr.optimizer.state      # the torch object only carries the hyper-parameters
 
 
