@@ -102,9 +102,9 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int nblk) {
 // EPI 2: the stored value is g = o masked by the sign bits of the BatchNorm output this gradient belongs to, the sums are
 // those of g and g * xhat (first half of that BatchNorm's backward; the expression of colsum_kernel<1> in train_ops.hip).
 // DB: DropBlock2D's scaling of the output rows (a.rowmask / a.rowcnt) -- a compile-time variant, instantiated for the kernels of
-// pemp_conv2d_dropblock_nhwc_f32 only.  (As a run-time branch in every epilogue it changed the code generated for the
-// padding-value split-K 128 x 128 kernel into one that returned wrong tiles with rowmask == NULL; the other kernels were not
-// affected in any test, but none of them carries the code any more.)
+// pemp_conv2d_dropblock_nhwc_f32 only: it keeps the four instructions out of every other epilogue.  (Round 4 made it one because
+// the run-time branch "broke" one kernel; the cause was an unrelated wait-state hazard in conv_dma2.hip's inline asm that the
+// branch merely re-scheduled into view -- DESIGN.md section 4, scratch/t31/README.md.)
 template <int TM, int TN, int NPRE, int EPI = 0, bool DB = false>
 __device__ __forceinline__ void conv_epilogue_lds_pre(const ConvArgs& a, f32x16 (&acc)[TM][TN], float* S, int m_base,
                                                       int n_base, int lane, const v4f (&pre)[NPRE], float* R = nullptr) {

@@ -162,8 +162,18 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     // (the three loop-invariant inputs are produced by an asm statement with an "=s" result: hipcc has been seen to keep
     // a uniform value -- even the result of __builtin_amdgcn_readfirstlane -- in a VGPR and to print that VGPR into an
     // "s" operand)
+    // HAZARDS the statement must cover itself (gfx940 / gfx950 wait-state rules that hipcc's hazard recogniser applies to the
+    // instructions it schedules, NOT to the text of an inline-asm statement): "VALU writes a VGPR -> v_readlane /
+    // v_readfirstlane reads it: 1 wait state" on the way in -- the "v" inputs are materialised by the compiler (v_mov /
+    // v_cndmask from SGPRs) and may be the very instruction in front of the statement -- and "VALU writes an SGPR -> VALU reads it:
+    // 2, v_readlane lane select: 4, VMEM reads it: 5 wait states" on the way out.  Hence the leading s_nop 0 and the trailing
+    // s_nop 4.  Round 4's "tile 31" wrong results were exactly the first one: in ONE instantiation (128 x 128, 4 waves, padding
+    // value, split-K) the scheduler put `v_cndmask_b32 v3, 0, 1, s[8:9]` (ntaps > 1 ? 1 : 0) directly in front of
+    // `v_readfirstlane_b32 s8, v3`, the read returned v3's previous content, `multi` came out 0 and the K loop walked a 3 x 3
+    // conv as if it were 1 x 1 (found round 5 by tracing the scalar state of the failing binary and inserting single s_nops
+    // into its assembly: DESIGN.md section 4).
     int multi, s_kw, s_ntaps;
-    asm volatile("v_readfirstlane_b32 %0, %3\n\tv_readfirstlane_b32 %1, %4\n\tv_readfirstlane_b32 %2, %5"
+    asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %3\n\tv_readfirstlane_b32 %1, %4\n\tv_readfirstlane_b32 %2, %5\n\ts_nop 4"
                  : "=s"(multi), "=s"(s_kw), "=s"(s_ntaps)
                  : "v"(a.ntaps > 1 ? 1 : 0), "v"(a.KW), "v"(a.ntaps));
 #define PEMP_ADVANCE2()                                                                                           \

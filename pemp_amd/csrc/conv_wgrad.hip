@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradArgs a) {
     // SGPR (inline asm: left to hipcc it sits in a VGPR and every LDS-DMA that uses it as soffset becomes a readfirstlane
     // loop -- four of them per step, which also keeps the scheduler from placing the DMA issue between the MFMAs).
     int s_g0, s_ginc;                      // soffset of step k of this block = s_g0 + k * s_ginc, computed on the scalar unit
-    asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3"
+    // (leading s_nop 0 / trailing s_nop 4: the gfx950 wait states "VALU writes VGPR -> v_readfirstlane reads it" and "VALU writes
+    // SGPR -> VALU / VMEM reads it", which hipcc does not insert around the text of an asm statement -- see conv_dma2.hip)
+    asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 4"
                  : "=s"(s_g0), "=s"(s_ginc)
                  : "v"(s_begin * 32 * a.ldg * 4), "v"(32 * a.ldg * 4));
 

@@ -407,6 +407,36 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert hip_lib.pemp_mpm_workspace_bytes(1, 1, 2601, 512, 3) > 6 * 2601 * 4
 
 
+def test_inline_asm_statements_cover_their_own_hazards():
+    """hipcc's hazard recogniser inserts the gfx950 wait states for the instructions it schedules; it does not read the text of
+    an inline-asm statement.  A statement that begins with a VALU instruction consuming a compiler-materialised VGPR, or ends
+    with a VALU instruction that writes an SGPR, is therefore one scheduling decision away from a silent wrong result (round 4's
+    "tile 31" failure: `v_cndmask v3` directly in front of an asm `v_readfirstlane_b32 s8, v3` -- 1 wait state required, none
+    inserted; scratch/t31/README.md).  Rule enforced here on every asm statement of csrc/: if its text holds a v_readlane /
+    v_readfirstlane / v_writelane / v_permlane, its first instruction is an s_nop and its last instruction is an s_nop of at
+    least 5 wait states (VALU writes SGPR -> VMEM reads it)."""
+    csrc = os.path.join(ROOT, "pemp_amd", "csrc")
+    found = 0
+    for name in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r"asm\s+volatile\s*\(", text):
+            depth, i = 1, m.end()
+            while depth and i < len(text):
+                depth += {"(": 1, ")": -1}.get(text[i], 0)
+                i += 1
+            stmt = text[m.end():i - 1]
+            template = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', stmt.split(":")[0]))
+            insns = [t.strip() for t in re.split(r"\\n|\\t|;", template) if t.strip()]
+            if not any(re.match(r"v_(readlane|readfirstlane|writelane|permlane)", t) for t in insns):
+                continue
+            found += 1
+            where = f"{name}:{text.count(chr(10), 0, m.start()) + 1}"
+            assert insns[0].startswith("s_nop"), f"{where}: lane-access asm must start with s_nop (VALU -> v_readlane hazard): {insns}"
+            last = insns[-1].split()
+            assert last[0] == "s_nop" and int(last[1]) >= 4, f"{where}: lane-access asm must end with s_nop >= 4: {insns}"
+    assert found >= 2          # conv_dma2.hip and conv_wgrad.hip pin their loop invariants this way
+
+
 def test_state_dict_layout_baseline_and_stage2():
     from pemp_amd.networks import baseline as b, pemp_stage2 as s2
     spec = lambda net: [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
