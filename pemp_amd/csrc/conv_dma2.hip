@@ -24,6 +24,10 @@
 // piece give wrong data -- so a piece cannot be assembled from two).
 #include "conv_common.h"
 
+#ifndef PEMP_SK_ACQUIRE
+#define PEMP_SK_ACQUIRE 1     // 0: round 4's hand-off without the consumer acquire (A/B builds only)
+#endif
+
 namespace pemp {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -342,19 +346,34 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
                         const v4f v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
                         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(part + ((mi * TN + ni) * 4 + q) * 64), "v"(v) : "memory");
                     }
-            // The hand-off, in the form MI355X_MICROARCH.md lists as valid for a last-arriver combine (round 4; rounds 2-3 used plain
-            // stores and non-temporal loads on uncached memory, which held in every test until one launch of one run returned a
-            // different tile -- `nt` is not a coherent access): EVERY store of the handed-off bytes is a device-scope write-through
-            // store (`sc0 sc1`, 16 B), every storing wave drains them (`s_waitcnt vmcnt(0)`), the workgroup's barrier, then ONE
-            // lane's returning agent-scope atomic add; the workgroup whose add came last -- told by the returned value -- reads
-            // after a workgroup barrier that lane joins, EVERY load of those bytes a `global_load_dwordx4 sc0 sc1` to registers.
-            // The workspace stays uncached device memory (pemp_uncached_alloc) on top of that.  An agent-scope release / acquire
-            // fence pair would be the C++-model form; it writes back and invalidates an XCD's whole L2 under the other tiles
-            // (measured: 118 -> 94 TFLOP/s on the 128 x 128 variant).
+            // The hand-off.  Producer side: EVERY store of the handed-off bytes is a device-scope write-through store (`sc0 sc1`,
+            // 16 B), every storing wave drains them (`s_waitcnt vmcnt(0)`), the workgroup's barrier, then ONE lane's returning
+            // agent-scope atomic add on the tile's counter.  Consumer side (the workgroup whose add came last, told by the returned
+            // value): that lane runs an AGENT-SCOPE ACQUIRE (`buffer_inv sc1`: this CU's vector L1) and waits for it before it
+            // publishes the verdict through LDS, the other waves join it at the workgroup barrier, and every load of the bytes is
+            // a `global_load_dwordx4 sc0 sc1` to registers.  That is MI355X_MICROARCH.md's "Consumer, always" form (one returned
+            // atomic -> one agent acquire -> vmcnt(0) -> workgroup barrier -> loads) with the sc1-store producer form; the loads stay
+            // sc1 on top of it.  Round 4 shipped this WITHOUT the acquire, claiming the guide's table of hand-offs measured with
+            // sc1 loads in its place -- but that table's row is for hipMalloc memory at one workgroup per CU, and this workspace is
+            // hipExtMallocWithFlags(uncached) with two workgroups per CU for the 128-row tiles: outside the row in two cells, so
+            // the acquire stays (the guide's condition (4)).  It costs one L1 invalidate per SPLIT TILE in ONE workgroup --
+            // measured (A/B of PEMP_SK_ACQUIRE, profiles/r05_splitk_acquire_ab.txt): +0.4 ... 1.1 us on the 35-70 us launches of a one-episode step, nothing at the training shapes --
+            // not the release/acquire fence PAIR in every workgroup that round 2 measured at 118 -> 94 TFLOP/s.  (Rounds 2-3 used
+            // plain stores and non-temporal loads on uncached memory, which held in every test until one launch of one run returned
+            // a different tile: `nt` is not a coherent access.)  The workspace stays uncached device memory on top of that.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's partial stores have been acknowledged
             __syncthreads();                                               // ... everybody's
             int* flag = (int*)smem;
-            if (tid == 0) *flag = __hip_atomic_fetch_add(a.sk_cnt + sk_r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // only now this block counts as arrived
+            if (tid == 0) {
+                const int v = __hip_atomic_fetch_add(a.sk_cnt + sk_r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // only now this block counts as arrived
+#if PEMP_SK_ACQUIRE
+                if (v == a.sk_S - 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the invalidate has completed before anybody is released
+                }
+#endif
+                *flag = v;
+            }
             __syncthreads();
             const int arrived = *flag;
             __syncthreads();
