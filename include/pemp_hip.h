@@ -46,7 +46,10 @@ typedef struct pemp_conv_desc {
     uint32_t flags;
     int32_t tile;           /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64 block tile (register staging);
                                11..13 the same with LDS-DMA staging; 14/15 = 128x128 / 128x64, 8 waves;
-                               16/17 = 256x128 / 256x256, 8 waves (all bit-identical results)      */
+                               16/17 = 256x128 / 256x256, 8 waves; 21..27 = the shapes of 11..17 on the
+                               buffer-addressed kernels; 28 = 32x64 blocks of 16-row wave tiles on
+                               v_mfma_f32_16x16x4_f32 (few-row launches: finer granularity)
+                               -- all bit-identical results; 31..37: split-K forms of 21..27 (see below) */
 } pemp_conv_desc;
 
 const char* pemp_last_error(void);
@@ -75,7 +78,7 @@ int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x, const flo
 
 /* Up to 4 INDEPENDENT convolutions in ONE launch (arrays of n descriptors / operand pointers; scale, shift, residual,
  * pad_value: NULL or arrays with NULL entries; pad_value for every member or for none; every descriptor names the same
- * tile variant 21..27).  Each member is computed exactly as by pemp_conv2d_padv_nhwc_f32 on its own -- same tiles, same K
+ * tile variant 21..28).  Each member is computed exactly as by pemp_conv2d_padv_nhwc_f32 on its own -- same tiles, same K
  * order, bit-identical -- but the members' tiles share one grid: a one-episode evaluation step (5202 feature rows: 41-82
  * tiles per conv on 256 CUs) runs the dilated ASPPV2 branches (networks/backbones.py:330-357, all reading the same
  * activations) and a stage's downsample conv beside its conv1 (backbones.py:47,110) this way.  Members must not write

@@ -240,6 +240,50 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& a, f32x16 (&ac
     conv_epilogue_lds_pre<TM, TN, 1, 0, DB>(a, acc, S, m_base, n_base, lane, none);
 }
 
+// Epilogue of the 16-row wave tiles (conv_dma2.hip, R16): TN accumulators of 16 x 16 (rows 4 (lane >> 4) + e, column lane & 15) go
+// through a 16 x (16 TN) LDS patch (row stride + 4 floats: the four lane groups write different banks) so that a lane owns 4
+// consecutive channels of one pixel; the arithmetic is conv_epilogue_lds_pre's, statement for statement (identical rounding).
+template <int TN>
+__device__ __forceinline__ void conv_epilogue_r16(const ConvArgs& a, v4f (&acc)[TN], float* S, int m_base, int n_base, int lane) {
+    constexpr int WN = TN * 16, LD = WN + 4, QPR = WN / 4;
+    static_assert(16 * LD * 4 <= 4096 && (16 * QPR) % 64 == 0, "R16 epilogue patch");
+    const bool relu = a.flags & PEMP_CONV_RELU;
+    const bool per_img = a.flags & PEMP_CONV_SHIFT_PER_IMAGE;
+    const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[(4 * g + e) * LD + ni * 16 + r16] = acc[ni][e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's writes have landed (DS is in-order per wave)
+    const int c4 = (lane % QPR) * 4, n = n_base + c4;
+    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.scale) sc = *(const v4f*)(a.scale + n);
+    if (a.shift && !per_img) sh = *(const v4f*)(a.shift + n);
+#pragma unroll
+    for (int i = 0; i < 16 * QPR / 64; ++i) {
+        const int row = (lane + 64 * i) / QPR;
+        const int m = m_base + row;
+        const v4f v = *(const v4f*)(S + row * LD + c4);
+        if (m < a.M) {
+            v4f add = sh;
+            if (per_img) add += *(const v4f*)(a.shift + (size_t)(m / a.HoWo) * a.Cout + n);
+            if (a.res) add += load_quad(a.res, (size_t)m * a.ldr + n, a.flags & PEMP_CONV_BF16_IO);
+            v4f o;
+            o.x = __builtin_fmaf(v.x, sc.x, add.x);
+            o.y = __builtin_fmaf(v.y, sc.y, add.y);
+            o.z = __builtin_fmaf(v.z, sc.z, add.z);
+            o.w = __builtin_fmaf(v.w, sc.w, add.w);
+            if (relu) {
+                o.x = fmaxf(o.x, 0.f);
+                o.y = fmaxf(o.y, 0.f);
+                o.z = fmaxf(o.z, 0.f);
+                o.w = fmaxf(o.w, 0.f);
+            }
+            store_quad(a.y, (size_t)m * a.ldy + n, o, a.flags & PEMP_CONV_BF16_IO);
+        }
+    }
+}
+
 // conv_dma.hip
 int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st);
 // conv_dma2.hip

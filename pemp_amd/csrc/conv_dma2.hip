@@ -40,15 +40,23 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // v_mfma_f32_32x32x16_bf16 (lanes 0-31: K 0..7, lanes 32-63: K 8..15 = quads 2j and 2j + 1, exactly the pair a fragment read
 // of step j fetches), so one MFMA does the work of the four v_mfma_f32_32x32x2_f32 of the fp32 kernel at 8 cycles instead of
 // 4 x 64.  Accumulation stays fp32; the epilogue writes bf16 (or fp32 for the last layer) -- PEMP_CONV_BF16_IO.
-template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false, bool DB = false>
+// R16 (tile id 28: 32 x 64 block, four waves of 16 x 32): the same K loop on v_mfma_f32_16x16x4_f32.  Measured on gfx950
+// (scratch/mfma_eq): the fp32 MFMAs of every shape accumulate as ONE sequential fma chain in their k order -- 32x32x2, 16x16x4
+// and fmaf() agree bit for bit -- so a 16-row wave tile that feeds the chain in the order of the 32-row kernels (per quarter j
+// of a K step: k = 8j + {0, 4, 1, 5, 2, 6, 3, 7}) is BIT-IDENTICAL to them and may serve the exact evaluation path.  What it
+// buys: granularity.  A one-episode step has 5202 output rows; a 256-channel conv is 1304 wave tiles of 32 x 32 on 1024 SIMDs --
+// two rounds, the second 27 % full, 64 % of the chip's MFMA time at best -- and 2608 of 16 x 32 -- three rounds of half the
+// length, 85 %.  It pays twice the LDS reads per flop for that, so it only wins where a launch is a few rounds long.
+template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false, bool DB = false, bool R16 = false>
 __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid, const int nblk) {
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the launch stub (buffer-resource builtins / "s" asm operands are device-only)
     constexpr int WGN = NW / WGM;
     constexpr int RPI = NW * 8;                 // rows covered by one DMA instruction round of the block
     constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(!R16 || (WM == 16 && WN % 16 == 0 && EPI == 0 && !SK && !BF16 && !DB), "R16: 16-row wave tiles, plain epilogue only");
+    constexpr int TM = R16 ? 1 : WM / 32, TN = R16 ? WN / 16 : WN / 32;      // R16: TN counts 16-column MFMA tiles
     constexpr int AL = BM / RPI, BL = BN / RPI; // DMA wave-instructions per thread per K step
-    constexpr int NMF = TM * TN * (BF16 ? 1 : 4), NDS = TM + TN, NDMA = AL + BL;   // per quarter step: MFMAs, fragment reads; DMAs per step
+    constexpr int NMF = R16 ? 2 * TN : TM * TN * (BF16 ? 1 : 4), NDS = R16 ? 1 + TN : TM + TN, NDMA = AL + BL;   // per quarter step: MFMAs, fragment reads; DMAs per step
     constexpr int PER = (NDS + NDMA + NMF - 1) / NMF;
 
     extern __shared__ __attribute__((aligned(16))) v4f smem[];
@@ -202,13 +210,16 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
             : "scc");                                                                                             \
     } while (0)
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[R16 ? 1 : TM][R16 ? 1 : TN];
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
+    for (int mi = 0; mi < (R16 ? 1 : TM); ++mi)
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
+        for (int ni = 0; ni < (R16 ? 1 : TN); ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    v4f acc16[R16 ? TN : 1];             // R16: one 16 x 16 accumulator per column tile (rows 4 (lane >> 4) + e, column lane & 15)
+#pragma unroll
+    for (int ni = 0; ni < (R16 ? TN : 1); ++ni) acc16[ni] = v4f{0.f, 0.f, 0.f, 0.f};
 
     PEMP_DMA2(0);
     if (nkl > 1) {
@@ -224,19 +235,42 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     // fragment read positions: quad Q of row (.. + lr) sits at position Q ^ ((lr>>1)&7)
     const int rsw = (lr >> 1) & 7;
     const int arow = (wm0 + lr) * 8, brow = (wn0 + lr) * 8;
-    v4f af[2][TM], bf[2][TN];
+    v4f af[2][R16 ? 1 : TM], bf[2][R16 ? 1 : TN];
+    // R16: lane (r16, g) feeds k slot g of v_mfma_f32_16x16x4_f32.  The two MFMAs of quarter j must see k = 8j + {0, 4, 1, 5} and
+    // 8j + {2, 6, 3, 7} in their slots 0..3 (the chain order of the 32-row kernels): slot g reads quad 2j + (g & 1) of its row and
+    // uses element (g >> 1) for the first MFMA, element 2 + (g >> 1) for the second -- one ds_read2_b32 (dwords +0, +2) per row.
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int rsw16 = (r16 >> 1) & 7;                 // wm0 / wn0 / 16 ni are multiples of 16: the row's swizzle is that of r16
+    const int arow16 = (wm0 + r16) * 32 + (g16 >> 1), brow16 = (wn0 + r16) * 32 + (g16 >> 1);     // in floats
+    float a16[2][2], b16[2][R16 ? TN : 1][2];
 
 #define PEMP_READ(dst_, buf_, j_)                                                                                 \
     do {                                                                                                          \
         const v4f* Ab_ = As + (buf_) * BM * 8;                                                                    \
         const v4f* Bb_ = Bs + (buf_) * BN * 8;                                                                    \
-        const int pos_ = (2 * (j_) + lh) ^ rsw;                                                                   \
-        _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) af[dst_][mi] = Ab_[arow + mi * 256 + pos_];             \
-        _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) bf[dst_][ni] = Bb_[brow + ni * 256 + pos_];             \
+        if constexpr (R16) {                                                                                      \
+            const int pos_ = ((2 * (j_) + (g16 & 1)) ^ rsw16) * 4;                                                \
+            const float* pa_ = (const float*)Ab_ + arow16 + pos_;                                                 \
+            a16[dst_][0] = pa_[0];                                                                                \
+            a16[dst_][1] = pa_[2];                                                                                \
+            _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) {                                                   \
+                const float* pb_ = (const float*)Bb_ + brow16 + ni * 512 + pos_;                                  \
+                b16[dst_][ni][0] = pb_[0];                                                                        \
+                b16[dst_][ni][1] = pb_[2];                                                                        \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            const int pos_ = (2 * (j_) + lh) ^ rsw;                                                               \
+            _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) af[dst_][mi] = Ab_[arow + mi * 256 + pos_];         \
+            _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) bf[dst_][ni] = Bb_[brow + ni * 256 + pos_];         \
+        }                                                                                                         \
     } while (0)
 
 #define PEMP_MMA(src_)                                                                                            \
     do {                                                                                                          \
+        if constexpr (R16) {      /* column tiles interleaved: no MFMA waits for the one in front of it */         \
+            _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)    \
+                acc16[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16[src_][h_], b16[src_][ni][h_], acc16[ni], 0, 0, 0); \
+        } else                                                                                                    \
         _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) {     \
             const v4f av = af[src_][mi], bv = bf[src_][ni];                                                       \
             if constexpr (BF16) {                                                                                 \
@@ -292,8 +326,8 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 
-    PEMP_READ(0, 0, 0);
     int kt = 0;
+    PEMP_READ(0, 0, 0);
     for (; kt + 2 < nkl; ++kt) {
         const int buf = kt & 1;
         PEMP_STEP(buf, true, true);
@@ -305,7 +339,7 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     }
     // Residual (shortcut) quads of small tiles are requested HERE, in front of the last K step's MFMAs, instead of inside
     // the epilogue where every tile would wait out a full memory latency between its LDS transpose and its stores.
-    constexpr bool PRE = TM * TN <= 2;
+    constexpr bool PRE = !R16 && TM * TN <= 2;
     v4f rpre[PRE ? TM * TN * 4 : 1];
 #pragma unroll
     for (int i = 0; i < (PRE ? TM * TN * 4 : 1); ++i) rpre[i] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -436,7 +470,9 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     // ---- epilogue: transpose through LDS.  No LDS read and no DMA is outstanding after the loop's last barrier. ----
     float* Rall = (float*)smem + NW * 1024;          // EPI: [NW][TN][2][8][32] sums of the waves, behind their transpose patches
     static_assert(EPI == 0 || NW * 1024 + NW * TN * 512 <= 64 * (BM + BN), "LDS: statistics area");
-    if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI, DB>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre, Rall + wave * TN * 512);
+    static_assert(NW * 1024 <= 64 * (BM + BN), "LDS: one 4 KB transpose patch per wave");
+    if constexpr (R16) conv_epilogue_r16<TN>(a, acc16, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
+    else if constexpr (PRE) conv_epilogue_lds_pre<TM, TN, TM * TN * 4, EPI, DB>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, rpre, Rall + wave * TN * 512);
     else if constexpr (EPI != 0) {
         const v4f none[1] = {{0.f, 0.f, 0.f, 0.f}};
         conv_epilogue_lds_pre<TM, TN, 1, EPI>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane, none, Rall + wave * TN * 512);
@@ -448,9 +484,9 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
 #endif
 }
 
-template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false, bool DB = false>
+template <int BM, int BN, int WGM, int NW, bool PADV, int EPI = 0, bool SK = false, bool BF16 = false, bool DB = false, bool R16 = false>
 __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
-    conv_dma2_body<BM, BN, WGM, NW, PADV, EPI, SK, BF16, DB>(a, blockIdx.x, gridDim.x);
+    conv_dma2_body<BM, BN, WGM, NW, PADV, EPI, SK, BF16, DB, R16>(a, blockIdx.x, gridDim.x);
 }
 
 // Several INDEPENDENT convs of the same tile shape in ONE launch: member i owns the blocks [first[i], first[i] + nblk[i]) (the
@@ -459,20 +495,20 @@ __global__ __launch_bounds__(NW * 64) void conv_dma2_kernel(ConvArgs a) {
 // CUs -- and convs that do not depend on each other (the dilated ASPP branches; a stage's downsample conv beside its conv1):
 // together they fill the chip without splitting K and without one launch + drain per member.  Same tiles, same K order: every
 // member's result is bit-identical to its own launch.
-template <int BM, int BN, int WGM, int NW, bool PADV>
+template <int BM, int BN, int WGM, int NW, bool PADV, bool R16 = false>
 __global__ __launch_bounds__(NW * 64) void conv_dma2_group_kernel(ConvGroupArgs g) {
     int which = 0;
 #pragma unroll
     for (int i = 1; i < CONV_GROUP_MAX; ++i) which += (i < g.n && (int)blockIdx.x >= g.first[i]) ? 1 : 0;
     const int bid = (int)blockIdx.x - g.first[which];
     if (bid >= g.nblk[which]) return;
-    conv_dma2_body<BM, BN, WGM, NW, PADV, 0, false>(g.a[which], bid, g.nblk[which]);
+    conv_dma2_body<BM, BN, WGM, NW, PADV, 0, false, false, false, R16>(g.a[which], bid, g.nblk[which]);
 }
 
-template <int BM, int BN, int WGM, int NW>
+template <int BM, int BN, int WGM, int NW, bool R16 = false>
 static int launch_dma2_group(ConvGroupArgs& g, bool padv, hipStream_t st) {
     const size_t lds = (size_t)2 * 8 * (BM + BN) * sizeof(v4f);
-    auto kern = padv ? conv_dma2_group_kernel<BM, BN, WGM, NW, true> : conv_dma2_group_kernel<BM, BN, WGM, NW, false>;
+    auto kern = padv ? conv_dma2_group_kernel<BM, BN, WGM, NW, true, R16> : conv_dma2_group_kernel<BM, BN, WGM, NW, false, R16>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -493,6 +529,7 @@ static int launch_dma2_group(ConvGroupArgs& g, bool padv, hipStream_t st) {
 
 int launch_conv_dma2_group(int tile, ConvGroupArgs& g, hipStream_t st) {
     const bool padv = g.a[0].padv != nullptr;
+    if (tile == 8) return launch_dma2_group<32, 64, 2, 4, true>(g, padv, st);
     if (tile == 7) return launch_dma2_group<256, 256, 4, 8>(g, padv, st);
     if (tile == 6) return launch_dma2_group<256, 128, 4, 8>(g, padv, st);
     if (tile == 4) return launch_dma2_group<128, 128, 4, 8>(g, padv, st);
@@ -594,13 +631,13 @@ int launch_conv_dma2_db(int tile, ConvArgs a, void* ws, size_t ws_bytes, bool sp
     return launch_db_tile<false>(tile, a, cdiv(a.M, bm) * (a.Cout / bn), st);
 }
 
-int conv_dma2_tile_rows(int tile) {        // BM of tile variant 1..7
-    static const int bm[8] = {0, 128, 128, 64, 128, 128, 256, 256};
-    return tile >= 1 && tile <= 7 ? bm[tile] : 0;
+int conv_dma2_tile_rows(int tile) {        // BM of tile variant 1..8
+    static const int bm[9] = {0, 128, 128, 64, 128, 128, 256, 256, 32};
+    return tile >= 1 && tile <= 8 ? bm[tile] : 0;
 }
 
 static void tile_shape(int tile, int& bm, int& bn) {
-    static const int shapes[8][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 128}, {128, 64}, {256, 128}, {256, 256}};
+    static const int shapes[9][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {128, 128}, {128, 64}, {256, 128}, {256, 256}, {32, 64}};
     bm = shapes[tile][0];
     bn = shapes[tile][1];
 }
@@ -681,7 +718,22 @@ bool conv_dma2_supported(const ConvArgs& a) {
     return xbytes < (1ll << 31) && wbytes < (1ll << 31);
 }
 
+// tile 8: the 16-row variant (32 x 64 block, 16 x 32 wave tiles on v_mfma_f32_16x16x4_f32); plain epilogue only
+static int launch_dma2_r16(const ConvArgs& a, hipStream_t st) {
+    if (a.stats) {
+        set_error("conv_dma2: the 16-row tile has no statistics epilogue");
+        return -1;
+    }
+    auto kern = a.padv ? conv_dma2_kernel<32, 64, 2, 4, true, 0, false, false, false, true>
+                       : conv_dma2_kernel<32, 64, 2, 4, false, 0, false, false, false, true>;
+    const size_t lds = (size_t)2 * 8 * (32 + 64) * sizeof(v4f);
+    const int grid = cdiv(a.M, 32) * (a.Cout / 64);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    return launch_status("conv_dma2/r16");
+}
+
 int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st) {
+    if (tile == 8) return launch_dma2_r16(a, st);
     if (tile == 7) return launch_dma2<256, 256, 4, 8>(a, st);
     if (tile == 6) return launch_dma2<256, 128, 4, 8>(a, st);
     if (tile == 4) return launch_dma2<128, 128, 4, 8>(a, st);

@@ -352,14 +352,15 @@ static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, 
         }
         tile -= 20;
     }
-    if (tile >= 21 && tile <= 27) {      // conv_dma2.hip: buffer-addressed LDS-DMA + barrier inside the MFMA stream (same tile shapes as 11..17)
+    if (tile >= 21 && tile <= 28) {      // conv_dma2.hip: buffer-addressed LDS-DMA + barrier inside the MFMA stream (same tile shapes as 11..17;
+                                         // 28: the 16-row variant, 32 x 64 blocks on v_mfma_f32_16x16x4_f32)
         if (conv_dma2_supported(a)) {
             const int t = tile - 20;
             PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || a.Cout % 128 == 0, "conv2d: tile N=128 needs Cout %% 128 == 0");
             PEMP_REQUIRE(t != 7 || a.Cout % 256 == 0, "conv2d: tile 256x256 needs Cout %% 256 == 0");
             return launch_conv_dma2(t, a, st);
         }
-        tile -= 10;                      // stem / padding value / > 32 taps / >= 2 GiB operands: the pointer-addressed variant
+        tile = tile == 28 ? 13 : tile - 10;      // stem / padding value / > 32 taps / >= 2 GiB operands: the pointer-addressed variant
     }
     if (tile >= 11 && tile <= 17) {      // LDS-DMA staging variants (conv_dma.hip); 14..17: 8-wave blocks, 16: 256x128, 17: 256x256
         PEMP_REQUIRE((tile != 11 && tile != 14 && tile != 16) || a.Cout % 128 == 0, "conv2d: tile N=128 needs Cout %% 128 == 0");
@@ -384,7 +385,7 @@ extern "C" int pemp_conv2d_group_nhwc_f32(int n, const pemp_conv_desc* d, const 
     ConvGroupArgs g;
     g.n = n;
     const int tile = d[0].tile;
-    PEMP_REQUIRE(tile >= 21 && tile <= 27, "conv2d_group: tile must be one of the buffer-addressed variants 21..27, got %d", tile);
+    PEMP_REQUIRE(tile >= 21 && tile <= 28, "conv2d_group: tile must be one of the buffer-addressed variants 21..28, got %d", tile);
     const int t = tile - 20;
     for (int i = 0; i < n; ++i) {
         PEMP_REQUIRE(d[i].tile == tile, "conv2d_group: every member must name the same tile variant");

@@ -66,7 +66,10 @@ class ConvParams:
 TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15: (128, 64), 3: (64, 64),
                  17: (256, 256), 16: (256, 128),    # 16/17: 8-wave blocks, 98/131 KB LDS, half the L2->LDS bytes per flop
                  # 2x: the same shapes on conv_dma2.hip (buffer-addressed LDS-DMA, barrier inside the MFMA stream)
-                 23: (64, 64), 24: (128, 128), 22: (128, 64), 21: (128, 128), 25: (128, 64), 27: (256, 256), 26: (256, 128)}
+                 23: (64, 64), 24: (128, 128), 22: (128, 64), 21: (128, 128), 25: (128, 64), 27: (256, 256), 26: (256, 128),
+                 # 28: 32 x 64 blocks of four 16 x 32 wave tiles on v_mfma_f32_16x16x4_f32 -- same K order, bit-identical (the fp32
+                 # MFMAs are sequential fma chains: scratch/mfma_eq); finer granularity for launches of a few rounds (one episode)
+                 28: (32, 64)}
 AUTOTUNE = True
 SPLITK = os.environ.get("PEMP_CONV_SPLITK", "1") != "0"     # the training convs may pick the split-K variants (A/B switch)
 DEFAULT_TILE = 13
@@ -429,7 +432,7 @@ def conv2d_group(xs, ps, outs, pad_values=None, residuals=None, tile=0):
         if tile is None:
             if AUTOTUNE and max(d[0] * d[5] * d[6] for d in descs) >= 1024 and not torch.cuda.is_current_stream_capturing():
                 tile = _pick_tile(launch, None, key, min(p.cout for p in ps),
-                                  only=[t for t in GROUP_TILES if all(p.cout % TILE_VARIANTS[t][1] == 0 for p in ps)])
+                                  only=[t for t in GROUP_TILES + (28,) if all(p.cout % TILE_VARIANTS[t][1] == 0 for p in ps)])
             else:
                 tile = DEFAULT_TILE + 10
     launch(tile)

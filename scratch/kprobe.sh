@@ -7,7 +7,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_IDX_ACTIVE" \
            "MfmaUtil" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pass$i -- python3 scratch/kprobe.py > $O/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $O/pass$i.log; }
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pass$i -- python3 ${KPROBE:-scratch/kprobe.py} > $O/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $O/pass$i.log; }
 done
 python3 scratch/kprobe_summary.py $O > $O/summary.txt 2>&1; cat $O/summary.txt
 find $O -name "*.csv" -delete; find $O -type d -empty -delete
