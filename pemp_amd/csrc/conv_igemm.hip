@@ -396,8 +396,30 @@ extern "C" int pemp_conv2d_group_nhwc_f32(int n, const pemp_conv_desc* d, const 
         PEMP_REQUIRE(conv_dma2_supported(g.a[i]), "conv2d_group: member %d lies outside the buffer-addressed kernels (stem / > 32 taps / 2 GiB operands / padding vector not behind the activations)", i);
         PEMP_REQUIRE((t != 1 && t != 4 && t != 6) || g.a[i].Cout % 128 == 0, "conv2d_group: tile N=128 needs Cout %% 128 == 0");
         PEMP_REQUIRE(t != 7 || g.a[i].Cout % 256 == 0, "conv2d_group: tile 256x256 needs Cout %% 256 == 0");
-        for (int j = 0; j < i; ++j) {          // members run beside each other: no one may write what another one reads or writes
-            PEMP_REQUIRE(y[i] != y[j], "conv2d_group: members %d and %d write the same output", j, i);
+    }
+    // members run beside each other in one grid: no member may write what another one writes or reads.  Two tensors that interleave
+    // in one buffer (the ASPP branches write channel slices of the concat buffer: equal per-pixel stride, disjoint channel windows)
+    // are fine; any other overlap of the byte ranges is refused.
+    auto clash = [](const float* pa, long long rows_a, int ld_a, int c_a, const float* pb, long long rows_b, int ld_b, int c_b) {
+        if (!pa || !pb) return false;
+        const char *a0 = (const char*)pa, *a1 = a0 + ((rows_a - 1) * ld_a + c_a) * 4;
+        const char *b0 = (const char*)pb, *b1 = b0 + ((rows_b - 1) * ld_b + c_b) * 4;
+        if (a1 <= b0 || b1 <= a0) return false;                       // disjoint ranges
+        if (ld_a != ld_b) return true;
+        const long long delta = (b0 - a0) / 4, r = ((delta % ld_a) + ld_a) % ld_a;      // b's window inside a's pixel
+        return !(r >= c_a && r + c_b <= ld_a);
+    };
+    for (int i = 0; i < n; ++i) {
+        const long long Mi = (long long)g.a[i].N * g.a[i].Ho * g.a[i].Wo;
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            const long long Mj = (long long)g.a[j].N * g.a[j].Ho * g.a[j].Wo, Pj = (long long)g.a[j].N * g.a[j].H * g.a[j].W;
+            PEMP_REQUIRE(j > i || !clash(g.a[i].y, Mi, g.a[i].ldy, g.a[i].Cout, g.a[j].y, Mj, g.a[j].ldy, g.a[j].Cout),
+                         "conv2d_group: members %d and %d write the same output", i, j);
+            PEMP_REQUIRE(!clash(g.a[i].y, Mi, g.a[i].ldy, g.a[i].Cout, g.a[j].x, Pj, g.a[j].ldx, g.a[j].Cin),
+                         "conv2d_group: member %d writes what member %d reads as its input", i, j);
+            PEMP_REQUIRE(!clash(g.a[i].y, Mi, g.a[i].ldy, g.a[i].Cout, g.a[j].res, Mj, g.a[j].ldr, g.a[j].Cout),
+                         "conv2d_group: member %d writes what member %d reads as its residual", i, j);
         }
     }
     for (int i = n; i < CONV_GROUP_MAX; ++i) g.a[i] = g.a[0];

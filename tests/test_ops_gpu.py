@@ -428,3 +428,12 @@ def test_conv2d_group_equals_the_members_own_launches(hip_lib, dev):
         ops.conv2d_group([xin, xin], [qs[1], qs[2]], [torch.empty_like(ref[1]), torch.empty_like(ref[2])], pad_values=[pvs[1], None], tile=23)
     with pytest.raises(_lib.PempHipError, match="21..28"):
         ops.conv2d_group([xb], [mem[0]], [torch.empty_like(refb[0])], tile=13)
+    # members run beside each other in one grid: overlapping channel windows of one buffer (different base pointers), and an output
+    # that is another member's input, are refused; disjoint windows of one buffer are what (a) does
+    wide = torch.empty(N, HW, HW, 2 * C, device=dev)
+    with pytest.raises(_lib.PempHipError, match="same output"):
+        ops.conv2d_group([xin, xin], [qs[0], qs[0]], [wide[..., :C], wide[..., C // 2:C // 2 + C]], tile=23)
+    ops.conv2d_group([xin, xin], [qs[0], qs[0]], [wide[..., :C], wide[..., C:]], tile=23)
+    assert torch.equal(wide[..., :C], ref[0]) and torch.equal(wide[..., C:], ref[0])
+    with pytest.raises(_lib.PempHipError, match="reads as its input"):
+        ops.conv2d_group([xin, wide[..., :C]], [qs[0], qs[0]], [wide[..., :C], torch.empty_like(ref[0])], tile=23)
