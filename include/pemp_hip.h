@@ -48,7 +48,8 @@ typedef struct pemp_conv_desc {
                                11..13 the same with LDS-DMA staging; 14/15 = 128x128 / 128x64, 8 waves;
                                16/17 = 256x128 / 256x256, 8 waves; 21..27 = the shapes of 11..17 on the
                                buffer-addressed kernels; 28 = 32x64 blocks of 16-row wave tiles on
-                               v_mfma_f32_16x16x4_f32 (few-row launches: finer granularity)
+                               v_mfma_f32_16x16x4_f32 (few-row launches: finer granularity); 29 = hybrid of 23
+                               and 28 in one grid for launches of a few rounds (other geometries: 23)
                                -- all bit-identical results; 31..37: split-K forms of 21..27 (see below) */
 } pemp_conv_desc;
 

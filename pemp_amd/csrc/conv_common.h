@@ -65,6 +65,7 @@ struct ConvArgs {
     int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, KH, KW, stride, pad, dil, ldr, Kpad;
     unsigned flags;
     int M, HoWo, cin_steps, nk, ntaps;
+    int bm_first = 0;       // conv_dma2.hip: the launch's first row tile (in units of its BM; 0 except in the hybrid launch's second member)
 };
 
 // up to CONV_GROUP_MAX independent convs of one tile shape in one launch (conv_dma2.hip: conv_dma2_group_kernel)
@@ -290,6 +291,7 @@ int launch_conv_dma(int tile, const ConvArgs& a, hipStream_t st);
 bool conv_dma2_supported(const ConvArgs& a);
 int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st);
 int launch_conv_dma2_group(int tile, ConvGroupArgs& g, hipStream_t st);      // fills g.first / g.nblk
+int launch_conv_dma2_hybrid(const ConvArgs& a, hipStream_t st);             // tile id 29; -2: the geometry has no hybrid split
 int launch_conv_dma2_bf16(int tile, const ConvArgs& a, hipStream_t st);      // bf16 operands (Cin / ldx / Kpad in dwords)
 int launch_conv_dma2_db(int tile, ConvArgs a, void* ws, size_t ws_bytes, bool split, hipStream_t st);   // + DropBlock row scaling
 int conv_dma2_tile_rows(int tile);

@@ -89,7 +89,7 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     } else {
         tile_id = xcd_tile_order(bid, nblk);
     }
-    const int bm = tile_id / ntn;
+    const int bm = a.bm_first + tile_id / ntn;
     const int bn = tile_id % ntn;
     const int m0 = bm * BM, n0 = bn * BN;
 
@@ -525,6 +525,54 @@ static int launch_dma2_group(ConvGroupArgs& g, bool padv, hipStream_t st) {
     g.first[g.n] = grid;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, g);
     return launch_status("conv_dma2/group");
+}
+
+// Hybrid launch (tile id 29) for convs of a FEW rounds: 32 x 32 wave tiles are the efficient shape, but T of them on 1024 SIMDs
+// take ceil(T / 1024) rounds (a one-episode 256-channel conv: 1304 tiles, two rounds, the second 27 % full).  Here the rows that
+// fill whole rounds go to the 64 x 64 tile and the remaining rows to 16-row wave tiles (half the work per K step) in the SAME
+// grid: the SIMDs that would have taken a second 32 x 32 tile take a 16 x 32 one beside their first, 1.5 instead of 2 units per
+// K step.  Both members run the K loop in the same order: bit-identical to every other variant.
+static int g_simds = 0;
+
+template <bool PADV>
+__global__ __launch_bounds__(256) void conv_dma2_hybrid_kernel(ConvGroupArgs g) {
+    const int bid = (int)blockIdx.x;
+    if (bid < g.first[1]) {
+        if (bid < g.nblk[0]) conv_dma2_body<64, 64, 2, 4, PADV, 0, false, false, false, false>(g.a[0], bid, g.nblk[0]);
+    } else {
+        conv_dma2_body<32, 64, 2, 4, PADV, 0, false, false, false, true>(g.a[1], bid - g.first[1], g.nblk[1]);
+    }
+}
+
+int launch_conv_dma2_hybrid(const ConvArgs& a, hipStream_t st) {
+    if (a.stats || (a.flags & PEMP_CONV_BF16_IO)) return -2;
+    if (!g_simds) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        g_simds = 4 * cus;
+    }
+    const int per32 = a.Cout / 32;                               // 32 x 32 wave tiles per 32 output rows
+    const int rounds = (int)(((long long)a.M / 32 * per32) / g_simds);      // whole rounds the 32-row tiles fill
+    if (rounds < 1 || rounds > 8) return -2;                     // (many rounds: the quantisation loss is small anyway)
+    const int rows_a = ((long long)rounds * g_simds / per32) * 32 / 64 * 64;
+    const int rest = a.M - rows_a;
+    if (rows_a <= 0 || rest <= 0 || (long long)cdiv(rest, 16) * per32 > g_simds) return -2;
+    ConvGroupArgs g;
+    g.n = 2;
+    g.a[0] = a;
+    g.a[0].M = rows_a;
+    g.a[1] = a;
+    g.a[1].bm_first = rows_a / 32;
+    for (int i = 2; i < CONV_GROUP_MAX; ++i) g.a[i] = a;
+    g.nblk[0] = (rows_a / 64) * (a.Cout / 64);
+    g.nblk[1] = cdiv(rest, 32) * (a.Cout / 64);
+    g.first[0] = 0;
+    g.first[1] = (g.nblk[0] + 7) & ~7;
+    g.first[2] = g.first[1] + g.nblk[1];
+    const size_t lds = (size_t)2 * 8 * (64 + 64) * sizeof(v4f);
+    auto kern = a.padv ? conv_dma2_hybrid_kernel<true> : conv_dma2_hybrid_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(g.first[2]), dim3(256), lds, st, g);
+    return launch_status("conv_dma2/hybrid");
 }
 
 int launch_conv_dma2_group(int tile, ConvGroupArgs& g, hipStream_t st) {

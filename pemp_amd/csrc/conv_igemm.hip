@@ -325,6 +325,7 @@ static int conv_fill(const pemp_conv_desc* d, const float* x, const float* w, fl
     a.nk = d->Kpad / 32;
     if (residual) PEMP_REQUIRE(d->ldr >= d->Cout && d->ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0, "conv2d: ldr must be >= Cout and x4, residual 16-byte aligned");
     a.sk_ws = nullptr; a.sk_cnt = nullptr; a.sk_full = 0; a.sk_S = 1;
+    a.bm_first = 0;
     return 0;
 }
 
@@ -351,6 +352,13 @@ static int conv2d_impl(const pemp_conv_desc* d, const float* x, const float* w, 
             return launch_conv_dma2_splitk(t, a, ws, ws_bytes, st);
         }
         tile -= 20;
+    }
+    if (tile == 29) {                    // hybrid (conv_dma2.hip): whole rounds of 32 x 32 wave tiles + the remaining rows on 16-row tiles, one grid
+        if (conv_dma2_supported(a)) {
+            const int rc2 = launch_conv_dma2_hybrid(a, st);
+            if (rc2 != -2) return rc2;
+        }
+        tile = 23;                       // no hybrid split for this geometry: the 64 x 64 tile (same results)
     }
     if (tile >= 21 && tile <= 28) {      // conv_dma2.hip: buffer-addressed LDS-DMA + barrier inside the MFMA stream (same tile shapes as 11..17;
                                          // 28: the 16-row variant, 32 x 64 blocks on v_mfma_f32_16x16x4_f32)
@@ -497,6 +505,7 @@ static int conv_stats_fill(const char* what, const pemp_conv_desc* d, ConvArgs& 
     a.cin_steps = d->Cin / 32;
     a.nk = d->Kpad / 32;
     a.sk_ws = nullptr; a.sk_cnt = nullptr; a.sk_full = 0; a.sk_S = 1;
+    a.bm_first = 0;
     if (!conv_dma2_supported(a)) {
         set_error("%s: geometry / operand size outside the buffer-addressed kernels", what);
         return -2;

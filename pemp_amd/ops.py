@@ -69,7 +69,10 @@ TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15
                  23: (64, 64), 24: (128, 128), 22: (128, 64), 21: (128, 128), 25: (128, 64), 27: (256, 256), 26: (256, 128),
                  # 28: 32 x 64 blocks of four 16 x 32 wave tiles on v_mfma_f32_16x16x4_f32 -- same K order, bit-identical (the fp32
                  # MFMAs are sequential fma chains: scratch/mfma_eq); finer granularity for launches of a few rounds (one episode)
-                 28: (32, 64)}
+                 28: (32, 64),
+                 # 29: hybrid launch for convs of a few rounds -- the rows that fill whole rounds of the chip on the 64 x 64 tile, the
+                 # remaining rows on 16-row wave tiles, one grid (csrc/conv_dma2.hip); other geometries run as 23
+                 29: (64, 64)}
 AUTOTUNE = True
 SPLITK = os.environ.get("PEMP_CONV_SPLITK", "1") != "0"     # the training convs may pick the split-K variants (A/B switch)
 DEFAULT_TILE = 13

@@ -22,7 +22,7 @@ for (cin, cout, k, d, res) in ((256, 256, 3, 2, 0), (1024, 256, 1, 1, 0), (256, 
     r = torch.randn(2, 51, 51, cout, device=dev) if res else None
     ref = ops.conv2d(x, prm, residual=r, tile=23)
     row = []
-    for tile in (23, 22, 25, 21, 24, 26, 27, 28):
+    for tile in (23, 22, 25, 21, 24, 26, 27, 28, 29):
         if cout % ops.TILE_VARIANTS[tile][1]: continue
         same = torch.equal(ops.conv2d(x, prm, residual=r, tile=tile), ref)
         row.append(f"{tile}: {t(lambda: ops.conv2d(x, prm, residual=r, tile=tile)):6.1f}{'' if same else '!'}")

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 TILE_N = {3: 64, 2: 64, 1: 128, 13: 64, 12: 64, 11: 128, 15: 64, 14: 128, 16: 128, 17: 256,
-          23: 64, 22: 64, 21: 128, 25: 64, 24: 128, 26: 128, 27: 256, 28: 64}     # 2x: conv_dma2.hip (buffer-addressed LDS-DMA)
+          23: 64, 22: 64, 21: 128, 25: 64, 24: 128, 26: 128, 27: 256, 28: 64, 29: 64}     # 2x: conv_dma2.hip (buffer-addressed LDS-DMA)
 
 
 def _cases(n, seed):

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TILE_N = {21: 128, 22: 64, 23: 64, 24: 128, 25: 64, 26: 128, 27: 256, 28: 64, 31: 128, 32: 64, 34: 128, 35: 64, 36: 128, 37: 256,
+TILE_N = {21: 128, 22: 64, 23: 64, 24: 128, 25: 64, 26: 128, 27: 256, 28: 64, 29: 64, 31: 128, 32: 64, 34: 128, 35: 64, 36: 128, 37: 256,
           # the pointer-addressed LDS-DMA kernels (conv_dma.hip) and the first-generation kernel (conv_igemm.hip): the fall-backs
           11: 128, 12: 64, 13: 64, 14: 128, 15: 64, 16: 128, 17: 256, 1: 128, 2: 64, 3: 64}
 

@@ -107,7 +107,7 @@ def test_conv2d_pad_value_folds_a_leading_batchnorm(hip_lib, dev, Cin, Cout, k, 
     xd = _nhwc(x).to(dev)
     tol = 3e-5 * (Cin * k * k / 64) ** 0.5
     outs = []
-    for tile in (3, 2, 13, 12, 15, 23, 22, 25, 28) + ((11, 14, 16, 21, 24, 26) if Cout % 128 == 0 else ()) + ((17, 27) if Cout % 256 == 0 else ()):
+    for tile in (3, 2, 13, 12, 15, 23, 22, 25, 28, 29) + ((11, 14, 16, 21, 24, 26) if Cout % 128 == 0 else ()) + ((17, 27) if Cout % 256 == 0 else ()):
         y = ops.conv2d(xd, q, tile=tile, pad_value=padv if k > 1 else None)
         outs.append(y)
         assert ((_nchw(y.cpu()) - ref).abs() / (1 + ref.abs())).max().item() < tol, tile
@@ -120,7 +120,7 @@ def test_conv2d_pad_value_folds_a_leading_batchnorm(hip_lib, dev, Cin, Cout, k, 
         flat[:N * HW * HW].copy_(xd.view(-1, Cin))
         flat[N * HW * HW + 2].copy_(padv)
         xin, pin = flat[:N * HW * HW].view(N, HW, HW, Cin), flat[N * HW * HW + 2]
-        for tile in (23, 22, 25, 28) + ((21, 24, 26) if Cout % 128 == 0 else ()) + ((27,) if Cout % 256 == 0 else ()):
+        for tile in (23, 22, 25, 28, 29) + ((21, 24, 26) if Cout % 128 == 0 else ()) + ((27,) if Cout % 256 == 0 else ()):
             assert torch.equal(ops.conv2d(xin, q, tile=tile, pad_value=pin), outs[0]), tile
     if k > 1:       # zero padding is NOT the same thing (the border differs), and 1x1 convs reject a pad value
         y0 = ops.conv2d(xd, q, tile=3)
