@@ -1,11 +1,11 @@
 #!/bin/bash
 # Produces the round's measurement artefacts under gpurun_out/$R/ on the GPU box (copy into profiles/ afterwards, prefixed with $R_):
-#   [R=r04] bash scratch/make_profiles.sh [part]        part = bench | trace | b1 | head | pmc | pmctrain | all (default)
+#   [R=r05] bash scratch/make_profiles.sh [part]        part = bench | trace | b1 | head | pmc | pmctrain | all (default)
 # rocprofv3 is always given the program itself after `--` (python3 bench.py ...), never a wrapper.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 PART=${1:-all}
-R=${R:-r04}
+R=${R:-r05}
 export PEMP_ROUND=$R
 O=gpurun_out/$R; mkdir -p $O
 B="--cpu-episodes 0 --no-e2e --no-single --no-sides"
@@ -21,6 +21,7 @@ timeout -k 10 500 python3 bench.py --model stage2 --shot 5 --batch 8 --steps 10 
 timeout -k 10 500 python3 bench.py --dataset COCO --steps 10 --warmup 3 --cpu-episodes 4 > $O/bench_eval_coco_b25.json 2>> $O/err.log && echo coco ok
 timeout -k 10 500 python3 bench.py --model baseline --batch 12 --steps 10 --warmup 3 > $O/bench_baseline_vgg16_b12.json 2>> $O/err.log && echo baseline ok
 PEMP_EVAL_SPLITK=1 timeout -k 10 500 python3 bench.py --batch 1 --steps 100 --warmup 10 $B > $O/bench_eval_b1.json 2>> $O/err.log && echo b1 ok
+timeout -k 10 500 python3 bench.py --batch 1 --steps 100 --warmup 10 $B > $O/bench_eval_b1_exact.json 2>> $O/err.log && echo b1 exact ok
 fi
 if [ $PART = trace ] || [ $PART = all ]; then
 # 2. kernel traces (rocprofv3 --kernel-trace --stats) of the eval and train commands.  The eval command runs with ONE engine lane
@@ -43,7 +44,13 @@ unset PEMP_BENCH_LANES
 fi
 if [ $PART = b1 ] || [ $PART = all ]; then
 # 2b. the one-episode step (split-K variants allowed, one lane) kernel by kernel
-export PEMP_BENCH_LANES=1 PEMP_EVAL_SPLITK=1
+export PEMP_BENCH_LANES=1
+rm -rf $O/kt_b1x
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_b1x -- python3 bench.py --batch 1 --steps 20 --warmup 5 $B --no-roofline > $O/kt_b1x.log 2>&1 || echo "kt b1 exact failed"
+find $O/kt_b1x -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 scratch/profile_summary.py {} $O/eval_b1_exact_steady.json eval 46
+find $O/kt_b1x -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 scratch/step_sequence.py {} pack_input > $O/eval_b1_exact_sequence.txt
+rm -rf $O/kt_b1x
+export PEMP_EVAL_SPLITK=1
 rm -rf $O/kt_b1
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_b1 -- python3 bench.py --batch 1 --steps 20 --warmup 5 $B --no-roofline > $O/kt_b1.log 2>&1 || echo "kt b1 failed"
 find $O/kt_b1 -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 scratch/profile_summary.py {} $O/eval_b1_steady.json eval 46
