@@ -77,6 +77,13 @@ int pemp_conv2d_padv_nhwc_f32(const pemp_conv_desc* d, const float* x, const flo
                               const float* scale, const float* shift, const float* residual,
                               const float* pad_value, void* stream);
 
+/* Tile id 29 ("hybrid"): for a conv whose 32 x 32 wave tiles fill only a few rounds of the chip (a one-episode evaluation step's
+ * 256-channel convs: 1304 tiles on 1024 SIMDs -- reference networks/backbones.py:42-77 at the reference's own data.test_bs = 1,
+ * data_kits/datasets.py:23), the rows that fill WHOLE rounds run on the 64 x 64 tile and the remaining rows on 16-row wave tiles
+ * in the same grid; bit-identical to every other exact variant.  Returns how many output rows of `d` go to the 64 x 64 part
+ * (0: this geometry has no such split -- pemp_conv2d_nhwc_f32 then runs tile 29 as tile 23).                                */
+int pemp_conv2d_hybrid_rows(const pemp_conv_desc* d);
+
 /* Up to 4 INDEPENDENT convolutions in ONE launch (arrays of n descriptors / operand pointers; scale, shift, residual,
  * pad_value: NULL or arrays with NULL entries; pad_value for every member or for none; every descriptor names the same
  * tile variant 21..28).  Each member is computed exactly as by pemp_conv2d_padv_nhwc_f32 on its own -- same tiles, same K

@@ -39,6 +39,7 @@ CONV_STEM4 = 4
 SYMBOLS = {
     "pemp_last_error": (C.c_char_p, []),
     "pemp_abi_version": (c_int, []),
+    "pemp_conv2d_hybrid_rows": (c_int, [C.POINTER(ConvDesc)]),
     "pemp_conv2d_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "pemp_conv2d_padv_splitk_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size, c_fp]),
     "pemp_conv2d_padv_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),

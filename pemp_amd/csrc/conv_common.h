@@ -292,6 +292,7 @@ bool conv_dma2_supported(const ConvArgs& a);
 int launch_conv_dma2(int tile, const ConvArgs& a, hipStream_t st);
 int launch_conv_dma2_group(int tile, ConvGroupArgs& g, hipStream_t st);      // fills g.first / g.nblk
 int launch_conv_dma2_hybrid(const ConvArgs& a, hipStream_t st);             // tile id 29; -2: the geometry has no hybrid split
+int conv_dma2_hybrid_rows(int M, int Cout);                               // rows on the 64 x 64 tile in that launch (0: no split)
 int launch_conv_dma2_bf16(int tile, const ConvArgs& a, hipStream_t st);      // bf16 operands (Cin / ldx / Kpad in dwords)
 int launch_conv_dma2_db(int tile, ConvArgs a, void* ws, size_t ws_bytes, bool split, hipStream_t st);   // + DropBlock row scaling
 int conv_dma2_tile_rows(int tile);

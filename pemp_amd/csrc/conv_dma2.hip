@@ -544,19 +544,28 @@ __global__ __launch_bounds__(256) void conv_dma2_hybrid_kernel(ConvGroupArgs g) 
     }
 }
 
-int launch_conv_dma2_hybrid(const ConvArgs& a, hipStream_t st) {
-    if (a.stats || (a.flags & PEMP_CONV_BF16_IO)) return -2;
+// rows of an M x Cout conv that go to the 64 x 64 tile in the hybrid launch (the rest: 16-row tiles); 0 = no such split
+int conv_dma2_hybrid_rows(int M, int Cout) {
     if (!g_simds) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         g_simds = 4 * cus;
     }
-    const int per32 = a.Cout / 32;                               // 32 x 32 wave tiles per 32 output rows
-    const int rounds = (int)(((long long)a.M / 32 * per32) / g_simds);      // whole rounds the 32-row tiles fill
-    if (rounds < 1 || rounds > 8) return -2;                     // (many rounds: the quantisation loss is small anyway)
+    if (M <= 0 || Cout < 64 || Cout % 64) return 0;
+    const int per32 = Cout / 32;                                 // 32 x 32 wave tiles per 32 output rows
+    const int rounds = (int)(((long long)M / 32 * per32) / g_simds);        // whole rounds the 32-row tiles fill
+    if (rounds < 1 || rounds > 8) return 0;                      // (many rounds: the quantisation loss is small anyway)
     const int rows_a = ((long long)rounds * g_simds / per32) * 32 / 64 * 64;
+    const int rest = M - rows_a;
+    if (rows_a <= 0 || rest <= 0 || (long long)cdiv(rest, 16) * per32 > g_simds) return 0;
+    return rows_a;
+}
+
+int launch_conv_dma2_hybrid(const ConvArgs& a, hipStream_t st) {
+    if (a.stats || (a.flags & PEMP_CONV_BF16_IO)) return -2;
+    const int rows_a = conv_dma2_hybrid_rows(a.M, a.Cout);
+    if (!rows_a) return -2;
     const int rest = a.M - rows_a;
-    if (rows_a <= 0 || rest <= 0 || (long long)cdiv(rest, 16) * per32 > g_simds) return -2;
     ConvGroupArgs g;
     g.n = 2;
     g.a[0] = a;

@@ -524,6 +524,11 @@ static int conv_stats_common(const char* what, const pemp_conv_desc* d, ConvArgs
     return launch_conv_dma2(d->tile == 0 ? 3 : d->tile - 20, a, st);
 }
 
+extern "C" int pemp_conv2d_hybrid_rows(const pemp_conv_desc* d) {
+    if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return 0;
+    return conv_dma2_hybrid_rows(d->N * d->Ho * d->Wo, d->Cout);
+}
+
 extern "C" int pemp_conv2d_stats_rows(const pemp_conv_desc* d) {
     if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
     const int t = d->tile == 0 ? 3 : (d->tile > 30 ? d->tile - 30 : d->tile - 20);

@@ -189,6 +189,12 @@ def _pick_tile(launch, p, key, cout, only=None):
     return best
 
 
+def hybrid_rows(n, ho, wo, cout):
+    """Rows of an [n, ho, wo, cout] conv output that the hybrid launch (tile id 29) gives to the 64 x 64 tile; 0 = no split."""
+    d = ConvDesc(n, ho, wo, 32, 32, ho, wo, cout, cout, 1, 1, 1, 0, 1, 0, 32, 0, 29)
+    return int(_lib.load().pemp_conv2d_hybrid_rows(C.byref(d)))
+
+
 def pack_conv_weight(w_oihw, stem4=False):
     """[Cout,Cin,KH,KW] -> KRSC [Cout, Kpad] (Cin contiguous).  STEM4: Cin padded to 4, row padded x32."""
     co, ci, kh, kw = w_oihw.shape
@@ -293,6 +299,8 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
             else:
                 only = list(TILE_VARIANTS) + list(SPLITK_TILES) if splitk else None
             if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():
+                if only is None and not hybrid_rows(n, ho, wo, p.cout):
+                    only = [t for t in TILE_VARIANTS if t != 29]          # no hybrid split for this geometry: id 29 would run as 23
                 tile = _pick_tile(launch, p, key, p.cout, only=only)
             else:
                 tile = DEFAULT_TILE + (10 if dropblock is not None else 0)

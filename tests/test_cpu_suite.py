@@ -437,6 +437,18 @@ def test_inline_asm_statements_cover_their_own_hazards():
     assert found >= 2          # conv_dma2.hip and conv_wgrad.hip pin their loop invariants this way
 
 
+def test_hybrid_split_of_a_few_round_conv(hip_lib):
+    """pemp_conv2d_hybrid_rows (tile id 29): the rows that fill whole rounds of 32 x 32 wave tiles on the chip's SIMDs go to the
+    64 x 64 tile, the rest to 16-row tiles -- only where the rest fits one round of those.  (No GPU: 256 CUs assumed.)"""
+    from pemp_amd import ops
+    assert ops.hybrid_rows(2, 51, 51, 256) == 4096          # one episode, 256 channels: 1304 tiles -> 1024 + 560 half-size ones
+    assert ops.hybrid_rows(2, 51, 51, 128) == 0             # 652 tiles: one round anyway
+    assert ops.hybrid_rows(2, 51, 51, 512) == 0             # the remainder would need more than one round of 16-row tiles
+    assert ops.hybrid_rows(2, 51, 51, 1024) == 5120         # five whole rounds + 82 rows
+    assert ops.hybrid_rows(50, 51, 51, 256) == 0            # 25 episodes: 32 rounds, nothing to gain
+    assert ops.hybrid_rows(2, 101, 101, 64) == 16384        # layer 1 at one episode
+
+
 def test_state_dict_layout_baseline_and_stage2():
     from pemp_amd.networks import baseline as b, pemp_stage2 as s2
     spec = lambda net: [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
