@@ -836,7 +836,7 @@ def single_episode(net, dev, args, n=120):
     out["conv_variants"] = "split-K allowed for layers of <= 12000 output rows (Evaluator(splitk=True) / PEMP_EVAL_SPLITK=1; opt-in)"
     # The reference's Evaluator.test_step body as written (entry/pemp_stage1.py:48-53): host tensors in, three .cuda()
     # copies, forward, loss.item() and argmax .cpu().numpy() out -- two host synchronisations per episode.
-    ev = Evaluator(net, device=dev, splitk=True)
+    ev = Evaluator(net, device=dev, splitk=False)
     host = [(tuple(x.cpu() for x in ins), msk.cpu()) for ins, msk in eps]
     for ins, msk in host:
         ev.test_step(ins, msk)
@@ -891,7 +891,7 @@ def protocol_5x1000(net, pool, dev, args, rounds=5, test_n=1000, lanes=4):
     from pemp_amd.entry.pemp_stage1 import Evaluator
     nclass = 20 if args.dataset == "PASCAL" else 80
     data = ResidentEpisodes(pool, test_n)
-    ev = Evaluator(net, device=dev, lanes=lanes, splitk=True)
+    ev = Evaluator(net, device=dev, lanes=lanes, splitk=False)      # the exact (bit-identical) variants: since round 5's hybrid launch also the faster ones
     warm = ResidentEpisodes(pool, 8 * lanes)
     ev.start_eval_loop(warm, nclass, 0, te_epochs=1, batch=1, dataset_name=args.dataset)      # graphs of every lane / label size
     torch.cuda.synchronize()
@@ -906,7 +906,7 @@ def protocol_5x1000(net, pool, dev, args, rounds=5, test_n=1000, lanes=4):
             "biou_per_round": [round(float(np.nanmean(r)), 6) for r in ev.round_biou],
             "miou": round(float(np.nanmean(miou)), 6), "biou": round(float(np.nanmean(biou)), 6), "mean_ce_loss": round(float(loss), 6),
             "distinct_episodes": len(data.eps),
-            "what": "Evaluator.start_eval_loop: 5 rounds x 1000 single-episode test_steps (split-K conv variants allowed), per-round "
+            "what": "Evaluator.start_eval_loop: 5 rounds x 1000 single-episode test_steps (the default, bit-identical conv variants), per-round "
                     "device-side metric table + one fetch; timer_cps = calls / time inside test_step (the reference's Timer), "
                     "episodes_per_s = wall clock of the whole loop; episodes cycle through a resident pool of synthetic E(seed) "
                     "episodes (the mIoU says nothing about PASCAL accuracy)"}
