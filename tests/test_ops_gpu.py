@@ -88,6 +88,38 @@ def test_conv2d_channel_slices_and_per_image_shift(hip_lib, dev):
     assert torch.allclose(got[..., 64:192].permute(0, 3, 1, 2), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,d", [(2, 51, 51, 64, 256, 3, 2), (3, 37, 45, 96, 256, 1, 1), (2, 101, 101, 64, 64, 3, 1),
+                                                 (1, 72, 73, 32, 1024, 1, 1)])
+def test_sixteen_row_and_hybrid_tiles_with_every_epilogue_option(hip_lib, dev, N, H, W, Cin, Cout, k, d):
+    """Tile ids 28 (16-row wave tiles on v_mfma_f32_16x16x4_f32) and 29 (hybrid: whole rounds on the 64 x 64 tile + the remaining rows
+    on 16-row tiles, one grid) against tile 23, bit for bit, with everything their own epilogue / row-tile offset has to get
+    right: input and output as channel slices of wider buffers, a residual with its own stride, per-channel scale, a PER-IMAGE
+    shift, ReLU, and row counts that end inside a 16-row tile (4995 = 156 x 32 + 3; 5256 = 5120 + 8 x 16 + 8).  The geometries are ones the
+    hybrid really splits (asserted)."""
+    from pemp_amd import ops
+    assert ops.hybrid_rows(N, H, W, Cout) > 0
+    xw = _rand(N, H, W, Cin + 32, seed=1).to(dev)
+    x = xw[..., 32:]
+    w = _rand(Cout, Cin, k, k, seed=2) * (1.0 / (Cin * k * k) ** 0.5)
+    packed, kpad = ops.pack_conv_weight(w.to(dev))
+    scale = _rand(Cout, seed=3, lo=0.5, hi=1.5).to(dev)
+    prm = ops.ConvParams(packed, scale, None, Cin, Cout, k, k, 1, d * (k // 2), d, kpad, False, True)
+    shift = _rand(N, Cout, seed=4).to(dev).contiguous()
+    resw = _rand(N, H, W, Cout + 64, seed=5).to(dev)
+    res = resw[..., 64:]
+    outs = {}
+    for tile in (23, 28, 29):
+        yw = torch.full((N, H, W, Cout + 128), -3.0, device=dev)
+        ops.conv2d(x, prm, out=yw[..., 64:64 + Cout], residual=res, shift_override=shift, per_image_shift=True, tile=tile)
+        assert bool((yw[..., :64] == -3).all()) and bool((yw[..., 64 + Cout:] == -3).all()), tile
+        outs[tile] = yw[..., 64:64 + Cout].clone()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).cpu(), w, None, 1, d * (k // 2), d) * scale.cpu()[None, :, None, None] + shift.cpu()[:, :, None, None]
+    ref = F.relu(ref + res.permute(0, 3, 1, 2).cpu())
+    got = outs[23].permute(0, 3, 1, 2).cpu()
+    assert ((got - ref).abs() / (1 + ref.abs())).max().item() < 3e-5 * max(1.0, (Cin * k * k / 64) ** 0.5)
+    assert torch.equal(outs[28], outs[23]) and torch.equal(outs[29], outs[23])
+
+
 @pytest.mark.parametrize("Cin,Cout,k,dil,HW", [(64, 64, 3, 2, 13), (64, 128, 3, 6, 19), (256, 256, 3, 18, 51), (64, 64, 1, 1, 9)])
 def test_conv2d_pad_value_folds_a_leading_batchnorm(hip_lib, dev, Cin, Cout, k, dil, HW):
     """ASPPV2 (networks/backbones.py:330-357): BN -> conv with the BN OUTPUT zero-padded.  The folded conv reads
