@@ -615,8 +615,12 @@ def cpu_leg(args):
     from pemp_amd import synth
     threads = int(args.cpu_leg)
     torch.set_num_threads(threads)
-    kind = "stage2" if args.model == "stage2" else "stage1"
-    _, sd = build_model(None, "stage1", 1)
+    kind = args.model if args.model in ("stage2", "baseline") else "stage1"
+    # BASELINE.json configs[0] ("baseline model, VGG-16, 4 test episodes on CPU", entry/baseline.py:46-62 around
+    # networks/baseline.py:69-118): the timed episodes are exactly seeds 5678..5681, the
+    # warm-up episode in front of them is seed 5677; the other models time 5679.. after warming on 5678
+    first = 5677 if kind == "baseline" else 5678
+    _, sd = build_model(None, "baseline" if kind == "baseline" else "stage1", 1)
     sd2 = build_model(None, "stage2", args.shot)[1] if kind == "stage2" else None
     t = lambda a: torch.from_numpy(a)
     budget = float(os.environ.get("PEMP_CPU_BUDGET_S", "25"))
@@ -644,13 +648,15 @@ def cpu_leg(args):
         rows = []
         with torch.no_grad():
             for i in range(args.cpu_episodes + 1):
-                ep = synth.make_episode(5678 + i, shot=args.shot, index=i, dataset=args.dataset)
+                ep = synth.make_episode(first + i, shot=args.shot, index=i, dataset=args.dataset)
                 sup, msk, qry = t(ep["sup_img"])[None], t(ep["sup_mask"])[None], t(ep["qry_img"])[None]
                 gt = t(ep["qry_mask"])
                 t0 = time.time()
                 if kind == "stage2":
                     prior = ref_cpu.stage1_forward(sd, sup, msk, qry, tuple(sup.shape[-2:])).argmax(dim=1, keepdim=True)
                     fwd = lambda a, b, c, hw: ref_cpu.stage2_forward(sd2, a, b, c, prior, hw)
+                elif kind == "baseline":
+                    fwd = lambda a, b, c, hw: ref_cpu.baseline_forward(sd, a, b, c, hw, backbone="vgg16")
                 else:
                     fwd = lambda a, b, c, hw: ref_cpu.stage1_forward(sd, a, b, c, hw)
                 pred, loss, _ = ref_cpu.test_step(fwd, (sup, msk, qry), gt)
@@ -660,12 +666,13 @@ def cpu_leg(args):
                 # outside the timed region: the episode's tp/fp/fn row (core/metrics.py:9-23) for the mIoU comparison
                 m = ref_cpu.FewShotMetric(80)
                 m.update(pred, gt.numpy(), [int(ep["cls"])])
-                rows.append({"seed": 5678 + i, "index": i, "shot": args.shot, "dataset": args.dataset, "cls": int(ep["cls"]),
+                rows.append({"seed": first + i, "index": i, "shot": args.shot, "dataset": args.dataset, "cls": int(ep["cls"]),
                              "counts": [float(v) for v in np.r_[m.stat[0], m.stat[int(ep["cls"])]]], "loss": loss})
-                if sum(times) > budget:
+                if sum(times) > budget and kind != "baseline":          # configs[0] is exactly its four episodes
                     break
         per = 1
-        what = f"{len(times)} episodes (seeds 5679..), oracle/ref_cpu.py test_step"
+        what = (f"{len(times)} episodes (seeds {first + 1}..{first + len(times)}), oracle/ref_cpu.py test_step"
+                + (" over baseline_forward, VGG-16 (BASELINE.json configs[0])" if kind == "baseline" else ""))
     tot = sum(times)
     res = {"value": round(len(times) * per / tot, 3), "threads": threads, "steps": len(times),
            "median_ms": round(float(np.median(times)) * 1e3, 1), "min_ms": round(min(times) * 1e3, 1), "max_ms": round(max(times) * 1e3, 1),
@@ -727,7 +734,7 @@ def cpu_baseline(args):
             env.setdefault("PEMP_CPU_TRAIN_BATCH", "1")
         else:
             env.setdefault("PEMP_CPU_BUDGET_S", "20")
-        n_ep = args.cpu_episodes if threads > 1 else max(2, min(args.cpu_episodes, 10))
+        n_ep = args.cpu_episodes if threads > 1 or args.model == "baseline" else max(2, min(args.cpu_episodes, 10))
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(threads), "--mode", args.mode, "--model", args.model,
                "--shot", str(args.shot), "--batch", str(args.batch), "--dataset", args.dataset, "--cpu-episodes", str(n_ep)]
         try:
@@ -833,7 +840,9 @@ def single_episode(net, dev, args, n=120):
     ex1, exn = run(1, False), run(lanes_n, False)
     out["exact"] = {"value": ex1[0], "ms_per_episode": ex1[1], f"value_{lanes_n}_in_flight": exn[0],
                     "what": "the default conv variants (all bit-identical): one episode per step == the batched step bit for bit"}
-    out["conv_variants"] = "split-K allowed for layers of <= 12000 output rows (Evaluator(splitk=True) / PEMP_EVAL_SPLITK=1; opt-in)"
+    out["conv_variants"] = ("`value` / `value_N_in_flight`: split-K allowed for layers of <= 12000 output rows (Evaluator(splitk=True) / "
+                            "PEMP_EVAL_SPLITK=1; opt-in); `exact`, `reference_body`, `reference_body_pinned`: the default exact variants")
+    out["exact"]["conv_variants"] = "exact"
     # The reference's Evaluator.test_step body as written (entry/pemp_stage1.py:48-53): host tensors in, three .cuda()
     # copies, forward, loss.item() and argmax .cpu().numpy() out -- two host synchronisations per episode.
     ev = Evaluator(net, device=dev, splitk=False)
@@ -847,9 +856,21 @@ def single_episode(net, dev, args, n=120):
         pred, loss = ev.test_step(*host[i % len(host)])
     dt = time.perf_counter() - t0
     assert pred.ndim == 3 and np.isfinite(loss)
-    out["reference_body"] = {"value": round(m / dt, 2), "ms_per_episode": round(dt / m * 1e3, 4),
+    out["reference_body"] = {"value": round(m / dt, 2), "ms_per_episode": round(dt / m * 1e3, 4), "conv_variants": "exact",
                              "what": "Evaluator.test_step as the reference writes it: host tensors -> 3 H2D copies -> forward -> "
-                                     "loss float + argmax numpy on the host, every episode (pageable host memory, no overlap)"}
+                                     "loss float + argmax numpy on the host, every episode (pageable host memory, no overlap); "
+                                     "exact conv variants since round 5 (rounds <= 4: split-K allowed -- not like for like)"}
+    # the same body with the episode's host tensors in PINNED memory (what a DataLoader(pin_memory=True) hands over)
+    pinned = [(tuple(x.pin_memory() for x in ins), msk) for ins, msk in host]
+    for ins, msk in pinned:
+        ev.test_step(ins, msk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(m):
+        pred, loss = ev.test_step(*pinned[i % len(pinned)])
+    dt = time.perf_counter() - t0
+    out["reference_body_pinned"] = {"value": round(m / dt, 2), "ms_per_episode": round(dt / m * 1e3, 4), "conv_variants": "exact",
+                                    "what": "the same test_step body, inputs in pinned host memory"}
     out.update(unit="episodes/s", episodes_per_step=1,
                protocol="one episode per test_step (reference data.test_bs = 1), hipGraph replay, statistics fetched once per round")
     return out
@@ -906,6 +927,7 @@ def protocol_5x1000(net, pool, dev, args, rounds=5, test_n=1000, lanes=4):
             "biou_per_round": [round(float(np.nanmean(r)), 6) for r in ev.round_biou],
             "miou": round(float(np.nanmean(miou)), 6), "biou": round(float(np.nanmean(biou)), 6), "mean_ce_loss": round(float(loss), 6),
             "distinct_episodes": len(data.eps),
+            "conv_variants": "exact (rounds <= 4 of this project ran this figure with split-K allowed: not like for like with BENCH_r04)",
             "what": "Evaluator.start_eval_loop: 5 rounds x 1000 single-episode test_steps (the default, bit-identical conv variants), per-round "
                     "device-side metric table + one fetch; timer_cps = calls / time inside test_step (the reference's Timer), "
                     "episodes_per_s = wall clock of the whole loop; episodes cycle through a resident pool of synthetic E(seed) "
@@ -1107,6 +1129,52 @@ def timed_train_steps(tr, pool, steps, warmup, world, dev):
     return dt, host / steps * 1e3, ls, local_dt, exposed
 
 
+def train_end_to_end(tr, dev, B=4, S=1, steps=10, warmup=3):
+    """Training episodes/s INCLUDING input staging ("end-to-end"): decoded uint8 samples of
+    PASCAL-like sizes in host memory -> the reference's augmentation DRAWS on the host (data_kits/pascal_voc.py:184-240: scale
+    1..1.5, flip, colour-jitter order and factors, crop_obj window -- pemp_amd.data_kits.episode.train_samples) -> one pinned
+    blob per step -> async H2D -> Pillow-exact resize / flip / jitter / crop / normalise on the device
+    (pemp_episode_preprocess) -> the same train_step, the next batch staged on a side stream while the step runs.  JPEG decode
+    is not included (no dataset).  Stage 1 only."""
+    import random
+    from pemp_amd.data_kits import synth_u8
+    from pemp_amd.data_kits.episode import EpisodeLoader, EpisodeTransform, train_samples
+    sizes = [(375, 500), (333, 500), (500, 375), (366, 500), (457, 500)]
+    rng = random.Random(4321)
+    imgs = [[(synth_u8.image(100 * g + k, *sizes[g]), synth_u8.mask(100 * g + k, *sizes[g])) for k in range(S + 1)] for g in range(len(sizes))]
+    host = 0.0
+
+    def batches():
+        nonlocal host
+        for i in range(warmup + steps):
+            h0 = time.perf_counter()
+            batch = []
+            for e in range(B):
+                im = imgs[(i * B + e) % len(imgs)]
+                batch += train_samples(im[:S], im[S:], 401, 401, rng)
+            host += time.perf_counter() - h0
+            yield batch
+
+    loader = EpisodeLoader(batches(), EpisodeTransform(401, 401, device=dev))
+    losses, per_ep = [], None
+    t0 = None
+    for i, (img, planes, labels) in enumerate(loader):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0, host = time.perf_counter(), 0.0
+        img = img.view(B, S + 1, 3, 401, 401)
+        losses.append(tr.train_step(img[:, :S].contiguous(), planes.view(B, S, 2, 401, 401), img[:, S:].contiguous(), torch.stack(labels)))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ls = torch.stack(losses).cpu().numpy()
+    assert np.isfinite(ls).all() and len(losses) == warmup + steps
+    per_ep = sum(a.size + b.size for a, b in imgs[0])
+    return {"value": round(steps * B / dt, 2), "unit": "episodes/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "host_augment_draw_ms_per_step": round(host / steps * 1e3, 3), "h2d_bytes_per_episode": int(per_ep),
+            "path": "host uint8 (decoded) -> augmentation draws (scale, flip, jitter, crop_obj) -> pinned blob -> async H2D -> device "
+                    "resize/flip/jitter/crop/normalise -> train_step; next batch staged on a side stream; JPEG decode excluded"}
+
+
 def train_comm(tr, world, rank_ms, exposed):
     """The `comm` object of a training line: the gradient exchange of one step as the trainer issues it."""
     flat = tr.eng.flat
@@ -1187,6 +1255,8 @@ def main_train(args, world, rank, dev):
         # rank 0 alone, after the process group is gone; the pass is collective-free by construction as well
         # (train_roofline switches every collective of the step off)
         guarded("roofline", lambda: attach_train_pmc(train_roofline(tr, pool, step_ms), args))
+    if world == 1 and not s2 and not os.environ.get("PEMP_BENCH_STUB"):
+        guarded("end_to_end", lambda: train_end_to_end(tr, dev, B, args.shot, steps=max(6, min(args.steps, 20))))
     if world == 1 and args.cpu_episodes > 0 and not os.environ.get("PEMP_BENCH_STUB"):
         guarded("cpu_baseline", lambda: cpu_baseline(args))
     print(json.dumps(out))
@@ -1204,7 +1274,11 @@ def side_train(dev, model="stage1", shot=1, batch=4, steps=10, warmup=4, keep=No
     if keep is not None:
         keep.update(trainer=tr, pool=pool, step_ms=step_ms)
     r = attach_train_pmc(r, argparse.Namespace(model=model, batch=batch, shot=shot))
-    return {"workload": "pemp_%s train_step, ResNet-50, %d-shot, 401x401, %d episodes/step (see --mode train)" % (model, shot, batch),
+    try:
+        e2e = train_end_to_end(tr, dev, batch, shot, steps=steps) if model == "stage1" else None
+    except Exception as exc:  # noqa: BLE001
+        e2e = {"error": f"{type(exc).__name__}: {exc}"}
+    return {"end_to_end": e2e, "workload": "pemp_%s train_step, ResNet-50, %d-shot, 401x401, %d episodes/step (see --mode train)" % (model, shot, batch),
             "episodes_per_step": batch, "steps": steps, "warmup": warmup, "ms_per_step": round(step_ms, 3),
             "episodes_per_s": round(steps * batch / dt, 2), "host_enqueue_ms_per_step": round(host_ms, 2),
             "gflop_per_step": r["gflop_per_step"], "step_effective_tflops": eff,
@@ -1544,7 +1618,9 @@ def main():
         guarded("single_episode", lambda: single_episode(net, dev, args))
     if headline and not args.no_e2e and args.dataset == "PASCAL":
         guarded("end_to_end", lambda: end_to_end(net, args, dev))
-    if world == 1 and args.cpu_episodes > 0 and not vgg:
+    if world == 1 and args.cpu_episodes > 0 and args.model != "panet":
+        if args.model == "baseline":
+            args.cpu_episodes = 4                # BASELINE.json configs[0]: exactly four test episodes
         guarded("cpu_baseline", lambda: cpu_baseline(args))
         if args.model == "stage1" and isinstance(out["cpu_baseline"], dict) and "episodes" in out["cpu_baseline"]:
             rows = {"episodes": out["cpu_baseline"].pop("episodes")}
@@ -1577,6 +1653,14 @@ def main():
                                                "ground truth up to 640x640), 25 episodes/step"))
         guarded("baseline_vgg16", lambda: side_eval(dev, "baseline", "PASCAL", 12,
                                                     what="baseline eval test_step, VGG-16, 1-shot, 401x401, 12 episodes/step"))
+        if isinstance(out.get("baseline_vgg16"), dict) and "error" not in out["baseline_vgg16"] and args.cpu_episodes > 0:
+            # configs[0] names its own CPU figure: "VGG-16, 4 test episodes on CPU" -- the oracle's baseline_forward on seeds 5678..5681
+            try:
+                cb = cpu_baseline(argparse.Namespace(mode="eval", model="baseline", shot=1, batch=1, dataset="PASCAL", cpu_episodes=4))
+                cb.pop("episodes", None)
+                out["baseline_vgg16"]["cpu_baseline"] = cb
+            except Exception as exc:  # noqa: BLE001
+                out["baseline_vgg16"]["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     print(json.dumps(out))
 
 

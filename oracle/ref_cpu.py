@@ -587,6 +587,7 @@ def train_step(sd, sup_img, sup_mask, qry_img, qry_msk, model="stage1", qry_prio
         if model == "stage1" and max_norm > 0:
             # clip_grad_norm_'s own arithmetic (torch/nn/utils/clip_grad.py): float32 norm of the per-tensor float32 norms
             total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g, 2.0) for g in live]), 2.0)
+            train_step.last_grad_norm = float(total)             # what clip_grad_norm_ returns (the norm before clipping)
             coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
             for g in live:
                 g.mul_(coef)

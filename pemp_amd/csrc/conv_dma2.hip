@@ -239,9 +239,17 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     // R16: lane (r16, g) feeds k slot g of v_mfma_f32_16x16x4_f32.  The two MFMAs of quarter j must see k = 8j + {0, 4, 1, 5} and
     // 8j + {2, 6, 3, 7} in their slots 0..3 (the chain order of the 32-row kernels): slot g reads quad 2j + (g & 1) of its row and
     // uses element (g >> 1) for the first MFMA, element 2 + (g >> 1) for the second -- one ds_read2_b32 (dwords +0, +2) per row.
+    // BANKS.  Read as one ds_read2_b32 (+0, +2) per lane, a pass of 64 lanes touches elements {0, 1} of its quads only -- 32 of the
+    // 64 banks, two lanes each -- and the second dword the other 32: every fragment read ran at half rate, and this variant, which
+    // already pays twice the LDS reads per flop, was LDS-bound (round 5: LdsUtil 82.7 %, conflict ratio 2.95).  Now the ODD k slots
+    // (g & 1: the lanes on quad 2j + 1) fetch their two elements in the opposite order: pass one reads element (g >> 1) on the
+    // even and 2 + (g >> 1) on the odd slots, pass two the rest -- elements {0, 1} of one quad and {2, 3} of its neighbour, all
+    // 64 banks once per pass -- and a v_cndmask per operand puts them back (``odd16``).  Same values in the same MFMA slots.
     const int r16 = lane & 15, g16 = lane >> 4;
     const int rsw16 = (r16 >> 1) & 7;                 // wm0 / wn0 / 16 ni are multiples of 16: the row's swizzle is that of r16
-    const int arow16 = (wm0 + r16) * 32 + (g16 >> 1), brow16 = (wn0 + r16) * 32 + (g16 >> 1);     // in floats
+    const bool odd16 = (g16 & 1) != 0;
+    const int e16 = (g16 >> 1) + (odd16 ? 2 : 0);     // element of the quad the FIRST pass reads; the second reads e16 ^ 2
+    const int arow16 = (wm0 + r16) * 32, brow16 = (wn0 + r16) * 32;     // in floats
     float a16[2][2], b16[2][R16 ? TN : 1][2];
 
 #define PEMP_READ(dst_, buf_, j_)                                                                                 \
@@ -251,12 +259,14 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
         if constexpr (R16) {                                                                                      \
             const int pos_ = ((2 * (j_) + (g16 & 1)) ^ rsw16) * 4;                                                \
             const float* pa_ = (const float*)Ab_ + arow16 + pos_;                                                 \
-            a16[dst_][0] = pa_[0];                                                                                \
-            a16[dst_][1] = pa_[2];                                                                                \
+            const float a0_ = pa_[e16], a1_ = pa_[e16 ^ 2];                                                       \
+            a16[dst_][0] = odd16 ? a1_ : a0_;                                                                     \
+            a16[dst_][1] = odd16 ? a0_ : a1_;                                                                     \
             _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) {                                                   \
                 const float* pb_ = (const float*)Bb_ + brow16 + ni * 512 + pos_;                                  \
-                b16[dst_][ni][0] = pb_[0];                                                                        \
-                b16[dst_][ni][1] = pb_[2];                                                                        \
+                const float b0_ = pb_[e16], b1_ = pb_[e16 ^ 2];                                                   \
+                b16[dst_][ni][0] = odd16 ? b1_ : b0_;                                                             \
+                b16[dst_][ni][1] = odd16 ? b0_ : b1_;                                                             \
             }                                                                                                     \
         } else {                                                                                                  \
             const int pos_ = (2 * (j_) + lh) ^ rsw;                                                               \
@@ -532,7 +542,7 @@ static int launch_dma2_group(ConvGroupArgs& g, bool padv, hipStream_t st) {
 // fill whole rounds go to the 64 x 64 tile and the remaining rows to 16-row wave tiles (half the work per K step) in the SAME
 // grid: the SIMDs that would have taken a second 32 x 32 tile take a 16 x 32 one beside their first, 1.5 instead of 2 units per
 // K step.  Both members run the K loop in the same order: bit-identical to every other variant.
-static int g_simds = 0;
+static int g_simds_of[64] = {0};     // SIMD count per device id (filled on first use; racing fills write the same value)
 
 template <bool PADV>
 __global__ __launch_bounds__(256) void conv_dma2_hybrid_kernel(ConvGroupArgs g) {
@@ -546,11 +556,14 @@ __global__ __launch_bounds__(256) void conv_dma2_hybrid_kernel(ConvGroupArgs g) 
 
 // rows of an M x Cout conv that go to the 64 x 64 tile in the hybrid launch (the rest: 16-row tiles); 0 = no such split
 int conv_dma2_hybrid_rows(int M, int Cout) {
-    if (!g_simds) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        g_simds = 4 * cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;        // no device (CPU-side query): the MI355X count
+    if (!g_simds_of[dev]) {
+        int cus = 0;
+        if (dev == 63 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        g_simds_of[dev] = 4 * cus;
     }
+    const int g_simds = g_simds_of[dev];
     if (M <= 0 || Cout < 64 || Cout % 64) return 0;
     const int per32 = Cout / 32;                                 // 32 x 32 wave tiles per 32 output rows
     const int rounds = (int)(((long long)M / 32 * per32) / g_simds);        // whole rounds the 32-row tiles fill

@@ -532,6 +532,7 @@ extern "C" int pemp_conv2d_hybrid_rows(const pemp_conv_desc* d) {
 extern "C" int pemp_conv2d_stats_rows(const pemp_conv_desc* d) {
     if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
     const int t = d->tile == 0 ? 3 : (d->tile > 30 ? d->tile - 30 : d->tile - 20);
+    if (t < 1 || t > 7) return 0;            // 28 / 29 (16-row and hybrid launches) have no statistics epilogue
     const int bm = conv_dma2_tile_rows(t);
     return bm ? cdiv(d->N * d->Ho * d->Wo, bm) : 0;
 }

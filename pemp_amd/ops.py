@@ -74,6 +74,11 @@ TILE_VARIANTS = {13: (64, 64), 14: (128, 128), 12: (128, 64), 11: (128, 128), 15
                  # remaining rows on 16-row wave tiles, one grid (csrc/conv_dma2.hip); other geometries run as 23
                  29: (64, 64)}
 AUTOTUNE = True
+#: test hook: ``PICK_HOOK(kind, cands, key) -> one of cands`` decides every kernel-variant pick INSTEAD of timing (kind "conv":
+#: tile ids, "wgrad": block counts / (tile kind, block count) pairs), at any problem size.  Timing-based picks differ from box
+#: to box and the split-K / weight-gradient splits change the rounding: a whole-step parity test pins them (tests/conftest.py
+#: ``pinned_picks``: AUTOTUNE off = one fixed variant per layer) or sweeps them through this hook.
+PICK_HOOK = None
 SPLITK = os.environ.get("PEMP_CONV_SPLITK", "1") != "0"     # the training convs may pick the split-K variants (A/B switch)
 DEFAULT_TILE = 13
 _TILE_CACHE = {}     # (layer geometry, input shape) -> fastest variant; shared by every ConvParams object
@@ -159,6 +164,11 @@ def tuned_by_rank0(warm):
         warm()
 
 
+def _tunes(rows, least=1024):
+    """Whether a variant pick happens now: the autotuner on a problem worth timing, or the test hook (any size)."""
+    return (PICK_HOOK is not None or (AUTOTUNE and rows >= least)) and not torch.cuda.is_current_stream_capturing()
+
+
 def _pick_tile(launch, p, key, cout, only=None):
     """Time the candidate variants for this (layer, input shape) and remember the fastest: two rounds over all
     candidates (the minimum of a variant's two timings counts: a round can be disturbed by whatever else the GPU is
@@ -167,6 +177,12 @@ def _pick_tile(launch, p, key, cout, only=None):
         cands = [t for t, (bm, bn) in TILE_VARIANTS.items() if cout % bn == 0]
     else:
         cands = [t for t in only if cout % TILE_VARIANTS[t - 10 if t > 30 else t][1] == 0]
+    if PICK_HOOK is not None:
+        best = PICK_HOOK("conv", list(cands), key)
+        if best not in cands:
+            raise ValueError(f"PICK_HOOK returned {best!r}, not one of {cands}")
+        _TILE_CACHE[key] = best
+        return best
 
     def timed(t, reps):
         launch(t)                                   # warm
@@ -298,9 +314,11 @@ def conv2d(x, p, out=None, residual=None, shift_override=None, per_image_shift=F
                 only = list(GROUP_TILES) + (list(SPLITK_TILES) if splitk else [])
             else:
                 only = list(TILE_VARIANTS) + list(SPLITK_TILES) if splitk else None
-            if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():
-                if only is None and not hybrid_rows(n, ho, wo, p.cout):
-                    only = [t for t in TILE_VARIANTS if t != 29]          # no hybrid split for this geometry: id 29 would run as 23
+            if _tunes(n * ho * wo):
+                if only is None:
+                    only = list(TILE_VARIANTS)
+                if 29 in only and not (hybrid_rows(n, ho, wo, p.cout) and dma2_supported(x, p)):
+                    only = [t for t in only if t != 29]       # no hybrid launch for this geometry / layer: id 29 would run as 23 (or 13)
                 tile = _pick_tile(launch, p, key, p.cout, only=only)
             else:
                 tile = DEFAULT_TILE + (10 if dropblock is not None else 0)
@@ -347,7 +365,7 @@ def _conv2d_bf16(x, p, out, residual, shift_override, per_image_shift, relu, til
         key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 5, n, h, w, int(residual is not None), int(pad_value is not None))   # 5: bf16
         tile = _TILE_CACHE.get(key)
         if tile is None:
-            if AUTOTUNE and n * ho * wo >= 1024 and not torch.cuda.is_current_stream_capturing():
+            if _tunes(n * ho * wo):
                 tile = _pick_tile(launch, p, key, p.cout, only=GROUP_TILES)
             else:
                 tile = 24 if p.cout % 128 == 0 else 23
@@ -441,7 +459,7 @@ def conv2d_group(xs, ps, outs, pad_values=None, residuals=None, tile=0):
         key = (-7,) + tuple(keys)               # -7: a grouped launch (the cache file stores keys as integer lists)
         tile = _TILE_CACHE.get(key)
         if tile is None:
-            if AUTOTUNE and max(d[0] * d[5] * d[6] for d in descs) >= 1024 and not torch.cuda.is_current_stream_capturing():
+            if _tunes(max(d[0] * d[5] * d[6] for d in descs)):
                 tile = _pick_tile(launch, None, key, min(p.cout for p in ps),
                                   only=[t for t in GROUP_TILES + (28,) if all(p.cout % TILE_VARIANTS[t][1] == 0 for p in ps)])
             else:
@@ -557,7 +575,7 @@ def conv2d_stats(x, p, out=None, tile=0):
         key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 2, n, h, w, 0, 0)     # 2: the stats epilogue
         tile = _TILE_CACHE.get(key)
         if tile is None:
-            if AUTOTUNE and m >= 1024 and not torch.cuda.is_current_stream_capturing():
+            if _tunes(m):
                 tile = _pick_tile(launch, p, key, p.cout, only=_train_tiles(p.cout) if SPLITK else range(21, 28))
             else:
                 tile = DEFAULT_TILE + 10
@@ -609,7 +627,7 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
         key = (p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil, 3, n, h, w, int(residual is not None), 0)   # 3: this epilogue
         tile = _TILE_CACHE.get(key)
         if tile is None:
-            if AUTOTUNE and m >= 1024 and not torch.cuda.is_current_stream_capturing():
+            if _tunes(m):
                 tile = _pick_tile(launch, p, key, p.cout, only=_train_tiles(p.cout) if SPLITK else range(21, 28))
             else:
                 tile = DEFAULT_TILE + 10

@@ -218,7 +218,14 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=N
         blocks = _WGRAD_BLOCKS.get(key)
         if blocks is None:
             blocks = 0
-            if ops.AUTOTUNE and not accumulate and m >= 4096 and not torch.cuda.is_current_stream_capturing():
+            cands = list(WGRAD_BLOCK_CHOICES)
+            if variant == 0 and not p.stem and cin % 128 == 0 and cout % 128 == 0:      # both tile sizes apply
+                cands = [(k, nb) for k in (2, 3) for nb in WGRAD_BLOCK_CHOICES]
+            if ops.PICK_HOOK is not None and not accumulate and not torch.cuda.is_current_stream_capturing():
+                blocks = ops.PICK_HOOK("wgrad", list(cands), key)
+                if blocks not in cands:
+                    raise ValueError(f"PICK_HOOK returned {blocks!r}, not one of {cands}")
+            elif ops.AUTOTUNE and not accumulate and m >= 4096 and not torch.cuda.is_current_stream_capturing():
                 def timed(nb, reps=3):
                     launch(nb)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -228,9 +235,6 @@ def conv_wgrad(x, g, p, dw, accumulate=False, ws_cache=None, variant=0, blocks=N
                     e1.record()
                     e1.synchronize()
                     return e0.elapsed_time(e1)
-                cands = list(WGRAD_BLOCK_CHOICES)
-                if variant == 0 and not p.stem and cin % 128 == 0 and cout % 128 == 0:      # both tile sizes apply
-                    cands = [(k, nb) for k in (2, 3) for nb in WGRAD_BLOCK_CHOICES]
                 ms = {nb: timed(nb) for nb in cands}
                 for nb in cands:
                     ms[nb] = min(ms[nb], timed(nb))

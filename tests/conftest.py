@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "autotuned: a whole-step test that WANTS the timing-based kernel picks (HIP against HIP, bit for bit)")
 
 
 # Collection order of the GPU suite.  The driver runs `pytest -m gpu -x`: whatever fails first hides everything behind it, so
@@ -55,6 +56,37 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+#: modules whose tests compare whole training steps with reference-made fixtures at a tolerance
+_PINNED_MODULES = {"test_train_gpu.py", "test_grad_frozen_gpu.py", "test_panet_gpu.py", "test_autograd_bridge_gpu.py", "test_cedt_gpu.py",
+                   "test_regularisers_gpu.py"}
+
+
+@pytest.fixture(autouse=True)
+def pinned_picks(request, monkeypatch):
+    """Whole-step parity tests run ONE fixed kernel variant per layer (pemp_amd.ops.AUTOTUNE off: the 64 x 64 tile, no split-K,
+    the library's 768-block weight-gradient split) from EMPTY pick caches.  The autotuners choose by timing, so their picks
+    differ from box to box, and the split-K / weight-gradient splits regroup float32 sums: with timing-based picks a step
+    that is green on one box says nothing about the next one (a fresh box landed on the other side of a
+    bound five builder runs had met).  Every kernel reduces in a fixed order, so with the picks pinned the same test computes
+    the same bits on every MI355X.  The admissible picks are swept, against the one-step bound, by
+    test_train_gpu.py::test_train_step_under_every_admissible_pick; tests marked ``autotuned`` (HIP against HIP, bit for bit)
+    keep the timing-based picks, which is what they are about."""
+    if os.path.basename(str(request.node.fspath)) not in _PINNED_MODULES or request.node.get_closest_marker("autotuned"):
+        yield None
+        return
+    from pemp_amd import ops
+    saved = (dict(ops._TILE_CACHE), dict(ops.WGRAD_PICKS))
+    ops._TILE_CACHE.clear()
+    ops.WGRAD_PICKS.clear()
+    monkeypatch.setattr(ops, "AUTOTUNE", False)
+    monkeypatch.setattr(ops, "PICK_HOOK", None)
+    yield ops
+    ops._TILE_CACHE.clear()
+    ops.WGRAD_PICKS.clear()
+    ops._TILE_CACHE.update(saved[0])
+    ops.WGRAD_PICKS.update(saved[1])
 
 
 @pytest.fixture

@@ -310,15 +310,23 @@ def traj_seeds(step):
     return (31 + 2 * step, 32 + 2 * step)
 
 
-def gen_train_trajectory(tmp):
-    """G25: FIVE consecutive training steps of the reference (entry/pemp_stage1.py:57-65 repeated by core/base_trainer.py:194-200):
-    the imported PEMPStage1 in train() mode (DropBlock off), torch.optim.SGD as core/solver.py:87-91 builds it (lr 1e-3,
-    momentum 0.9, weight decay 5e-4), clip_grad_norm_(1.1), a different batch of two 97 x 97 episodes per step.  Stored: the
-    loss of every step, the gradient norm before clipping, and the weights / BatchNorm buffers after the last step."""
-    from networks import pemp_stage1 as m
+TRAJ_REPLICAS = 8          # perturbed replicas of the trajectory (the fixture's own sensitivity to one float32 ulp)
+TRAJ_REL_EPS = 1e-7
+
+
+def _sampled(v):
+    a = v.detach().reshape(-1)
+    return (a if a.numel() <= 4096 else a[::max(1, a.numel() // 2048)]).numpy()
+
+
+def _run_trajectory(m, tmp, perturb_seed=None):
+    """The reference's five steps from Wgen(1234); ``perturb_seed``: every parameter multiplied by 1 + 1e-7 N(0,1) first."""
     cfg = dict(dist_scalar=20, init_channels=3, out_channels=512, backbone="resnet50", protos=3, drop_rate=0.0, block_size=4)
     model = _build(m, "PEMPStage1", cfg, (), tmp)
     _load_wgen(model)
+    if perturb_seed is not None:
+        from tests import util
+        util.perturb_parameters(model.named_parameters(), perturb_seed, TRAJ_REL_EPS)
     model.train()
     opt = torch.optim.SGD(model.parameters(), 1e-3, momentum=0.9, weight_decay=5e-4, nesterov=False)
     losses, norms = [], []
@@ -331,7 +339,23 @@ def gen_train_trajectory(tmp):
         norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.1)))
         opt.step()
         losses.append(float(loss.detach()))
-    res = {"losses": np.array(losses, np.float64), "grad_norms": np.array(norms, np.float64), "steps": np.array(TRAJ_STEPS)}
+    return model, np.array(losses, np.float64), np.array(norms, np.float64)
+
+
+def gen_train_trajectory(tmp):
+    """G25: FIVE consecutive training steps of the reference (entry/pemp_stage1.py:57-65 repeated by core/base_trainer.py:194-200):
+    the imported PEMPStage1 in train() mode (DropBlock off), torch.optim.SGD as core/solver.py:87-91 builds it (lr 1e-3,
+    momentum 0.9, weight decay 5e-4), clip_grad_norm_(1.1), a different batch of two 97 x 97 episodes per step.  Stored: the
+    loss of every step, the gradient norm before clipping, and the weights / BatchNorm buffers after the last step.
+
+    ENVELOPE (``env_*``): the same five steps by the same reference code from TRAJ_REPLICAS copies of the initial weights, every
+    parameter multiplied by 1 + 1e-7 N(0,1) (about one float32 ulp; seeds 9000 + r).  Per step the largest |loss_r - loss| and
+    |norm_r - norm| / norm over the replicas, per tensor the largest relative L-inf distance of the sampled final weights:
+    how far ANY float32 evaluation of this trajectory may sit from the stored one.  The trajectory amplifies rounding from
+    step to step (the gradient norm jumps 15 -> 37.5 at step 4), so a bound on a later step has to come from here."""
+    from networks import pemp_stage1 as m
+    model, losses, norms = _run_trajectory(m, tmp)
+    res = {"losses": losses, "grad_norms": norms, "steps": np.array(TRAJ_STEPS)}
     sd = model.state_dict()
     names = []
     for k, v in sd.items():
@@ -339,12 +363,30 @@ def gen_train_trajectory(tmp):
             res["buf__" + k] = v.numpy()
             continue
         names.append(k)
-        a = v.detach().reshape(-1)
-        res["w__" + k] = (a if a.numel() <= 4096 else a[::max(1, a.numel() // 2048)]).numpy()
+        res["w__" + k] = _sampled(v)
         res["norm__" + k] = np.array(float(v.detach().double().norm()), np.float64)
     res["names"] = np.array(names)
+    env_l, env_n = np.zeros(TRAJ_STEPS), np.zeros(TRAJ_STEPS)
+    env_w = {k: 0.0 for k in names}
+    rep_l, rep_n = [], []
+    for r in range(TRAJ_REPLICAS):
+        mr, lr_, nr = _run_trajectory(m, tmp, perturb_seed=9000 + r)
+        rep_l.append(lr_)
+        rep_n.append(nr)
+        env_l = np.maximum(env_l, np.abs(lr_ - losses))
+        env_n = np.maximum(env_n, np.abs(nr - norms) / norms)
+        sdr = mr.state_dict()
+        for k in names:
+            ref = res["w__" + k]
+            env_w[k] = max(env_w[k], float(np.abs(_sampled(sdr[k]) - ref).max() / (np.abs(ref).max() + 1e-12)))
+        print(f"  replica {r}: d loss {np.abs(lr_ - losses)}, rel d norm {np.abs(nr - norms) / norms}")
+    res["env_loss"], res["env_norm"] = env_l, env_n
+    res["env_w"] = np.array([env_w[k] for k in names], np.float64)
+    res["env_replica_losses"], res["env_replica_norms"] = np.array(rep_l), np.array(rep_n)
+    res["env_rel_eps"], res["env_replicas"] = np.array(TRAJ_REL_EPS), np.array(TRAJ_REPLICAS)
     np.savez_compressed(OUT / "stage1_rn50_trajectory.npz", **res)
     print("wrote stage1_rn50_trajectory; losses", losses, "grad norms", norms)
+    print("  envelope: loss", env_l, "norm", env_n, "weights max", max(env_w.values()))
 
 
 def gen_train_step_5shot(tmp):

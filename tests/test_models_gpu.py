@@ -77,8 +77,10 @@ def test_stage1_resnet101_matches_reference_golden(hip_lib, dev):
         with torch.no_grad():
             out, resp = net(t["sup_img"], t["sup_mask"], t["qry_img"], hw, ret_ind=True)
         _compare(g, e, out, t["qry_mask"], net._last_feats)
-        _, margin = util.response_reference(net._last_feats, t["sup_mask"], net.ctr, 1, 1, 3, 20, hw)
-        util.assert_response_exact(resp[0, ::7, ::7], g[f"e{e}_resp_s7"], margin[0, ::7, ::7], what="rn101")
+        sd101 = util.wgen_state_dict("stage1_rn101")
+        _, margin = util.response_reference(util.oracle_stage1_feats(sd101, t["sup_img"], t["qry_img"], "resnet101"), t["sup_mask"],
+                                            sd101["ctr"], 1, 1, 3, 20, hw)
+        util.assert_response_exact(resp[0, ::7, ::7], g[f"e{e}_resp_s7"], margin[0, ::7, ::7], what="rn101", max_masked=0.02)   # the oracle's share: 0.0046
 
 
 def test_stage1_plain_map_branch_matches_reference_golden(hip_lib, dev):

@@ -40,6 +40,7 @@ def _run(model, dev, seed, shot, H, hw, ret_ind=True):
 def test_stage1_matches_reference_golden(model, dev, fixture):
     g = util.gold(fixture)
     shot, H = int(g["shot"]), int(g["H"])
+    sd = util.wgen_state_dict("stage1_rn50")
     for e, seed in enumerate(g["seeds"]):
         hw = tuple(int(v) for v in g[f"e{e}_out_hw"])
         t, (logits, resp) = _run(model, dev, seed, shot, H, hw)
@@ -71,9 +72,11 @@ def test_stage1_matches_reference_golden(model, dev, fixture):
         # 0 and the first-max rule amplifies 1-ulp differences -- those pixels are the masked ones.
         rref = g[f"e{e}_resp_s7"]
         rgot = resp[0, ::7, ::7].cpu().numpy()
-        _, margin = util.response_reference(model._last_feats, t["sup_mask"], model.ctr, 1, shot, 3, 20, hw)
+        # the margins come from the ORACLE's features (the reference's arithmetic on the CPU), not from the model's own
+        _, margin = util.response_reference(util.oracle_stage1_feats(sd, t["sup_img"], t["qry_img"]), t["sup_mask"], sd["ctr"], 1, shot, 3, 20, hw)
         rmask = util.assert_response_exact(rgot, rref, margin[0, ::7, ::7], what=f"{fixture} e{e}",
-                                           max_masked=0.18 if fixture == "stage1_rn50_small" else 0.12)
+                                           max_masked=0.14 if fixture == "stage1_rn50_small" else 0.02)     # shares of the fixtures: 0.1224
+                                           # (24 of the 196 sampled pixels of small/e0, 4 of them exact ties) and <= 0.0093; + two pixels
         print(f"{fixture} e{e}: |dlogit| {lerr:.2e}  argmax pixels inside the margin {masked:.5f}  response {rmask:.4f}")
 
 
@@ -90,8 +93,8 @@ def test_stage1_matches_cpu_oracle_batched(model, dev):
     assert got.shape == ref.shape and gresp.shape == rresp.shape and gresp.dtype == torch.int64
     assert (got.cpu() - ref).abs().max().item() < util.LOGIT_TOL
     util.assert_argmax_exact(got, ref.argmax(1), what="batched")
-    _, margin = util.response_reference(model._last_feats, msk, model.ctr, 2, 2, 3, 20, (71, 113))
-    util.assert_response_exact(gresp, rresp, margin, what="batched")
+    _, margin = util.response_reference(util.oracle_stage1_feats(sd, sup, qry), msk, sd["ctr"], 2, 2, 3, 20, (71, 113))
+    util.assert_response_exact(gresp, rresp, margin, what="batched", max_masked=0.02)         # the oracle's share: 0.0055
 
 
 def test_stage1_non_square_and_odd_sizes(model, dev):

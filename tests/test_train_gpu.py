@@ -73,6 +73,39 @@ def test_train_step_gradients_match_reference(hip_lib, dev, head, fixture):
         assert torch.allclose(sd[name].cpu().to(ref.dtype), ref, rtol=1e-4, atol=1e-5), name
 
 
+@pytest.mark.parametrize("policy", range(8))
+def test_train_step_under_every_admissible_pick(hip_lib, dev, monkeypatch, policy):
+    """The kernel picks the autotuners may make change the rounding of a training step (split-K variants regroup the K sum, the
+    weight-gradient kernels split the pixel rows over 512 .. 1536 blocks on 64 x 64 or 128 x 128 tiles).  The fixture tests run
+    one pinned variant per layer (conftest.py::pinned_picks); here the SAME one-step bound (loss 2e-5, gradients by
+    util.check_gradients against float64) is held under eight forced pick policies that between them put every split-K tile
+    (31, 32, 34 .. 37), every plain tile family and every (tile kind, block count) of the weight gradient on every layer that
+    admits it -- ops.PICK_HOOK decides instead of the timer, at any problem size."""
+    from pemp_amd import ops
+    fixture = "stage1_rn50_trainstep"
+    g, g64 = util.gold(fixture), util.gold(fixture + "_f64")
+    seen = {"conv": set(), "wgrad": set()}
+
+    def hook(kind, cands, key):
+        if kind == "conv":
+            want = ops.SPLITK_TILES[policy % len(ops.SPLITK_TILES)]
+            pick = want if want in cands else cands[(policy * 3 + 1) % len(cands)]
+        else:
+            pick = cands[policy % len(cands)]
+        seen[kind].add(pick)
+        return pick
+
+    monkeypatch.setattr(ops, "PICK_HOOK", hook)
+    tr, net = _trainer(dev)
+    (sup, msk, qry, gt), _, H, _ = _fixture_batch(g, dev)
+    loss, _ = tr.forward_backward(sup, msk, qry, gt)
+    torch.cuda.synchronize()
+    assert any(t > 30 for t in seen["conv"]) and seen["wgrad"], seen          # the policy really reached the kernels
+    print(f"  policy {policy}: conv tiles {sorted(seen['conv'])}, weight-gradient picks {sorted(seen['wgrad'], key=str)}, loss {loss.item():.7f}")
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    _check_gradients(g, g64, dict(net.named_parameters()), fixture)
+
+
 def test_optimizer_step_matches_torch_sgd(hip_lib, dev):
     """Same gradients -> fused clip+SGD on the flat buffer == clip_grad_norm_ + torch.optim.SGD."""
     tr, net = _trainer(dev)
@@ -593,6 +626,7 @@ def test_segmented_graph_step_equals_the_eager_step(hip_lib, dev, model):
     assert all(torch.equal(b0[k], b1[k]) for k in b0)
 
 
+@pytest.mark.autotuned
 def test_full_size_training_steps_are_reproducible(hip_lib, dev):
     """BASELINE config 3 at its real shape (4 episodes of 401 x 401 per step, DropBlock on): two trainers started from the same
     weights take the same three steps bit for bit -- split-K fix-ups in arrival order, the two-stream overlap, the statistics
@@ -623,6 +657,7 @@ def test_full_size_training_steps_are_reproducible(hip_lib, dev):
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
+@pytest.mark.autotuned
 def test_full_size_graph_chain_equals_the_eager_step(hip_lib, dev):
     """The hipGraph chain against the eager step at BASELINE config 3's real shape (4 episodes of 401 x 401): the split-K
     variants (arrival counters reset by the kernels themselves, uncached workspace) and the per-shape weight-gradient picks are
@@ -655,36 +690,54 @@ def test_five_step_trajectory_matches_the_reference(hip_lib, dev):
     """FIVE consecutive training steps (the loop of core/base_trainer.py:194-200 around entry/pemp_stage1.py:57-65): fused
     clip + momentum SGD on the flat buffers, BatchNorm running statistics, a different batch every step -- against the
     reference model stepped by torch.optim.SGD(lr 1e-3, momentum 0.9, weight decay 5e-4) + clip_grad_norm_(1.1) on the CPU
-    (tests/golden/stage1_rn50_trajectory.npz; the oracle reproduces it to 2e-6 / 1e-6, test_cpu_suite.py).  Every step's loss
-    within 1e-4, the gradient norm before clipping within 2e-2 relative (measured 8e-3: the norm of a float32 gradient of this
-    step is itself only that good -- the reference's own float32 gradients sit up to 6e-3 of max|g| from float64, see the
-    module docstring -- and it only scales the clipped update), every weight tensor after the last step within
-    WEIGHT_TOL of its reference in relative L-inf over the sampled entries, running statistics within 1e-4, counters equal."""
-    WEIGHT_TOL = 2e-5
+    (tests/golden/stage1_rn50_trajectory.npz; the oracle reproduces it to 2e-6 / 1e-6, test_cpu_suite.py).
+
+    Bounds.  This trajectory amplifies rounding from step to step (the gradient norm jumps 15 -> 37.5 at step 4): the fixture
+    therefore carries its own ENVELOPE -- the same reference code run from 8 copies of the initial weights perturbed by a
+    relative 1e-7 N(0,1), about one float32 ulp (make_golden.py::gen_train_trajectory): per step the largest |d loss| and
+    relative |d norm|, per tensor the largest relative L-inf distance of the final weights.  Step 4 of those replicas moves
+    by up to 3.3e-2 in the norm and 4.7e-5 in the loss (steps 0-2: <= 6e-4 / 4e-6), so rounds 4-5's fixed 2e-2 / 1e-4 sat
+    INSIDE what one ulp does to the reference itself.  Every step is now held to  C x its own envelope + the one-step floor
+    (C = 3: the HIP path differs from ATen by the rounding of every accumulation, not by one ulp of the weights; floors: loss
+    2e-6 -- what the oracle keeps against the fixture --, norm 2e-4, weights 2e-6, running statistics 1e-4 -- the one-step fixtures' tolerance); steps 0-2, where a wrong momentum /
+    weight-decay / running-statistics update would show first, stay below 1e-3 in the norm and 1.4e-5 in the loss by that
+    rule, and are additionally capped at those values.  The kernel picks are pinned (conftest.py::pinned_picks), so the
+    arithmetic is the same on every box."""
+    C_ENV, FLOOR_LOSS, FLOOR_NORM, FLOOR_W = 3.0, 2e-6, 2e-4, 2e-6
     g = util.gold("stage1_rn50_trajectory")
     tr, net = _trainer(dev, lr=1e-3, momentum=0.9, weight_decay=5e-4, max_norm=1.1)
-    dl, dn = 0.0, 0.0
+    bad = []
     for step in range(int(g["steps"])):
         sup, msk, qry, gt = _batch(dev, seeds=(31 + 2 * step, 32 + 2 * step))
         loss = tr.train_step(sup, msk, qry, gt).item()
-        dl = max(dl, abs(loss - float(g["losses"][step])))
-        dn = max(dn, abs(float(tr.last_grad_norm) - float(g["grad_norms"][step])) / float(g["grad_norms"][step]))
-        print(f"  step {step}: loss {loss:.6f} (reference {float(g['losses'][step]):.6f}), gradient norm {float(tr.last_grad_norm):.4f} "
-              f"({float(g['grad_norms'][step]):.4f})")
+        dl = abs(loss - float(g["losses"][step]))
+        dn = abs(float(tr.last_grad_norm) - float(g["grad_norms"][step])) / float(g["grad_norms"][step])
+        bl = C_ENV * float(g["env_loss"][step]) + FLOOR_LOSS
+        bn = C_ENV * float(g["env_norm"][step]) + FLOOR_NORM
+        if step <= 2:
+            bl, bn = min(bl, 1.4e-5), min(bn, 1e-3)
+        print(f"  step {step}: loss {loss:.6f} (reference {float(g['losses'][step]):.6f}; |d| {dl:.2e} <= {bl:.2e}), gradient norm "
+              f"{float(tr.last_grad_norm):.4f} ({float(g['grad_norms'][step]):.4f}; rel {dn:.2e} <= {bn:.2e})")
+        if dl > bl or dn > bn:
+            bad.append((step, dl, bl, dn, bn))
+    assert not bad, bad
     sd = net.state_dict()
-    worst, worst_run, where = 0.0, 0.0, ""
+    worst, worst_run, where, tight = 0.0, 0.0, "", 0.0
+    env_w = dict(zip([str(k) for k in g["names"]], g["env_w"]))
     for k in g["names"]:
         k = str(k)
         a = sd[k].detach().cpu().contiguous().reshape(-1)
         got = (a if a.numel() <= 4096 else a[::max(1, a.numel() // 2048)]).numpy()
         ref = g["w__" + k]
         err = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+        bound = C_ENV * float(env_w[k]) + (1e-4 if "running" in k else FLOOR_W)     # running statistics: the one-step fixtures' rtol
+        tight = max(tight, err / bound)
         if "running" in k:
             worst_run = max(worst_run, err)
         elif err > worst:
             worst, where = err, k
-    print(f"5-step trajectory: max |d loss| {dl:.2e}, max rel d grad-norm {dn:.2e}, weights rel L-inf {worst:.2e} ({where}), "
-          f"running statistics {worst_run:.2e}")
-    assert dl <= 1e-4 and dn <= 2e-2, (dl, dn)
-    assert worst <= WEIGHT_TOL and worst_run <= 1e-4, (worst, where, worst_run)
+        if err > bound:
+            bad.append((k, err, bound))
+    print(f"5-step trajectory: weights rel L-inf {worst:.2e} ({where}), running statistics {worst_run:.2e}; largest error / bound {tight:.2f}")
+    assert not bad, bad
     assert int(sd["encoder.backbone.bn1.num_batches_tracked"]) == 5

@@ -28,6 +28,18 @@ def wgen_state_dict(name, seed=1234):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
 
 
+def perturb_parameters(named_params, seed, rel_eps=1e-7):
+    """In place: every parameter tensor of ``named_params`` (an ordered iterable of (name, float tensor): the order of
+    Module.named_parameters(), which is the order of the non-buffer keys of state_dict()) multiplied by 1 + rel_eps N(0,1) in
+    float64 and rounded back -- about one float32 ulp.  The trajectory fixture's envelope replicas
+    (tests/golden/make_golden.py::gen_train_trajectory) and the CPU test that re-creates one of them with the oracle draw
+    from the same generator in the same order."""
+    gen = torch.Generator().manual_seed(int(seed))
+    with torch.no_grad():
+        for _, p in named_params:
+            p.copy_((p.double() * (1.0 + rel_eps * torch.randn(p.shape, generator=gen, dtype=torch.float64))).to(p.dtype))
+
+
 def gold(name):
     return np.load(os.path.join(GOLD, name + ".npz"))
 
@@ -142,7 +154,8 @@ def assert_argmax_exact(logits, ref_argmax, margin=MARGIN, max_masked=0.03, what
 
 def response_reference(feats_nhwc, sup_mask, ctr, B, S, protos, dist_scalar, out_hw):
     """Response index + its decision margin by the reference's formulas (networks/pemp_stage1.py:195-222,232-261)
-    evaluated on OUR feature map (so that only the head's own rounding is in play): returns (response int64
+    evaluated on the given feature map (fixture tests pass the ORACLE's, ``oracle_stage1_feats``; the kernel tests of
+    test_ops_gpu.py their own random operands): returns (response int64
     [B,Ho,Wo], margin f32 [B,Ho,Wo]) at the output size (nearest upsample, pemp_stage1.py:162).  margin = the
     smaller of: lead of the winning prototype inside the winning class, lead of the winning class."""
     from oracle import ref_cpu
@@ -165,6 +178,20 @@ def response_reference(feats_nhwc, sup_mask, ctr, B, S, protos, dist_scalar, out
     margin = torch.minimum(pick(inner), (vals[:, 1, 0] - vals[:, 0, 0]).abs())
     up = lambda t: F.interpolate(t[:, None].float(), tuple(out_hw), mode="nearest")[:, 0]
     return up(resp).long(), up(margin)
+
+
+def oracle_stage1_feats(sd, sup_img, qry_img, backbone="resnet50"):
+    """The ORACLE's encoder output for an episode batch, laid out as the engines lay theirs out (NHWC, [all supports | all
+    queries]) -- what ``response_reference`` takes: the decision margins of a fixture test then come from the reference's
+    arithmetic on the CPU, not from the features of the model under test."""
+    from oracle import ref_cpu
+    sup_img, qry_img = sup_img.detach().cpu(), qry_img.detach().cpu()
+    B, S, ch, H, W = sup_img.shape
+    Q = qry_img.shape[1]
+    with torch.no_grad():
+        f = ref_cpu.encoder_stage1(torch.cat((sup_img, qry_img), dim=1).view(B * (S + Q), ch, H, W), sd, backbone)
+    f = f.view(B, S + Q, *f.shape[1:])
+    return torch.cat((f[:, :S].flatten(0, 1), f[:, S:].flatten(0, 1))).permute(0, 2, 3, 1).contiguous()
 
 
 def assert_response_exact(resp_got, resp_ref, margin_map, margin=MARGIN, what="", max_masked=0.12):
