@@ -239,17 +239,9 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     // R16: lane (r16, g) feeds k slot g of v_mfma_f32_16x16x4_f32.  The two MFMAs of quarter j must see k = 8j + {0, 4, 1, 5} and
     // 8j + {2, 6, 3, 7} in their slots 0..3 (the chain order of the 32-row kernels): slot g reads quad 2j + (g & 1) of its row and
     // uses element (g >> 1) for the first MFMA, element 2 + (g >> 1) for the second -- one ds_read2_b32 (dwords +0, +2) per row.
-    // BANKS.  Read as one ds_read2_b32 (+0, +2) per lane, a pass of 64 lanes touches elements {0, 1} of its quads only -- 32 of the
-    // 64 banks, two lanes each -- and the second dword the other 32: every fragment read ran at half rate, and this variant, which
-    // already pays twice the LDS reads per flop, was LDS-bound (round 5: LdsUtil 82.7 %, conflict ratio 2.95).  Now the ODD k slots
-    // (g & 1: the lanes on quad 2j + 1) fetch their two elements in the opposite order: pass one reads element (g >> 1) on the
-    // even and 2 + (g >> 1) on the odd slots, pass two the rest -- elements {0, 1} of one quad and {2, 3} of its neighbour, all
-    // 64 banks once per pass -- and a v_cndmask per operand puts them back (``odd16``).  Same values in the same MFMA slots.
     const int r16 = lane & 15, g16 = lane >> 4;
     const int rsw16 = (r16 >> 1) & 7;                 // wm0 / wn0 / 16 ni are multiples of 16: the row's swizzle is that of r16
-    const bool odd16 = (g16 & 1) != 0;
-    const int e16 = (g16 >> 1) + (odd16 ? 2 : 0);     // element of the quad the FIRST pass reads; the second reads e16 ^ 2
-    const int arow16 = (wm0 + r16) * 32, brow16 = (wn0 + r16) * 32;     // in floats
+    const int arow16 = (wm0 + r16) * 32 + (g16 >> 1), brow16 = (wn0 + r16) * 32 + (g16 >> 1);     // in floats
     float a16[2][2], b16[2][R16 ? TN : 1][2];
 
 #define PEMP_READ(dst_, buf_, j_)                                                                                 \
@@ -259,14 +251,12 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
         if constexpr (R16) {                                                                                      \
             const int pos_ = ((2 * (j_) + (g16 & 1)) ^ rsw16) * 4;                                                \
             const float* pa_ = (const float*)Ab_ + arow16 + pos_;                                                 \
-            const float a0_ = pa_[e16], a1_ = pa_[e16 ^ 2];                                                       \
-            a16[dst_][0] = odd16 ? a1_ : a0_;                                                                     \
-            a16[dst_][1] = odd16 ? a0_ : a1_;                                                                     \
+            a16[dst_][0] = pa_[0];                                                                                \
+            a16[dst_][1] = pa_[2];                                                                                \
             _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) {                                                   \
                 const float* pb_ = (const float*)Bb_ + brow16 + ni * 512 + pos_;                                  \
-                const float b0_ = pb_[e16], b1_ = pb_[e16 ^ 2];                                                   \
-                b16[dst_][ni][0] = odd16 ? b1_ : b0_;                                                             \
-                b16[dst_][ni][1] = odd16 ? b0_ : b1_;                                                             \
+                b16[dst_][ni][0] = pb_[0];                                                                        \
+                b16[dst_][ni][1] = pb_[2];                                                                        \
             }                                                                                                     \
         } else {                                                                                                  \
             const int pos_ = (2 * (j_) + lh) ^ rsw;                                                               \
