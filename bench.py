@@ -397,10 +397,7 @@ CLASS_OF = {
     # round 4: the DropBlock-fused forms, the grouped launch of small evaluation steps, the side figure's bf16 conv
     "pemp_conv2d_dropblock_nhwc_f32": "conv", "pemp_bn_apply_dropblock_f32": "batchnorm", "pemp_conv2d_group_nhwc_f32": "conv",
     "pemp_conv2d_bf16_nhwc": "conv",
-    # round 6: the statistics / BatchNorm-backward convs that finish their column sums inside the launch
-    "pemp_conv2d_stats_final_nhwc_f32": "conv", "pemp_conv2d_bnbwd_final_nhwc_f32": "conv", "pemp_bn_bwd_apply_f32": "batchnorm",
 }
-_BNBWD = ("pemp_conv2d_bnbwd_nhwc_f32", "pemp_conv2d_bnbwd_final_nhwc_f32")
 _RESIDUAL_AT_6 = ("pemp_conv2d_nhwc_f32", "pemp_conv2d_padv_nhwc_f32", "pemp_conv2d_splitk_nhwc_f32", "pemp_conv2d_padv_splitk_nhwc_f32",
                   "pemp_conv2d_dropblock_nhwc_f32", "pemp_conv2d_bf16_nhwc")
 
@@ -449,8 +446,8 @@ def _conv_work(name, a):
     m = d.N * d.Ho * d.Wo
     k = d.KH * d.KW * cin
     flops = 2.0 * m * d.Cout * k
-    res = (name in _RESIDUAL_AT_6 and bool(a[6])) or (name in _BNBWD and bool(a[4]))
-    outs = (2 if res else 1) + (1 if name in _BNBWD else 0)       # bnbwd also reads the BatchNorm's input z
+    res = (name in _RESIDUAL_AT_6 and bool(a[6])) or (name == "pemp_conv2d_bnbwd_nhwc_f32" and bool(a[4]))
+    outs = (2 if res else 1) + (1 if name == "pemp_conv2d_bnbwd_nhwc_f32" else 0)       # bnbwd also reads the BatchNorm's input z
     nbytes = 4.0 * (d.N * d.H * d.W * d.Cin + m * d.Cout * outs + d.Cout * d.KH * d.KW * d.Cin)
     return flops, nbytes, (m, d.Cout, k, res)
 

@@ -322,29 +322,6 @@ int pemp_bn_bwd_partials_f32(const float* g, int ldg, const float* z, int ldz, c
                              const float* gamma, const float* stats, int nrows, float* dz, int lddz, float* dgamma,
                              float* dbeta, int M, int C, void* stream);
 
-/* The same two convs with the TOTALS of their partial rows made inside the launch: the workgroup whose tile is the last of
- * its column tile to arrive (one arrival counter per 64 .. 256 output channels) adds that column tile's partial rows in the
- * order of pemp_bn_stats_partials_f32 / pemp_bn_bwd_partials_f32 (double, fixed order: bit-identical to them) and writes
- *   pemp_conv2d_stats_final_nhwc_f32:  mean, invstd (= 1 / sqrt(var + eps)) and the running-statistics update (run_* may be NULL)
- *   pemp_conv2d_bnbwd_final_nhwc_f32:  sum_g[c] = sum g, sum_gxhat[c] = sum g * xhat  (dbeta / dgamma of the BatchNorm)
- * -- the dependent one-block-per-32-channels launch behind every such conv (80 per training step of networks/backbones.py's
- * bottlenecks, :42-77) is gone; pemp_bn_apply_mask_f32 / pemp_bn_bwd_apply_f32 follow directly.
- * stats: pemp_conv2d_stats_rows(d) x 2 x Cout floats, counters: >= Cout / 64 ints, ZERO on entry and left zero -- both in
- * UNCACHED device memory (pemp_uncached_alloc: the exchange crosses XCDs), not shared by launches that may run beside each
- * other.  Everything else as pemp_conv2d_stats_nhwc_f32 / pemp_conv2d_bnbwd_nhwc_f32.                                       */
-int pemp_conv2d_stats_final_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,
-                                     int* counters, float eps, float momentum, float* mean, float* invstd,
-                                     float* run_mean, float* run_var, void* ws, size_t ws_bytes, void* stream);
-int pemp_conv2d_bnbwd_final_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* residual,
-                                     const uint32_t* mask, const float* z, int ldz, const float* mean, const float* invstd,
-                                     float* stats, int* counters, float* sum_g, float* sum_gxhat, void* ws, size_t ws_bytes,
-                                     void* stream);
-/* Second half of the BatchNorm backward from FINISHED sums (pemp_conv2d_bnbwd_final_nhwc_f32 wrote them):
- *   dz = gamma * invstd * (g - dbeta / M - xhat * dgamma / M)     (autograd of nn.BatchNorm2d in train(), backbones.py:55-75) */
-int pemp_bn_bwd_apply_f32(const float* g, int ldg, const float* z, int ldz, const float* mean, const float* invstd,
-                          const float* gamma, const float* dbeta, const float* dgamma, float* dz, int lddz, int M, int C,
-                          void* stream);
-
 /* Weight gradient of pemp_conv2d_nhwc_f32 (autograd of nn.Conv2d, same call sites):
  *   dw[co][kh][kw][ci] (+)= sum_m g[m][co] * x[pix(m,kh,kw)][ci]      dw is KRSC with row length d->Kpad
  * `d` describes the FORWARD conv (d->ldy = per-pixel stride of g).  STEM4 needs Kpad % 64 == 0.  d->tile: bits 0..7 = kernel choice

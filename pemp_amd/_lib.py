@@ -99,11 +99,6 @@ SYMBOLS = {
                                            c_size, c_fp]),
     "pemp_bn_bwd_partials_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int,
                                          c_int, c_fp]),
-    "pemp_conv2d_stats_final_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, C.c_float, C.c_float, c_fp, c_fp,
-                                                 c_fp, c_fp, c_fp, c_size, c_fp]),
-    "pemp_conv2d_bnbwd_final_nhwc_f32": (c_int, [C.POINTER(ConvDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp,
-                                                 c_fp, c_fp, c_fp, c_size, c_fp]),
-    "pemp_bn_bwd_apply_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "pemp_bn_apply_mask_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int,
                                        c_int, c_fp, c_fp]),
     "pemp_conv2d_wgrad_workspace_bytes": (c_size, [C.POINTER(ConvDesc)]),

@@ -66,17 +66,6 @@ struct ConvArgs {
     unsigned flags;
     int M, HoWo, cin_steps, nk, ntaps;
     int bm_first = 0;       // conv_dma2.hip: the launch's first row tile (in units of its BM; 0 except in the hybrid launch's second member)
-    // Finish of the EPI sums INSIDE the launch (pemp_conv2d_stats_final_nhwc_f32 / pemp_conv2d_bnbwd_final_nhwc_f32; NULL: the
-    // partial rows only): fin_cnt holds one arrival counter per column tile (zero on entry, left zero); the block whose tile is
-    // the last of its column tile to arrive adds the partial rows of those columns (conv_stats_finish) and writes
-    //   statistics (stats of y, y^2):     fin0 = mean, fin1 = 1 / sqrt(var + fin_eps), running statistics fin_rm / fin_rv (may be NULL)
-    //   BatchNorm backward (g, g * xhat): fin0 = sum g, fin1 = sum g * xhat
-    int* fin_cnt = nullptr;
-    float* fin0 = nullptr;
-    float* fin1 = nullptr;
-    float* fin_rm = nullptr;
-    float* fin_rv = nullptr;
-    float fin_eps = 0.f, fin_mom = 0.f;
 };
 
 // up to CONV_GROUP_MAX independent convs of one tile shape in one launch (conv_dma2.hip: conv_dma2_group_kernel)
@@ -241,122 +230,6 @@ __device__ __forceinline__ void conv_stats_store(const ConvArgs& a, const float*
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += Rall[((((wmi * WGN + wni) * TN + ni) * 2 + st) * 8 + g) * 32 + c];
         a.stats[((size_t)bm * 2 + st) * a.Cout + n0 + col] = s;
-    }
-}
-
-// The same finish with the TOTALS made inside the launch (a.fin_cnt != NULL): what the separate one-block-per-32-channels
-// kernels of train_ops.hip (bn_stats_partials_kernel / colsum_partials_kernel) do behind the conv -- a dependent launch each,
-// 80 per training step, and in the backward pass a launch that queues behind the weight-gradient blocks that fill the chip
-// beside the chain (26 us on average for 5 us of work).  Here the tile's partial row is stored write-through (sc0 sc1), the
-// block counts itself as arrived on its COLUMN tile's counter, and the block that arrives last adds all row tiles of its
-// BN columns in partials_total's order (thread (rl, q): rows rl, rl + 32, ... ascending in double, then the 32 row lanes
-// ascending): the result does not depend on which block that is, and equals the separate kernels' bit for bit.
-// Hand-off (MI355X_MICROARCH.md, "Valid forms"): every store of the handed-off bytes sc0 sc1 and drained, the workgroup's
-// barrier, ONE lane's returned agent-scope add, the last arriver's agent acquire + wait before it releases its workgroup,
-// every load of the bytes sc0 sc1 to registers.  ``smem``: the block's dynamic LDS (free by now), >= (NT / 256) * 16.7 KB.
-template <int BN, int WGM, int NW, int TN, int BM, int EPI>
-__device__ __forceinline__ void conv_stats_finish(const ConvArgs& a, const float* Rall, int bm, int bn, int n0, int tid, void* smem) {
-    constexpr int WGN = NW / WGM, WN = BN / WGN, NT = NW * 64;
-    if (tid < 2 * BN / 4) {
-        const int st = tid / (BN / 4), col = (tid - st * (BN / 4)) * 4;
-        const int wni = col / WN, ni = (col - wni * WN) >> 5, c = col & 31;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int wmi = 0; wmi < WGM; ++wmi)
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const v4f r = *(const v4f*)(Rall + ((((wmi * WGN + wni) * TN + ni) * 2 + st) * 8 + g) * 32 + c);
-                s[0] += r.x; s[1] += r.y; s[2] += r.z; s[3] += r.w;
-            }
-        const v4f v = {s[0], s[1], s[2], s[3]};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a.stats + ((size_t)bm * 2 + st) * a.Cout + n0 + col), "v"(v) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's partial stores have been acknowledged
-    __syncthreads();                                              // ... everybody's (and every read of Rall is done)
-    const int nrt = (a.M + BM - 1) / BM;
-    int* flag = (int*)smem;
-    if (tid == 0) {
-        const int v = __hip_atomic_fetch_add(a.fin_cnt + bn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v == nrt - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the invalidate has completed before anybody is released
-        }
-        *flag = v;
-    }
-    __syncthreads();
-    const int arrived = *flag;
-    __syncthreads();
-    if (arrived != nrt - 1) return;
-    if (tid == 0) __hip_atomic_store(a.fin_cnt + bn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-    double* red = (double*)smem;                                  // [NT / 256][32][65]
-    const int grp = tid >> 8, t8 = tid & 255, q = t8 & 7, rl = t8 >> 3;
-    for (int g0 = 0; g0 < BN / 32; g0 += NT / 256) {
-        const int c0 = n0 + (g0 + grp) * 32;                      // this group's 32 channels
-        const bool live = g0 + grp < BN / 32;
-        double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
-        if (live) {
-            const float* base = a.stats + c0 + q * 4;
-            int k = rl;
-            for (; k + 32 < nrt; k += 64) {                       // two rows (four coherent loads) in flight per thread, ONE asm
-                v4f x0, x1, x2, x3;                               // statement: nothing may touch the results before its wait.  (Few
-                // registers on purpose: this code must not raise the register count of the conv kernel it sits behind.)
-                asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
-                             "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
-                             "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
-                             "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
-                             "s_waitcnt vmcnt(0)"
-                             : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-                             : "v"(base + ((size_t)(k + 0) * 2 + 0) * a.Cout), "v"(base + ((size_t)(k + 0) * 2 + 1) * a.Cout),
-                               "v"(base + ((size_t)(k + 32) * 2 + 0) * a.Cout), "v"(base + ((size_t)(k + 32) * 2 + 1) * a.Cout)
-                             : "memory");
-                s[0] += (double)x0.x; s[1] += (double)x0.y; s[2] += (double)x0.z; s[3] += (double)x0.w;
-                ss[0] += (double)x1.x; ss[1] += (double)x1.y; ss[2] += (double)x1.z; ss[3] += (double)x1.w;
-                s[0] += (double)x2.x; s[1] += (double)x2.y; s[2] += (double)x2.z; s[3] += (double)x2.w;
-                ss[0] += (double)x3.x; ss[1] += (double)x3.y; ss[2] += (double)x3.z; ss[3] += (double)x3.w;
-            }
-            for (; k < nrt; k += 32) {
-                v4f x0, x1;
-                asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                             : "=&v"(x0), "=&v"(x1)
-                             : "v"(base + ((size_t)k * 2 + 0) * a.Cout), "v"(base + ((size_t)k * 2 + 1) * a.Cout)
-                             : "memory");
-                s[0] += (double)x0.x; s[1] += (double)x0.y; s[2] += (double)x0.z; s[3] += (double)x0.w;
-                ss[0] += (double)x1.x; ss[1] += (double)x1.y; ss[2] += (double)x1.z; ss[3] += (double)x1.w;
-            }
-        }
-        __syncthreads();                                          // (second round: the totals of the first have been read)
-        double* rg = red + grp * 32 * 65;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            rg[rl * 65 + q * 4 + e] = s[e];
-            rg[rl * 65 + 32 + q * 4 + e] = ss[e];
-        }
-        __syncthreads();
-        if (live && t8 < 32) {
-            double t0 = 0.0, t1 = 0.0;
-#pragma unroll 1
-            for (int i = 0; i < 32; ++i) {
-                t0 += rg[i * 65 + t8];
-                t1 += rg[i * 65 + 32 + t8];
-            }
-            const int c = c0 + t8;
-            if constexpr (EPI == 1) {        // bn_stats_partials_kernel's expressions
-                const int M = a.M;
-                const double mu = t0 / M;
-                double var = t1 / M - mu * mu;
-                if (var < 0.0) var = 0.0;
-                a.fin0[c] = (float)mu;
-                a.fin1[c] = (float)(1.0 / sqrt(var + (double)a.fin_eps));
-                if (a.fin_rm) {
-                    const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-                    a.fin_rm[c] = (float)((1.0 - a.fin_mom) * a.fin_rm[c] + a.fin_mom * mu);
-                    a.fin_rv[c] = (float)((1.0 - a.fin_mom) * a.fin_rv[c] + a.fin_mom * unbiased);
-                }
-            } else {                         // colsum_partials_kernel's
-                a.fin0[c] = (float)t0;
-                a.fin1[c] = (float)t1;
-            }
-        }
     }
 }
 

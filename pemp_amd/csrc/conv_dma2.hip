@@ -479,8 +479,7 @@ __device__ __forceinline__ void conv_dma2_body(const ConvArgs& a, const int bid,
     } else conv_epilogue_lds<TM, TN, DB>(a, acc, (float*)smem + wave * 1024, m0 + wm0, n0 + wn0, lane);
     if constexpr (EPI != 0) {
         __syncthreads();
-        if (a.fin_cnt == nullptr) conv_stats_store<BN, WGM, NW, TN>(a, Rall, bm, n0, tid);
-        else conv_stats_finish<BN, WGM, NW, TN, BM, EPI>(a, Rall, bm, bn, n0, tid, smem);
+        conv_stats_store<BN, WGM, NW, TN>(a, Rall, bm, n0, tid);
     }
 #endif
 }

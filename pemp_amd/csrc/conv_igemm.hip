@@ -568,44 +568,3 @@ extern "C" int pemp_conv2d_bnbwd_nhwc_f32(const pemp_conv_desc* d, const float* 
     a.bmask = mask; a.bz = z; a.bmean = mean; a.binvstd = invstd; a.ldbz = ldz;
     return conv_stats_common("conv2d_bnbwd", d, a, ws, ws_bytes, (hipStream_t)stream);
 }
-
-// The two epilogue forms with the totals made inside the launch (conv_common.h: conv_stats_finish).
-static int conv_final_check(const char* what, const pemp_conv_desc* d, const float* stats, const int* cnt, const float* o0, const float* o1) {
-    PEMP_REQUIRE(stats && cnt && o0 && o1, "%s: null pointer", what);
-    PEMP_REQUIRE((((uintptr_t)stats | (uintptr_t)cnt) & 15) == 0, "%s: stats / counters must be 16-byte aligned", what);
-    PEMP_REQUIRE(d->Cout / 64 <= 256, "%s: at most 256 column tiles", what);
-    return 0;
-}
-
-extern "C" int pemp_conv2d_stats_final_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, float* stats,
-                                                int* counters, float eps, float momentum, float* mean, float* invstd,
-                                                float* run_mean, float* run_var, void* ws, size_t ws_bytes, void* stream) {
-    PEMP_REQUIRE(d && x && w && y, "conv2d_stats_final: null pointer");
-    PEMP_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "conv2d_stats_final: pointers must be 16-byte aligned");
-    PEMP_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "conv2d_stats_final: running stats must both be given or both NULL");
-    const int rc = conv_final_check("conv2d_stats_final", d, stats, counters, mean, invstd);
-    if (rc) return rc;
-    ConvArgs a;
-    a.x = x; a.w = w; a.y = y; a.res = nullptr; a.stats = stats;
-    a.bmask = nullptr; a.bz = nullptr; a.bmean = nullptr; a.binvstd = nullptr; a.ldbz = 0;
-    a.fin_cnt = counters; a.fin0 = mean; a.fin1 = invstd; a.fin_rm = run_mean; a.fin_rv = run_var; a.fin_eps = eps; a.fin_mom = momentum;
-    return conv_stats_common("conv2d_stats_final", d, a, ws, ws_bytes, (hipStream_t)stream);
-}
-
-extern "C" int pemp_conv2d_bnbwd_final_nhwc_f32(const pemp_conv_desc* d, const float* x, const float* w, float* y, const float* residual,
-                                                const uint32_t* mask, const float* z, int ldz, const float* mean, const float* invstd,
-                                                float* stats, int* counters, float* sum_g, float* sum_gxhat, void* ws, size_t ws_bytes,
-                                                void* stream) {
-    PEMP_REQUIRE(d && x && w && y && z && mean && invstd, "conv2d_bnbwd_final: null pointer");
-    PEMP_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)z | (uintptr_t)residual | (uintptr_t)mean |
-                   (uintptr_t)invstd) & 15) == 0 && ((uintptr_t)mask & 3) == 0, "conv2d_bnbwd_final: pointers must be 16-byte aligned");
-    PEMP_REQUIRE(ldz >= d->Cout && ldz % 4 == 0 && (!residual || (d->ldr >= d->Cout && d->ldr % 4 == 0)), "conv2d_bnbwd_final: ldz / ldr");
-    const int rc = conv_final_check("conv2d_bnbwd_final", d, stats, counters, sum_g, sum_gxhat);
-    if (rc) return rc;
-    ConvArgs a;
-    a.x = x; a.w = w; a.y = y; a.res = residual; a.stats = stats;
-    a.bmask = mask; a.bz = z; a.bmean = mean; a.binvstd = invstd; a.ldbz = ldz;
-    a.fin_cnt = counters; a.fin0 = sum_g; a.fin1 = sum_gxhat;
-    return conv_stats_common("conv2d_bnbwd_final", d, a, ws, ws_bytes, (hipStream_t)stream);
-}
-

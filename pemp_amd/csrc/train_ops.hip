@@ -804,24 +804,6 @@ extern "C" int pemp_bn_fwd_partials_f32(const float* z, int ldz, const float* st
     return pemp_bn_apply_mask_f32(z, ldz, mean, invstd, gamma, beta, residual, ldr, y, ldy, M, C, relu, mask, stream);
 }
 
-extern "C" int pemp_bn_bwd_apply_f32(const float* g, int ldg, const float* z, int ldz, const float* mean, const float* invstd,
-                                     const float* gamma, const float* dbeta, const float* dgamma, float* dz, int lddz, int M, int C,
-                                     void* stream) {
-    CHK_VEC(g, ldg, C, "bn_bwd_apply");
-    CHK_VEC(z, ldz, C, "bn_bwd_apply");
-    CHK_VEC(dz, lddz, C, "bn_bwd_apply");
-    PEMP_REQUIRE(M > 0 && mean && invstd && gamma && dgamma && dbeta, "bn_bwd_apply: null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const long long total = (long long)M * (C / 4);
-    if (rows_form(C))
-        hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3(rows_grid(M, C)), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, z,
-                           ldz, mean, invstd, gamma, dbeta, dgamma, dz, lddz, (float*)nullptr, 0, M, C / 4, 0);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, g, ldg, (const float*)nullptr, 0, z,
-                           ldz, mean, invstd, gamma, dbeta, dgamma, dz, lddz, (float*)nullptr, 0, (long long)M, C / 4, 0);
-    return launch_status("bn_bwd_apply");
-}
-
 extern "C" int pemp_bn_bwd_partials_f32(const float* g, int ldg, const float* z, int ldz, const float* mean,
                                         const float* invstd, const float* gamma, const float* stats, int nrows, float* dz,
                                         int lddz, float* dgamma, float* dbeta, int M, int C, void* stream) {

@@ -527,44 +527,6 @@ def _splitk_ws(lib, desc, device):
     return ent
 
 
-#: Uncached workspaces of the in-launch finish of the BatchNorm sums (pemp_conv2d_stats_final_nhwc_f32 / _bnbwd_final_): 1 KB of
-#: arrival counters + the partial rows, one per (device, scope) like the split-K workspaces -- convs of one scope run one after
-#: the other, so they share it; a conv whose partial rows do not fit keeps the separate finishing launch.
-_FIN_WS = {}
-_FIN_WS_BYTES = 8 << 20
-#: most row tiles a conv may have for the in-launch finish: the LAST workgroup of a column tile adds them all, 32 at a time, and
-#: that tail is exposed (layer 1's 81 608 rows are 1 276 tiles of 64: they keep the separate launch)
-FIN_MAX_ROWS = int(os.environ.get("PEMP_FIN_MAX_ROWS", "704"))
-FUSE_FINISH = os.environ.get("PEMP_FUSE_FINISH", "1") != "0"      # A/B switch of the whole mechanism
-
-
-def finish_ws(device, m, cout):
-    """-> (counters pointer, partial-rows pointer) of this device's / scope's finish workspace, or None where the in-launch
-    finish does not apply (switched off, too many row tiles, rows that do not fit, or -- first use -- a hipGraph being
-    recorded before the workspace exists)."""
-    rows = (m + 63) // 64
-    if not FUSE_FINISH or rows > FIN_MAX_ROWS or 1024 + rows * 2 * cout * 4 > _FIN_WS_BYTES or cout // 64 > 256:
-        return None
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    ent = _FIN_WS.get((idx, SK_SCOPE))
-    if ent is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        lib = _lib.load()
-        with torch.cuda.device(device):
-            ptr = lib.pemp_uncached_alloc(_FIN_WS_BYTES)
-        if not ptr:
-            _lib.check(-1, "pemp_uncached_alloc")
-        ent = _FIN_WS[(idx, SK_SCOPE)] = (ptr, ptr + 1024)
-    return ent
-
-
-def _check_fin(lib, rc, fin):
-    """A failed launch may have left arrival counters of the finish workspace non-zero: clear them (its first 1024 bytes)."""
-    if rc and fin is not None:
-        lib.pemp_splitk_reset(C.c_void_p(fin[0]), _stream())
-
-
 def _check_sk(lib, rc, ws, what):
     """A split-K launch that failed may have left arrival counters non-zero (no block would ever be "last" again): clear
     them before the failure is raised."""
@@ -583,13 +545,10 @@ def _train_tiles(cout):
     return [t for t in list(range(21, 28)) + list(SPLITK_TILES) if cout % TILE_VARIANTS[t - 10 if t > 30 else t][1] == 0]
 
 
-def conv2d_stats(x, p, out=None, tile=0, final=None):
+def conv2d_stats(x, p, out=None, tile=0):
     """z = conv(x, w) with the per-32-row partial sums of z and z^2 left by the epilogue (pemp_conv2d_stats_nhwc_f32):
     -> (z, partials [row tiles of the chosen variant, 2, Cout]).  Raises PempHipError where the buffer-addressed kernels do not apply
-    (callers then use conv2d + bn_stats); ``stats_supported`` says so beforehand.
-    ``final`` = (eps, momentum, running_mean, running_var) with a workspace from ``finish_ws``: the batch statistics are FINISHED
-    inside the launch (pemp_conv2d_stats_final_nhwc_f32) -> (z, (mean, invstd)); the values are bit-identical to
-    train_ops.bn_stats_partials on the partials."""
+    (callers then use conv2d + bn_stats); ``stats_supported`` says so beforehand."""
     lib = _lib.load()
     _chk_dev(x, p.w, out)
     ldx = _nhwc(x, "x")
@@ -604,23 +563,11 @@ def conv2d_stats(x, p, out=None, tile=0, final=None):
         out = torch.empty((n, ho, wo, p.cout), dtype=torch.float32, device=x.device)
     ldy = _nhwc(out, "out")
     m = n * ho * wo
-    fin = finish_ws(x.device, m, p.cout) if final is not None else None
-    if fin is not None:
-        eps, mom, run_mean, run_var = final
-        mean = torch.empty(p.cout, dtype=torch.float32, device=x.device)
-        invstd = torch.empty(p.cout, dtype=torch.float32, device=x.device)
-    else:
-        part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)     # the smallest row tile has 64 rows
+    part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)     # the smallest row tile has 64 rows
 
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, 0, p.kpad, 0, t)
         ws, ws_bytes = _splitk_ws(lib, d, x.device) if t > 30 else (None, 0)
-        if fin is not None:
-            rc = lib.pemp_conv2d_stats_final_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), C.c_void_p(fin[1]), C.c_void_p(fin[0]), eps, mom,
-                                                      _p(mean), _p(invstd), _p(run_mean), _p(run_var), C.c_void_p(ws), ws_bytes, _stream())
-            _check_fin(lib, rc, fin)
-            _check_sk(lib, rc, ws, "pemp_conv2d_stats_final_nhwc_f32")
-            return
         _check_sk(lib, lib.pemp_conv2d_stats_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(part), C.c_void_p(ws), ws_bytes,
                                                       _stream()), ws, "pemp_conv2d_stats_nhwc_f32")
 
@@ -629,28 +576,19 @@ def conv2d_stats(x, p, out=None, tile=0, final=None):
         tile = _TILE_CACHE.get(key)
         if tile is None:
             if _tunes(m):
-                if fin is not None and run_mean is not None:        # timing runs must not move the running statistics
-                    keep = (run_mean.clone(), run_var.clone())
                 tile = _pick_tile(launch, p, key, p.cout, only=_train_tiles(p.cout) if SPLITK else range(21, 28))
-                if fin is not None and run_mean is not None:
-                    run_mean.copy_(keep[0])
-                    run_var.copy_(keep[1])
             else:
                 tile = DEFAULT_TILE + 10
     launch(tile)
-    if fin is not None:
-        return out, (mean, invstd)
     return out, part[:_stats_rows(m, tile)]
 
 
-def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0, final=None):
+def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0):
     """g = mask(conv(x, w) + residual) -- the gradient at the output of a train-mode BatchNorm(+ReLU), masked by that
     BatchNorm's ReLU -- with the per-32-row partial sums of g and g * xhat left by the epilogue
     (pemp_conv2d_bnbwd_nhwc_f32).  ``bn``: dict with z (the BatchNorm's input, NHWC like the result), mean, invstd and
     mask (int32 [M, C/32] sign bits from train_ops.bn_apply, or None for a BatchNorm without ReLU).
-    -> (g, partials [row tiles of the chosen variant, 2, Cout]).
-    ``final`` = (sum_g [Cout], sum_gxhat [Cout]) fp32 destinations (the BatchNorm's dbeta / dgamma) with a workspace from
-    ``finish_ws``: the column sums are FINISHED inside the launch (pemp_conv2d_bnbwd_final_nhwc_f32) -> (g, None)."""
+    -> (g, partials [row tiles of the chosen variant, 2, Cout])."""
     lib = _lib.load()
     z, mask = bn["z"], bn.get("mask")
     _chk_dev(x, p.w, out, residual, z, mask, bn["mean"], bn["invstd"])
@@ -676,24 +614,11 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0, final=None):
         ldr = _nhwc(residual, "residual")
         if tuple(residual.shape) != tuple(out.shape):
             raise ValueError("conv2d_bnbwd: residual shape mismatch")
-    fin = finish_ws(x.device, m, p.cout) if final is not None else None
-    if fin is not None:
-        _chk_dev(*final)
-        if any(t.dtype != torch.float32 or t.numel() != p.cout or not t.is_contiguous() for t in final):
-            raise ValueError("conv2d_bnbwd: final = two contiguous fp32 [Cout] tensors")
-    else:
-        part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)
+    part = torch.empty(((m + 63) // 64, 2, p.cout), dtype=torch.float32, device=x.device)
 
     def launch(t):
         d = ConvDesc(n, h, w, cin, ldx, ho, wo, p.cout, ldy, p.kh, p.kw, p.stride, p.pad, p.dil, ldr, p.kpad, 0, t)
         ws, ws_bytes = _splitk_ws(lib, d, x.device) if t > 30 else (None, 0)
-        if fin is not None:
-            rc = lib.pemp_conv2d_bnbwd_final_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(residual), _p(mask), _p(z), ldz,
-                                                      _p(bn["mean"]), _p(bn["invstd"]), C.c_void_p(fin[1]), C.c_void_p(fin[0]),
-                                                      _p(final[0]), _p(final[1]), C.c_void_p(ws), ws_bytes, _stream())
-            _check_fin(lib, rc, fin)
-            _check_sk(lib, rc, ws, "pemp_conv2d_bnbwd_final_nhwc_f32")
-            return
         _check_sk(lib, lib.pemp_conv2d_bnbwd_nhwc_f32(C.byref(d), _p(x), _p(p.w), _p(out), _p(residual), _p(mask), _p(z), ldz,
                                                       _p(bn["mean"]), _p(bn["invstd"]), _p(part), C.c_void_p(ws), ws_bytes,
                                                       _stream()), ws, "pemp_conv2d_bnbwd_nhwc_f32")
@@ -707,8 +632,6 @@ def conv2d_bnbwd(x, p, bn, residual=None, out=None, tile=0, final=None):
             else:
                 tile = DEFAULT_TILE + 10
     launch(tile)
-    if fin is not None:
-        return out, None
     return out, part[:_stats_rows(m, tile)]
 
 

@@ -453,34 +453,20 @@ class Stage1TrainEngine:
         prm = conv.fwd_params(relu=False, with_bias=False)
         part = None
         if FUSE_BN_STATS and img_bias is None and ops.stats_supported(x, prm):
-            # batch statistics started in the conv epilogue -- and, for convs of at most ops.FIN_MAX_ROWS row tiles, finished by
-            # the launch's last workgroup per column tile (``part`` is then the finished (mean, invstd) pair)
-            z, part = ops.conv2d_stats(x, prm, final=(bn.bn.eps, BN_MOM, bn.bn.running_mean, bn.bn.running_var))
+            z, part = ops.conv2d_stats(x, prm)         # batch statistics started in the conv epilogue
         else:
             z = conv2d(x, prm) if img_bias is None else conv2d(x, prm, shift_override=img_bias, per_image_shift=True)
         mask = None
         if FUSE_BN_BWD and relu and T.mask_supported(z.shape[-1]):       # sign bits of y: what the backward needs of it
             mask = torch.empty((z.numel() // z.shape[-1], z.shape[-1] // 32), dtype=torch.int32, device=z.device)
-        if part is not None and not isinstance(part, tuple):             # ... finished and applied by one call
+        if part is not None:                           # ... finished and applied by one call
             y, mean, invstd = T.bn_fwd_partials(z, part, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(z), bn.bn.eps, BN_MOM,
                                                 bn.bn.running_mean, bn.bn.running_var, residual=residual, relu=relu, mask=mask)
-            return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu, mask=mask, bn=bn)
-        mean, invstd = part if part is not None else bn.stats(z, self.ws)
+            return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu, mask=mask)
+        mean, invstd = bn.stats(z, self.ws)
         y = T.bn_apply(z, mean, invstd, bn.bn.weight.data, bn.bn.bias.data, torch.empty_like(z), residual=residual, relu=relu,
                        mask=mask)
-        return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu, mask=mask, bn=bn)
-
-    @staticmethod
-    def _bn_sums(rec):
-        """(dbeta, dgamma) destinations of the BatchNorm of tape record ``rec`` -- its slots of the flat gradient buffer, or two
-        temporaries for a frozen one -- remembered in the record: where ops.conv2d_bnbwd's in-launch finish leaves the column
-        sums and T.bn_bwd_apply reads them."""
-        go = rec["bn"].grad_out()
-        if go is None:
-            c = rec["z"].shape[-1]
-            go = (torch.empty(c, dtype=torch.float32, device=rec["z"].device), torch.empty(c, dtype=torch.float32, device=rec["z"].device))
-        rec["gsums"] = (go[1], go[0])
-        return rec["gsums"]
+        return y, dict(x=x, z=z, y=y, mean=mean, invstd=invstd, relu=relu, mask=mask)
 
     def _cbn_bwd(self, dy, rec, conv, bn, want_gout=False, need_dx=True, add_to=None, up=None):
         """-> (dx [compact for stride-2], gout).  ``add_to`` is added to dx inside the dgrad epilogue; the
@@ -489,11 +475,8 @@ class Stage1TrainEngine:
         starts its column sums (ops.conv2d_bnbwd), and up["gpart"] tells its _cbn_bwd to finish from there."""
         dz = torch.empty_like(rec["z"])
         if "gpart" in rec:           # dy is the masked gradient g already; its sums were started by the conv that made it
-            gpart = rec.pop("gpart")
-            if gpart is None:        # ... and finished inside that launch: (dbeta, dgamma) are in place
-                T.bn_bwd_apply(dy, rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, *rec.pop("gsums"), dz)
-            else:
-                T.bn_bwd_partials(dy, rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, gpart, dz, out=bn.grad_out())
+            T.bn_bwd_partials(dy, rec["z"], rec["mean"], rec["invstd"], bn.bn.weight.data, rec.pop("gpart"), dz,
+                              out=bn.grad_out())
             gout = dy if want_gout else None
         else:
             gout = torch.empty_like(rec["z"]) if want_gout else None
@@ -507,7 +490,7 @@ class Stage1TrainEngine:
         prm = conv.dgrad_params()
         if (up is not None and FUSE_BN_BWD and (up["mask"] is not None or not up["relu"]) and prm.shift is None
                 and ops.stats_supported(dz, prm)):
-            dx, up["gpart"] = ops.conv2d_bnbwd(dz, prm, up, residual=add_to, final=self._bn_sums(up))
+            dx, up["gpart"] = ops.conv2d_bnbwd(dz, prm, up, residual=add_to)
         else:
             dx = conv2d(dz, prm, residual=add_to)
         return dx, gout
@@ -696,7 +679,7 @@ class Stage1TrainEngine:
         self.p0.wgrad(tp["p0_in"], g, self.ws)
         prm = self.p0.dgrad_params()
         if up is not None and FUSE_BN_BWD and up["mask"] is not None and prm.shift is None and ops.stats_supported(g, prm):
-            dx, up["gpart"] = ops.conv2d_bnbwd(g, prm, up, final=self._bn_sums(up))
+            dx, up["gpart"] = ops.conv2d_bnbwd(g, prm, up)
             return dx
         return conv2d(g, prm)
 

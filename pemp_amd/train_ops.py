@@ -129,19 +129,6 @@ def bn_bwd_partials(g, z, mean, invstd, gamma, part, dz, out=None):
     return dgamma, dbeta
 
 
-def bn_bwd_apply(g, z, mean, invstd, gamma, dbeta, dgamma, dz):
-    """Second half of the BatchNorm backward from FINISHED column sums (ops.conv2d_bnbwd(final=(dbeta, dgamma)) wrote them):
-    dz = gamma * invstd * (g - dbeta / M - xhat * dgamma / M)  (pemp_bn_bwd_apply_f32)."""
-    lib = _lib.load()
-    _chk_dev(g, z, dz, dbeta, dgamma)
-    m, c, ldg = _rows(g, "g")
-    _, _, ldz = _rows(z, "z")
-    _, _, lddz = _rows(dz, "dz")
-    _lib.check(lib.pemp_bn_bwd_apply_f32(_p(g), ldg, _p(z), ldz, _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), _p(dz), lddz,
-                                         m, c, _stream()), "bn_bwd_apply")
-    return dz
-
-
 def bn_bwd(dy, y, z, mean, invstd, gamma, dz, gout=None, relu=True, ws_cache=None, out=None, mask=None):
     """-> (dgamma, dbeta); writes dz (and gout = dy*(y>0), the gradient of the residual branch).
     ``out=(dgamma, dbeta)``: contiguous [C] tensors to write into (e.g. the flat-buffer gradient views).

@@ -279,75 +279,6 @@ def test_input_gradient_conv_with_batchnorm_backward_in_the_epilogue(hip_lib, de
     assert torch.allclose(dz, dz0, rtol=1e-4, atol=1e-5), (dz - dz0).abs().max()
 
 
-FINISH_CASES = [  # N, H, W, Cin, Cout, k, p, d
-    (8, 51, 51, 256, 1024, 1, 0, 1),     # 326 row tiles of 64: the short-K, wide-N layer of the training step
-    (8, 51, 51, 1024, 256, 1, 0, 1),
-    (8, 51, 51, 256, 256, 3, 2, 2),      # split-K variants: the finishing workgroup of a split tile counts for it
-    (2, 26, 26, 128, 512, 1, 0, 1),
-    (1, 5, 3, 64, 64, 1, 0, 1),          # one row tile: the only workgroup of its column tile is the last one
-]
-
-
-@pytest.mark.parametrize("case", FINISH_CASES)
-def test_statistics_finished_inside_the_conv_launch(hip_lib, dev, case, monkeypatch):
-    """pemp_conv2d_stats_final_nhwc_f32 / pemp_conv2d_bnbwd_final_nhwc_f32: the workgroup whose tile arrives last on its column
-    tile's counter adds the partial rows itself.  On every tile variant: z / g bit-identical to the partial-rows form, mean /
-    invstd / running statistics bit-identical to pemp_bn_stats_partials_f32 on those partial rows and dbeta / dgamma to
-    pemp_bn_bwd_partials_f32's (same order, same double arithmetic), pemp_bn_bwd_apply_f32 = the second half of
-    pemp_bn_bwd_partials_f32 -- launch after launch on the same workspace (the counters are left zero), while a second
-    stream keeps the memory system busy in bursts (MI355X_MICROARCH.md: test every hand-off under uneven load)."""
-    from pemp_amd import ops, train_ops as T
-    monkeypatch.setattr(ops, "FIN_MAX_ROWS", 4096)
-    N, H, W, Cin, Cout, k, p, d = case
-    M = N * H * W
-    x = _nhwc(_rand(N, Cin, H, W, seed=1)).to(dev)
-    w = _rand(Cout, Cin, k, k, seed=2, lo=-0.1, hi=0.1)
-    packed, kpad = ops.pack_conv_weight(w.to(dev))
-    prm = ops.ConvParams(packed, None, None, Cin, Cout, k, k, 1, p, d, kpad, False, False)
-    assert ops.finish_ws(dev, M, Cout) is not None
-    zb = _nhwc(_rand(N, Cout, H, W, seed=11) * 2 + 0.3).to(dev)              # the BatchNorm the gradient belongs to
-    gamma, beta = _rand(Cout, seed=13, lo=0.5, hi=1.5).to(dev), _rand(Cout, seed=14).to(dev)
-    mean_b, invstd_b = T.bn_stats(zb.view(M, Cout))
-    mask = torch.empty((M, Cout // 32), dtype=torch.int32, device=dev)
-    T.bn_apply(zb, mean_b, invstd_b, gamma, beta, torch.empty_like(zb), relu=True, mask=mask)
-    bn = dict(z=zb, mean=mean_b, invstd=invstd_b, mask=mask)
-    add = _nhwc(_rand(N, Cout, H, W, seed=3)).to(dev)
-    rm0, rv0 = _rand(Cout, seed=5), _rand(Cout, seed=6, lo=0.5, hi=1.5)
-    big_a, big_b = torch.empty(32 << 20, device=dev), torch.empty(32 << 20, device=dev)
-    side = torch.cuda.Stream(device=dev)
-    tiles = [t for t in list(range(21, 28)) + list(ops.SPLITK_TILES) if Cout % ops.TILE_VARIANTS[t - 10 if t > 30 else t][1] == 0]
-    for tile in tiles:
-        z, part = ops.conv2d_stats(x, prm, tile=tile)
-        rm1, rv1 = rm0.to(dev), rv0.to(dev)
-        mean, invstd = T.bn_stats_partials(part, M, 1e-5, 0.1, rm1, rv1)
-        g, gpart = ops.conv2d_bnbwd(x, prm, bn, residual=add, tile=tile)
-        dz = torch.empty_like(zb)
-        dgamma, dbeta = T.bn_bwd_partials(g, zb, mean_b, invstd_b, gamma, gpart, dz)
-        side.wait_stream(torch.cuda.current_stream())
-        for rep in range(4):
-            with torch.cuda.stream(side):
-                if rep % 2 == 0:
-                    big_b.copy_(big_a)
-            rm2, rv2 = rm0.to(dev), rv0.to(dev)
-            z2, fin = ops.conv2d_stats(x, prm, tile=tile, final=(1e-5, 0.1, rm2, rv2))
-            assert isinstance(fin, tuple), "the in-launch finish did not run"
-            assert torch.equal(z2, z) and torch.equal(fin[0], mean) and torch.equal(fin[1], invstd), (tile, rep)
-            assert torch.equal(rm2, rm1) and torch.equal(rv2, rv1), (tile, rep)
-            db2, dg2 = torch.full_like(dbeta, 7.0), torch.full_like(dgamma, 7.0)
-            g2, none = ops.conv2d_bnbwd(x, prm, bn, residual=add, tile=tile, final=(db2, dg2))
-            assert none is None and torch.equal(g2, g) and torch.equal(db2, dbeta) and torch.equal(dg2, dgamma), (tile, rep)
-            dz2 = T.bn_bwd_apply(g2, zb, mean_b, invstd_b, gamma, db2, dg2, torch.empty_like(zb))
-            assert torch.equal(dz2, dz), (tile, rep)
-        torch.cuda.current_stream().wait_stream(side)
-    # the workspace's counters are zero again: a plain read of the uncached words
-    cnt_ptr, _ = ops.finish_ws(dev, M, Cout)
-    host = (ops.C.c_int * 256)()
-    torch.cuda.synchronize()
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    assert hip.hipMemcpy(host, ctypes.c_void_p(cnt_ptr), 1024, 2) == 0 and not any(host)
-
-
 def test_conv_with_batch_statistics_refuses_what_it_cannot_run(hip_lib, dev):
     from pemp_amd import _lib, ops
     x = torch.zeros(1, 8, 8, 64, device=dev)
