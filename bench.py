@@ -1030,7 +1030,7 @@ def stub_trainer(rank):
             f.data, f.grad, f.side_stream = torch.zeros(n), torch.zeros(n), None
             e.flat, e.ws = f, {}
             e.buckets = GradBuckets(f.grad, [n // 4, n // 2, 3 * n // 4], min_bytes=n)        # four buckets of 64 KB
-            self.eng, self.use_graph, self.optimizer, self.calls, self.device = e, False, None, 0, torch.device("cpu")
+            self.eng, self.use_graph, self.optimizer, self.calls, self.device = e, False, None, 0, torch.device("cpu")     # (no hipGraphs on the CPU: --train-graph is plumbing only here)
 
         def forward_backward(self, *ins):
             f, b = self.eng.flat, self.eng.buckets
@@ -1220,6 +1220,12 @@ def main_train(args, world, rank, dev):
     dt, host_ms, ls, local_dt, exposed = timed_train_steps(tr, pool, args.steps, args.warmup, world, dev)
     rank_ms = gather_rank_ms(local_dt, args.steps, world, dev)
     comm = train_comm(tr, world, rank_ms, exposed)
+    # every rank's own host time per step (Python enqueue of the step's launches; ``--train-graph``: of its hipGraph chain): a
+    # rank whose figure approaches its rank_ms_per_step is enqueue-bound, not communication-bound -- the eager step enqueues
+    # ~450 launches from ONE host thread per rank, eight of them share the node's cores
+    host_all = gather_rank_ms(host_ms * 1e-3 * args.steps, args.steps, world, dev)
+    comm["host_enqueue_ms_per_step"] = {"max": round(max(host_all), 3), "all": [round(v, 3) for v in host_all],
+                                        "of_step": round(max(h / max(r, 1e-9) for h, r in zip(host_all, rank_ms)), 3)}
     if world > 1:
         # the process group ends HERE: what rank 0 measures below is rank-local, and the other ranks leave instead of spinning
         # in a barrier kernel on their GPUs for its whole duration

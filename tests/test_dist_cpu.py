@@ -309,6 +309,24 @@ def test_bench_train_control_flow_two_ranks_with_the_rank0_roofline_pass():
     assert comm["gradient_elements"] == 1 << 16 and comm["allreduce_bytes_per_step"] == 4 << 16
     assert comm["buckets"] == [[49152, 65536], [32768, 49152], [16384, 32768], [0, 16384]] and comm["collectives_per_step"] == 4
     assert sum(comm["bucket_bytes"]) == comm["allreduce_bytes_per_step"] and comm["exposed_comm_ms"] > 0
+    # every rank's host time per step, next to its step time: what tells an enqueue-bound rank from a communication-bound one
+    he = comm["host_enqueue_ms_per_step"]
+    assert len(he["all"]) == 2 and he["max"] == max(he["all"]) > 0 and 0 < he["of_step"] <= 1.05
+
+
+def test_bench_train_graph_flag_two_ranks():
+    """`bench.py --gpus 2 --mode train --train-graph` end to end on gloo: the launcher hands the flag to both ranks, the line
+    says so (``config.hipgraph``), the gradient exchange is the one all-reduce BEHIND the replayed chain that the graph step
+    makes (Stage1Trainer.train_step: the buckets are switched off while a hipGraph chain replays), and the data-parallel
+    result is unchanged.  (The CPU stub has no hipGraphs: what runs here is the control flow around them.)"""
+    import json
+    r = _run_bench({"PEMP_BENCH_STUB": "1", "PEMP_BENCH_DRYRUN": "", "PEMP_BENCH_SILENCE_S": "60"},
+                   "--gpus", "2", "--steps", "3", "--warmup", "2", "--mode", "train", "--train-graph")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["config"]["hipgraph"] is True
+    assert abs(out["config"]["stub_weight"] - (-0.1 * 1.5 * 5)) < 1e-6
+    assert len(out["comm"]["host_enqueue_ms_per_step"]["all"]) == 2 and len(out["comm"]["rank_ms_per_step"]["all"]) == 2
 
 
 def test_bench_train_stub_roofline_pass_with_collectives_left_on_would_mismatch():
