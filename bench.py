@@ -522,7 +522,7 @@ def summarize(rec, reps, step_ms=None):
     return roof
 
 
-PROFILE_ROUNDS = ("r05", "r04", "r03")      # committed PMC summaries are looked up newest round first
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03")      # committed PMC summaries are looked up newest round first
 
 
 def attach_pmc(roof, workload_key):

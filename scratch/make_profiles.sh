@@ -5,7 +5,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 PART=${1:-all}
-R=${R:-r05}
+R=${R:-r06}
 export PEMP_ROUND=$R
 O=gpurun_out/$R; mkdir -p $O
 B="--cpu-episodes 0 --no-e2e --no-single --no-sides"
