@@ -201,7 +201,10 @@ def _check_comm(out, world, mode):
     per = comm["rank_ms_per_step"]
     assert len(per["all"]) == world and per["min"] == min(per["all"]) and per["max"] == max(per["all"])
     # every rank's OWN step time (before the collective couples them): rank r sleeps 2 (r + 1) ms per step
-    assert all(2.0 * (r + 1) <= v < 2.0 * (r + 1) + 3.0 for r, v in enumerate(per["all"])), per
+    # (lower bound exact -- a sleep never returns early --, upper bound generous: on a loaded 8-core container a 4 ms sleep was seen
+    # to take 7.3; what the line must show is each rank's OWN time, i.e. the ranks in the order of their sleeps)
+    assert all(2.0 * (r + 1) <= v < 2.0 * (r + 1) + 25.0 for r, v in enumerate(per["all"])), per
+    assert world < 2 or per["all"][-1] > per["all"][0], per
     assert 1 <= comm["host_threads_per_rank"] <= max(1, len(os.sched_getaffinity(0)) // world)
     assert out["process_group_alive_at_print"] is False
     if mode == "eval":
