@@ -1109,10 +1109,12 @@ def timed_train_steps(tr, pool, steps, warmup, world, dev):
     t0 = time.perf_counter()
     losses = []
     host = 0.0
+    cpu0 = time.process_time()
     for i in range(steps):
         h0 = time.perf_counter()
         losses.append(tr.train_step(*pool[i % len(pool)]))
         host += time.perf_counter() - h0
+    timed_train_steps.cpu_ms = (time.process_time() - cpu0) / steps * 1e3      # CPU time of ALL this process' threads while it enqueued
     device_sync(dev)
     local_dt = time.perf_counter() - t0
     barrier()
@@ -1224,8 +1226,12 @@ def main_train(args, world, rank, dev):
     # rank whose figure approaches its rank_ms_per_step is enqueue-bound, not communication-bound -- the eager step enqueues
     # ~450 launches from ONE host thread per rank, eight of them share the node's cores
     host_all = gather_rank_ms(host_ms * 1e-3 * args.steps, args.steps, world, dev)
+    cpu_all = gather_rank_ms(getattr(timed_train_steps, "cpu_ms", 0.0) * 1e-3 * args.steps, args.steps, world, dev)
     comm["host_enqueue_ms_per_step"] = {"max": round(max(host_all), 3), "all": [round(v, 3) for v in host_all],
-                                        "of_step": round(max(h / max(r, 1e-9) for h, r in zip(host_all, rank_ms)), 3)}
+                                        "of_step": round(max(h / max(r, 1e-9) for h, r in zip(host_all, rank_ms)), 3),
+                                        "cpu_ms_all": [round(v, 3) for v in cpu_all],
+                                        "note": "wall time inside train_step (includes waiting for room in the launch queue while the GPU "
+                                                "is the bottleneck); cpu_ms_all = process CPU time over the same calls, all threads"}
     if world > 1:
         # the process group ends HERE: what rank 0 measures below is rank-local, and the other ranks leave instead of spinning
         # in a barrier kernel on their GPUs for its whole duration
