@@ -964,6 +964,26 @@ def test_trajectory_envelope_is_the_reference_arithmetic_under_one_ulp():
                 assert dl <= 3 * float(g["env_loss"][step]) + 2e-6 and dn <= 3 * float(g["env_norm"][step]) + 2e-4, (step, dl, dn)
 
 
+def test_bench_cpu_leg_of_the_vgg16_baseline():
+    """bench.py's CPU leg for BASELINE.json configs[0] ("baseline model, VGG-16, 4 test episodes on CPU"): a child process times
+    the oracle's baseline_forward (networks/baseline.py:69-118 under entry/baseline.py:46-62) on seeds 5678.. after one warm-up
+    episode (5677), prints one JSON object with the legs' fields and the per-episode tp / fp / fn rows.  One episode here (the
+    bench runs four): what is checked is the plumbing, not a speed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="4", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-leg", "4", "--mode", "eval", "--model", "baseline", "--shot", "1",
+                        "--batch", "1", "--dataset", "PASCAL", "--cpu-episodes", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["threads"] == 4 and out["steps"] == 1 and out["value"] > 0
+    assert "baseline_forward, VGG-16" in out["sample"] and "seeds 5678..5678" in out["sample"]
+    rows = out["episodes"]
+    assert [e["seed"] for e in rows] == [5677, 5678] and all(np.isfinite(e["loss"]) and len(e["counts"]) == 6 for e in rows)
+
+
 def test_bench_counts_the_work_of_every_gemm_entry_point():
     """bench.py's live roofline adds up FLOPs per C-ABI entry point: an implicit-GEMM entry it does not know lands in class
     `other` with no work, and the step's TFLOP/s is quoted too low (round 4: the DropBlock-fused conv and the grouped launch
