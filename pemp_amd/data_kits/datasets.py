@@ -1,8 +1,11 @@
 """``data`` ingredient and label helpers with the reference's key surface (data_kits/datasets.py:13-31,83-117).
 
-There is no dataset on either box: the keys are accepted and carried so that a reference command line
-(``with data.test_n=1000 data.height=401 ...``) parses unchanged; the synthetic episode sources of
-``pemp_amd.entry`` read ``height / width / bs / test_bs / test_n / seed / test_seed / mean / std`` from here.
+There is no dataset on either box, so ``base_dir`` defaults to empty and the entry commands then run on the synthetic
+episode sources of ``pemp_amd.entry`` (which read ``height / width / bs / test_bs / test_n / seed / test_seed / mean / std``
+from here); a reference command line (``with data.test_n=1000 data.height=401 ...``) parses unchanged.  With
+``data.base_dir=<.../VOC2012>`` the commands read PASCAL-5i from disk with the reference's lists and task sampler
+(``pemp_amd.data_kits.pascal_voc``; the reference's config hook points base_dir at ``data/VOCdevkit/VOC2012`` itself,
+data_kits/datasets.py:34-50).
 """
 from ..config import Ingredient
 
@@ -12,7 +15,7 @@ data_ingredient = Ingredient("data", save_git_info=False)
 @data_ingredient.config
 def data_config():
     dataset = "PASCAL"              # str, dataset name [PASCAL, COCO]
-    base_dir = ""                   # str, data directory (unused: synthetic episodes)
+    base_dir = ""                   # str, dataset directory (PASCAL: .../VOCdevkit/VOC2012); empty: synthetic episodes
     mean = [0.485, 0.456, 0.406]    # list, normalization mean in data preprocessing
     std = [0.229, 0.224, 0.225]     # list, normalization std in data preprocessing
     height = 401                    # int, input image height

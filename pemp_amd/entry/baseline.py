@@ -4,7 +4,7 @@ stage 1; the model is ``pemp_amd.networks.baseline.Baseline`` (full-resolution m
 through the adjoint of the bilinear upsample)."""
 from ..config import Experiment
 from ..networks.baseline import ModelClass, net_ingredient  # noqa: F401
-from .pemp_stage1 import INGREDIENTS, Evaluator, SyntheticEpisodes, get_val_labels, num_classes  # noqa: F401
+from .pemp_stage1 import INGREDIENTS, Evaluator, SyntheticEpisodes, eval_episodes, get_val_labels, num_classes  # noqa: F401
 
 NAME = "Baseline"
 ex = Experiment(name=NAME, ingredients=[net_ingredient] + INGREDIENTS[1:])      # own ``net`` (backbone = vgg16) + data, tr, te, g, d
@@ -37,7 +37,7 @@ def test(_config, split, shot, exp_id, ckpt):
     model = model.cuda().eval()
     ev = Evaluator(model)
     d = _config["data"]
-    data = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"], d["dataset"])
+    data = eval_episodes(d, shot, split)
     loss, miou, biou = ev.start_eval_loop(data, num_classes(d["dataset"]), split, _config["te"]["epochs"], logger,
                                           batch=d["test_bs"], dataset_name=d["dataset"])
     return f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"

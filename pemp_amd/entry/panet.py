@@ -9,7 +9,7 @@ import torch.distributed as dist
 from .. import ops
 from ..config import Experiment
 from ..networks.panet import ModelClass, align_forward, net_ingredient  # noqa: F401
-from .pemp_stage1 import INGREDIENTS, SyntheticEpisodes, get_val_labels, num_classes  # noqa: F401
+from .pemp_stage1 import INGREDIENTS, SyntheticEpisodes, eval_episodes, get_val_labels, num_classes  # noqa: F401
 from .pemp_stage1 import Evaluator as _Evaluator
 
 NAME = "PEMP"
@@ -99,7 +99,7 @@ def test(_config, split, shot, exp_id, ckpt):
     model = model.cuda().eval()
     ev = Evaluator(model)
     d = _config["data"]
-    data = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"], d["dataset"])
+    data = eval_episodes(d, shot, split)
     (loss, aux), miou, biou = ev.start_eval_loop(data, num_classes(d["dataset"]), split, _config["te"]["epochs"],
                                                  logger, batch=d["test_bs"], dataset_name=d["dataset"])
     return f"Loss: {loss:.4f}, Aux loss: {aux:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"

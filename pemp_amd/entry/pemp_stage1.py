@@ -87,6 +87,38 @@ class SyntheticDecodedEpisodes(SyntheticEpisodes):
         return pairs[:self.shot], pairs[self.shot:], cls
 
 
+def eval_episodes(dcfg, shot, split, decoded=False):
+    """The evaluation episode source of a command.  ``data.base_dir`` set: the PASCAL-5i directory it names, read as the
+    reference reads it (data_kits/pascal_voc.py: class lists, deterministic task sampler; decoded uint8 episodes go through the
+    device-side preprocessing).  Empty (the default: there is no dataset on either box): synthetic ``E(seed)`` episodes."""
+    if dcfg.get("base_dir"):
+        from ..data_kits.pascal_voc import load
+        return load(dcfg, "test", split, shot, one_cls=dcfg.get("one_cls", 0))[0]
+    cls = SyntheticDecodedEpisodes if decoded else SyntheticEpisodes
+    return cls(dcfg["test_n"], dcfg["test_seed"], shot, split, dcfg["height"], dcfg["width"], dcfg["dataset"])
+
+
+def train_batches(dcfg, shot, split, rank, steps_per_epoch, device):
+    """-> ``batches(epoch)`` for ``TrainingLoop.start_training_loop``.  From ``data.base_dir`` when set: every epoch samples its
+    tasks with the reference's sampler (rank r of a data-parallel job seeds it with ``data.seed + r``: the reference has one
+    process), shuffles them, draws the augmentation on the host and preprocesses on the device, the next batch staged on a
+    side stream; synthetic batches otherwise."""
+    from .train_stage1 import device_batches, synthetic_batches
+    if not dcfg.get("base_dir"):
+        return lambda epoch: synthetic_batches(dcfg["bs"], shot, steps_per_epoch, dcfg["seed"] + 7919 * epoch, rank, dcfg["height"], dcfg["width"])
+    import random
+    from ..data_kits.episode import EpisodeLoader, EpisodeTransform
+    from ..data_kits.pascal_voc import load
+    ds = load(dict(dcfg, seed=dcfg["seed"] + rank), "train", split, shot, one_cls=dcfg.get("one_cls", 0))[0]
+    rng = random.Random(dcfg["seed"] * 7919 + rank)
+    tf = EpisodeTransform(dcfg["height"], dcfg["width"], mean=tuple(dcfg["mean"]), std=tuple(dcfg["std"]), device=device)
+
+    def batches(epoch):
+        ds.sample_tasks()
+        return device_batches(EpisodeLoader(ds.train_batches(dcfg["bs"], rng), tf), dcfg["bs"], shot, dcfg["height"], dcfg["width"])
+    return batches
+
+
 def shard_indices(n, rank, world):
     """Episode indices of one rank: every rank builds the same task list and takes tasks[rank::world]."""
     return range(rank, n, world)
@@ -332,7 +364,7 @@ def test(_config, split, shot, seed, exp_id, ckpt):
     load_for_eval(model, _config, exp_id, ckpt, logger)
     model = model.cuda().eval()
     dcfg = _config["data"]
-    data = SyntheticEpisodes(dcfg["test_n"], dcfg["test_seed"], shot, split, dcfg["height"], dcfg["width"], dcfg["dataset"])
+    data = eval_episodes(dcfg, shot, split)
     # the reference's protocol is one episode per step (data.test_bs = 1): keep it, with four steps in flight
     ev = Evaluator(model, lanes=4 if dcfg["test_bs"] == 1 else 1)
     nclass = num_classes(dcfg["dataset"])
@@ -349,7 +381,7 @@ def run_training(_config, name, make_trainer, make_evaluator, split, shot, seed,
     import logging
     import os
     from ..core.base_trainer import TrainingLoop
-    from .train_stage1 import broadcast_model, synthetic_batches
+    from .train_stage1 import broadcast_model
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     logger = logging.getLogger(name)
     if split < 0:
@@ -370,11 +402,8 @@ def run_training(_config, name, make_trainer, make_evaluator, split, shot, seed,
     if world > 1:
         dist.broadcast(run_id, 0)                             # rank 0 names the run
     loop = TrainingLoop(_config, trainer, make_evaluator(trainer, dev), logger, run_id=int(run_id.item()))
-    val = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"], d["dataset"])
-
-    def batches(epoch):
-        return synthetic_batches(d["bs"], shot, loop.steps_per_epoch, d["seed"] + 7919 * epoch, rank, d["height"], d["width"])
-
+    val = eval_episodes(d, shot, split)
+    batches = train_batches(d, shot, split, rank, loop.steps_per_epoch, dev)
     hist = loop.start_training_loop(batches, val, num_classes(d["dataset"]), split)
     return f"best val mIoU {loop.best_iou * 100:.2f} at epoch {loop.best_epoch}; checkpoints in {loop.model_dir}" if hist else "no epochs"
 
@@ -425,10 +454,11 @@ def evaluate_and_save(model, dataset, out_dir, n_episodes, device=None):
         cname = PASCAL_CLASSES[cls].replace("/", "_") if 0 <= cls < len(PASCAL_CLASSES) else str(cls)
         save = Path(out_dir) / f"{i:03d}_{cls:02d}"
         save.mkdir(parents=True, exist_ok=True)
-        data = {"acc": str(round(acc, 3)), "cls_id": int(cls), "cls_name": cname, "qry": f"q{i}"}
+        names = dataset.names(i) if hasattr(dataset, "names") else None        # a dataset on disk: the samples' own names
+        data = {"acc": str(round(acc, 3)), "cls_id": int(cls), "cls_name": cname, "qry": names[1][0] if names else f"q{i}"}
         for j, (im, lab) in enumerate(sup):
             key = "sup" if S == 1 else f"sup{j + 1}"
-            data[key] = f"s{i}_{j}"
+            data[key] = names[0][j] if names else f"s{i}_{j}"
             Image.fromarray(im).save(save / f"{cname}_sup_img_{data[key]}.jpg")
             Image.fromarray(lab).save(save / f"{cname}_sup_msk_{data[key]}.png")
         Image.fromarray(qry[0][0]).save(save / f"{cname}_qry_img_{data['qry']}.jpg")
@@ -451,7 +481,7 @@ def visualize(_config, split, shot, seed, tag, exp_id, ckpt):
     load_for_eval(model, _config, exp_id, ckpt)                  # entry/pemp_stage1.py:208-209
     model = model.cuda().eval()
     dcfg = _config["data"]
-    data = SyntheticDecodedEpisodes(dcfg["test_n"], dcfg["test_seed"], shot, split, dcfg["height"], dcfg["width"], dcfg["dataset"])
+    data = eval_episodes(dcfg, shot, split, decoded=True)
     out = f"http/static/{exp_id}_{dcfg['dataset'].lower()}_{shot}shot_{tag}_s{split}"
     accs = evaluate_and_save(model, data, out, dcfg["test_n"])
     return f"saved {len(accs)} episodes to {out}; mean Dice {np.mean(accs):.3f}"

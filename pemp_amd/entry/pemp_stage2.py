@@ -9,7 +9,7 @@ from ..core.metrics import Accumulator, FewShotMetric  # noqa: F401
 from ..networks.pemp_stage2 import ModelClass, PriorNet, net_ingredient  # noqa: F401
 from ..config import Experiment
 from .pemp_stage1 import Evaluator as _Stage1Evaluator
-from .pemp_stage1 import INGREDIENTS, SyntheticEpisodes, allreduce_round, get_val_labels, num_classes, shard_indices  # noqa: F401
+from .pemp_stage1 import INGREDIENTS, SyntheticEpisodes, eval_episodes, allreduce_round, get_val_labels, num_classes, shard_indices  # noqa: F401
 
 NAME = "PEMP_Stage2"
 ex = Experiment(name=NAME, ingredients=INGREDIENTS)
@@ -107,7 +107,7 @@ def test(_config, split, shot, seed, exp_id, ckpt, s1):
     load_for_eval(model, _config, exp_id, ckpt, logger, wgen_seed=4321)      # entry/pemp_stage2.py:176-177
     model = model.cuda().eval()
     d = _config["data"]
-    data = SyntheticEpisodes(d["test_n"], d["test_seed"], shot, split, d["height"], d["width"], d["dataset"])
+    data = eval_episodes(d, shot, split)
     ev = Evaluator(stage1, model)
     loss, miou, biou = ev.start_eval_loop(data, num_classes(d["dataset"]), split, _config["te"]["epochs"], logger,
                                           batch=d["test_bs"], dataset_name=d["dataset"])

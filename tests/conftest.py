@@ -23,7 +23,7 @@ _FILE_TIER = {
     "test_cedt_gpu.py": 0, "test_episode_io_gpu.py": 0, "test_regularisers_gpu.py": 0, "test_properties_gpu.py": 0,
     "test_bf16_variant_gpu.py": 0,
     "test_stage1_gpu.py": 2, "test_models_gpu.py": 2, "test_panet_gpu.py": 2, "test_eval_protocol_gpu.py": 2,
-    "test_autograd_bridge_gpu.py": 2, "test_grad_frozen_gpu.py": 3, "test_train_gpu.py": 3,
+    "test_autograd_bridge_gpu.py": 2, "test_dataset_gpu.py": 2, "test_grad_frozen_gpu.py": 3, "test_train_gpu.py": 3,
 }
 _TEST_TIER = {
     "test_optimizer_step_matches_torch_sgd": 0, "test_fused_adam_step_matches_torch_adam": 0,

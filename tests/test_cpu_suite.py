@@ -964,6 +964,65 @@ def test_trajectory_envelope_is_the_reference_arithmetic_under_one_ulp():
                 assert dl <= 3 * float(g["env_loss"][step]) + 2e-6 and dn <= 3 * float(g["env_norm"][step]) + 2e-4, (step, dl, dn)
 
 
+def _voc_cfg(root, **kw):
+    cfg = dict(dataset="PASCAL", base_dir=str(root), height=97, width=97, seed=1234, test_seed=5678, train_n=12, test_n=9, cache=True,
+               mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], bs=4, test_bs=1, one_cls=0)
+    cfg.update(kw)
+    return cfg
+
+
+def test_pascal_directory_dataset_follows_the_reference_sampler(tmp_path):
+    """pemp_amd.data_kits.pascal_voc.PascalVOCEpisodes on a tiny directory tree in the reference's layout: class sets
+    (data_kits/pascal_voc.py:114-116,270-272), the task sampler's call sequence (:118-135: RandomState(test_seed / seed),
+    choice(classes) then choice(n, size, replace=False) per task -- restated here from those lines), the reference's own golden
+    fact that does not need the real lists (split 0, test_seed 5678: the first class drawn is 5, data_kits/pascal_voc_test.py:59),
+    decoded uint8 episodes, one_cls, errors."""
+    from pemp_amd.data_kits import pascal_voc as pv
+    lists = util.make_tiny_voc(tmp_path)
+    ds, ncls = pv.load(_voc_cfg(tmp_path), "test", 0, 2)
+    assert ncls == 20 and ds.classes == [1, 2, 3, 4, 5] and len(ds) == 9 and not ds.train
+    ds.reset_sampler()
+    ds.sample_tasks()
+    rs = np.random.RandomState(5678)                       # the reference's statements, pascal_voc.py:124-131
+    want = []
+    for _ in range(9):
+        c = rs.choice([1, 2, 3, 4, 5])
+        idx = rs.choice(len(lists[("val", c)]), size=3, replace=False)
+        want.append((int(c), [lists[("val", c)][j] for j in idx]))
+    assert ds.tasks == want and ds.tasks[0][0] == 5
+    ds.reset_sampler()
+    ds.sample_tasks()
+    assert ds.tasks == want                                # reset_sampler: every evaluation round sees the same episodes
+    sup, qry, cls = ds.decoded_task(0)
+    assert cls == 5 and len(sup) == 2 and len(qry) == 1 and ds.names(0) == (want[0][1][:2], want[0][1][2:])
+    for img, lab in sup + qry:
+        assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3 and lab.dtype == np.uint8 and lab.shape == img.shape[:2]
+        assert set(np.unique(lab)) <= {0, 255}
+    assert ds.decoded_task(0)[0][0][0] is sup[0][0]        # data.cache: decoded once
+    tr, _ = pv.load(_voc_cfg(tmp_path), "train", 1, 1)
+    assert tr.classes == [c for c in range(1, 21) if not 6 <= c <= 10] and len(tr) == 12 and tr.train
+    tr.sample_tasks()
+    rs = np.random.RandomState(1234)
+    c0 = rs.choice(tr.classes)
+    assert tr.tasks[0][0] == int(c0) and tr.tasks[0][1] == [lists[("train", c0)][j] for j in rs.choice(len(lists[("train", c0)]), size=2, replace=False)]
+    one, _ = pv.load(_voc_cfg(tmp_path, one_cls=3), "test", 0, 1, one_cls=3)
+    one.sample_tasks()
+    assert {t[0] for t in one.tasks} == {3}
+    # training batches: shuffled tasks, the reference's augmentation draws per sample, short last batch dropped
+    import random
+    b1 = list(tr.train_batches(4, random.Random(7), shuffle=list(range(12))))
+    b2 = list(tr.train_batches(4, random.Random(7), shuffle=list(range(12))))
+    assert len(b1) == 3 and all(len(b) == 8 for b in b1)
+    assert [(s.scaled, s.crop, s.flip, s.mask_mode) for b in b1 for s in b] == [(s.scaled, s.crop, s.flip, s.mask_mode) for b in b2 for s in b]
+    assert all(97 <= s.scaled[0] <= 145 for s in b1[0][::2]) and all(s.scaled == (97, 97) for s in b1[0][1::2])
+    with pytest.raises(NotImplementedError, match="pycocotools"):
+        pv.load(_voc_cfg(tmp_path, dataset="COCO"), "test", 0, 1)
+    with pytest.raises(ValueError, match="training mode"):
+        pv.load(_voc_cfg(tmp_path), "train_canet", 0, 1)
+    with pytest.raises(FileNotFoundError, match="PASCAL is not found"):
+        pv.load(_voc_cfg(tmp_path / "nowhere"), "test", 0, 1)
+
+
 def test_bench_cpu_leg_of_the_vgg16_baseline():
     """bench.py's CPU leg for BASELINE.json configs[0] ("baseline model, VGG-16, 4 test episodes on CPU"): a child process times
     the oracle's baseline_forward (networks/baseline.py:69-118 under entry/baseline.py:46-62) on seeds 5678.. after one warm-up

@@ -1,0 +1,115 @@
+"""PASCAL-5i from a directory (pemp_amd.data_kits.pascal_voc: the reference's lists and task sampler, decoded uint8 episodes,
+device-side preprocessing) through the evaluator, the training loop and the command layer -- on a tiny tree in the reference's
+layout written by tests/util.make_tiny_voc (there is no dataset on either box).
+
+Parity statement: an evaluation round over the directory equals the CPU oracle on the SAME files -- Pillow decode, the integer
+restatement of the reference's evaluation transform (oracle/pil_ops.py; data_kits/pascal_voc.py:200-229), the reference forward
+(oracle/ref_cpu.py), FewShotMetric on the host: |d mIoU|, |d bIoU|, |d loss| <= 1e-4 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(root, **kw):
+    cfg = dict(dataset="PASCAL", base_dir=str(root), height=97, width=97, seed=1234, test_seed=5678, train_n=8, test_n=10, cache=True,
+               mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], bs=2, test_bs=1, one_cls=0)
+    cfg.update(kw)
+    return cfg
+
+
+@pytest.mark.parametrize("shot", [1, 2])
+def test_evaluation_round_from_a_directory_matches_the_oracle(hip_lib, dev, tmp_path, shot):
+    from oracle import pil_ops as P, ref_cpu
+    from pemp_amd.data_kits import pascal_voc as pv
+    from pemp_amd.data_kits.episode import MEAN, STD
+    from pemp_amd.entry import pemp_stage1 as e
+    from pemp_amd.networks import pemp_stage1 as m
+    util.make_tiny_voc(tmp_path, splits=("val",))
+    sd = util.wgen_state_dict("stage1_rn50")
+    net = m.ModelClass(None)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    ds, ncls = pv.load(_cfg(tmp_path), "test", 0, shot)
+    ev = e.Evaluator(net, dev)
+    loss, _, _ = ev.start_eval_loop(ds, ncls, 0, te_epochs=2)
+    miou_c, biou_c = ev.round_miou.mean(axis=0), ev.round_biou.mean(axis=0)     # per class (the loop's return value averages the classes too)
+    # the oracle on the same files: two rounds of the same ten tasks (reset_sampler once, sample_tasks per round)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    ds.reset_sampler()
+    miou, biou, losses = [], [], []
+    fwd = lambda a, b, c, hw: ref_cpu.stage1_forward(sd, a, b, c, hw)
+    for _ in range(2):
+        ds.sample_tasks()
+        metric, ls = ref_cpu.FewShotMetric(20), []
+        with torch.no_grad():
+            for i in range(len(ds)):
+                sup, qry, cls = ds.decoded_task(i)
+                sup_img = torch.stack([t(P.to_tensor_normalize(P.resize_bilinear(im, 97, 97), MEAN, STD)) for im, _ in sup])[None]
+                sup_msk = torch.stack([t(P.support_mask_planes(P.resize_nearest(lb, 97, 97))) for _, lb in sup])[None]
+                qry_img = t(P.to_tensor_normalize(P.resize_bilinear(qry[0][0], 97, 97), MEAN, STD))[None, None]
+                gt = t((qry[0][1] // 255).astype(np.int64))[None]              # the query label keeps its own size (:229)
+                pred, l, _ = ref_cpu.test_step(fwd, (sup_img, sup_msk, qry_img), gt)
+                metric.update(pred, gt.numpy(), [cls])
+                ls.append(l)
+        labels = e.get_val_labels(0)
+        miou.append(metric.miou(labels)[0])
+        biou.append(metric.miou(labels, binary=True)[0])
+        losses.append(np.mean(ls))
+    ref_miou, ref_biou = np.mean(miou, axis=0), np.mean(biou, axis=0)            # per class, mean over the rounds (Accumulator.mean)
+    print(f"shot {shot}: per-class IoU hip {np.round(miou_c, 5)} oracle {np.round(ref_miou, 5)}  bIoU {np.round(biou_c, 5)} / {np.round(ref_biou, 5)}  "
+          f"loss {loss:.6f} / {np.mean(losses):.6f}")
+    # (a validation class that draws no episode in one of the two ten-task rounds has no mean IoU on either side: NaN, as in the reference)
+    assert np.allclose(miou_c, ref_miou, rtol=0, atol=1e-4, equal_nan=True) and np.isfinite(miou_c).sum() >= 2
+    assert np.allclose(biou_c, ref_biou, rtol=0, atol=1e-4) and abs(loss - float(np.mean(losses))) <= 1e-4
+
+
+def test_commands_run_on_a_directory(hip_lib, dev, tmp_path):
+    """``train`` / ``test`` / ``visualize with data.base_dir=<tree>``: the training loop draws its tasks with the reference's
+    sampler every epoch (augmentation draws on the host, pixels on the device), evaluates on the directory's validation lists,
+    writes checkpoints; ``test`` evaluates them -- the same numbers as an evaluator fed the dataset object directly;
+    ``visualize`` names its files after the samples (core/base_trainer.py:311-403)."""
+    import json
+    from pemp_amd.data_kits import pascal_voc as pv
+    from pemp_amd.entry import pemp_stage1 as e
+    voc = tmp_path / "VOC2012"
+    util.make_tiny_voc(voc)
+    common = ["split=0", f"g.model_dir={tmp_path / 'runs'}", f"data.base_dir={voc}", "data.height=97", "data.width=97", "data.test_n=14",
+              "te.epochs=1", "data.test_bs=2"]        # 14 tasks: the first count at which the sampler has drawn all five validation classes
+
+    def run(*argv):
+        try:
+            return e.ex.run_commandline(["prog", *argv])
+        finally:
+            for ing in e.INGREDIENTS + [e.ex]:
+                ing._updates.clear()
+                ing._cfg = None
+
+    msg = run("train", "with", *common, "tr.total_epochs=2", "data.train_n=4", "data.bs=2")
+    d = tmp_path / "runs" / "pemp_stage1" / "1"
+    assert sorted(p.name for p in d.iterdir()) == ["bestckpt.pth", "ckpt.pth"] and "best val mIoU" in msg
+    out = run("test", "with", *common, "exp_id=1")
+    net = e.ModelClass(None)
+    net.load_weights(d / "bestckpt.pth", __import__("logging").getLogger("t"))
+    ds, _ = pv.load(_cfg(voc, test_n=14), "test", 0, 1)
+    loss, miou, biou = e.Evaluator(net.to(dev).eval(), device=dev).start_eval_loop(ds, 20, 0, te_epochs=1, batch=2)
+    assert out == f"Loss: {loss:.4f}, mIoU: {np.mean(miou) * 100:.2f}, bIoU: {np.mean(biou) * 100:.2f}"
+    # visualize: the viewer's layout, files named after the samples of the first tasks
+    import os
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        vis = run("visualize", "with", *[c for c in common if not c.startswith("data.test_n")], "data.test_n=2", "exp_id=1")
+    finally:
+        os.chdir(cwd)
+    assert vis.startswith("saved 2 episodes")
+    ds2, _ = pv.load(_cfg(voc, test_n=2), "test", 0, 1)
+    ds2.sample_tasks()
+    out_dir = tmp_path / "http" / "static" / "1_pascal_1shot_pemp_stage1_s0"
+    first = sorted(out_dir.iterdir())[0]
+    meta = json.loads((first / "data.json").read_text())
+    assert meta["sup"] == ds2.names(0)[0][0] and meta["qry"] == ds2.names(0)[1][0] and meta["cls_id"] == ds2.tasks[0][0]
+    assert any(p.name.endswith(f"_qry_pred_{meta['qry']}.png") for p in first.iterdir())

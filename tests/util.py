@@ -276,3 +276,34 @@ def check_gradients_live(hip, g32, g64, what, eps=3e-3):
     print(f"{what}: {len(rows)} tensors, relative L2 error vs float64: hip max {rows[0][0]:.2e} ({rows[0][2]}), "
           f"median {rows[len(rows) // 2][0]:.2e}; oracle float32 max {max(r[1] for r in rows):.2e}")
     return rows
+
+
+# ---------------------------------------------------------------------------------------------
+# a tiny PASCAL-5i directory tree (reference layout, data_kits/pascal_voc.py:103-107,262-264) written from synthetic pictures
+# ---------------------------------------------------------------------------------------------
+def make_tiny_voc(root, per_class=(4, 5, 6, 7), splits=("train", "val"), seed=0):
+    """<root>/JPEGImages/<name>.jpg, <root>/Binary_map_aug/{train,val}/<cls>.txt and .../<cls>/<name>.png for the 20 classes:
+    class c has per_class[c % len(per_class)] samples named like VOC's ("2007_00c0k"), pictures of four sizes from
+    pemp_amd.data_kits.synth_u8 (JPEG quality 95), 0 / 255 label images.  -> {(mode, cls): [names]}."""
+    from pathlib import Path
+    from PIL import Image
+    from pemp_amd.data_kits import synth_u8
+    root = Path(root)
+    (root / "JPEGImages").mkdir(parents=True, exist_ok=True)
+    sizes = ((120, 160), (150, 130), (133, 177), (160, 160))
+    lists = {}
+    for mode in splits:
+        d = root / "Binary_map_aug" / mode
+        d.mkdir(parents=True, exist_ok=True)
+        for c in range(1, 21):
+            names = [f"20{7 + (c + k) % 6:02d}_{'0' if mode == 'val' else '1'}{c:02d}{k:02d}" for k in range(per_class[c % len(per_class)])]
+            (d / f"{c}.txt").write_text("\n".join(names) + "\n")
+            (d / str(c)).mkdir(exist_ok=True)
+            for k, n in enumerate(names):
+                h, w = sizes[(c + k) % len(sizes)]
+                s = seed + 1000 * c + 10 * k + (1 if mode == "val" else 0)
+                if not (root / "JPEGImages" / f"{n}.jpg").exists():
+                    Image.fromarray(synth_u8.image(s, h, w)).save(root / "JPEGImages" / f"{n}.jpg", quality=95)
+                Image.fromarray(synth_u8.mask(s, h, w)).save(d / str(c) / f"{n}.png")
+            lists[(mode, c)] = names
+    return lists
