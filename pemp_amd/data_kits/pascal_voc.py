@@ -110,10 +110,6 @@ class PascalVOCEpisodes:
         cls, all_names = self.tasks[i]
         return self.pairs(cls, all_names[:self.shot]), self.pairs(cls, all_names[self.shot:]), cls
 
-    def episode(self, cls, sup_names, qry_names):
-        """``OneExampleLoader.load`` (pascal_voc.py:539-558): a chosen episode (``visualize with p.cls=.. p.sup=.. p.qry=..``)."""
-        return self.pairs(cls, list(sup_names)), self.pairs(cls, list(qry_names)), int(cls)
-
     def train_batches(self, bs, rng=None, shuffle=None):
         """One epoch of training batches as Sample lists for ``EpisodeLoader``: ``sample_tasks()`` must have been called.  The
         reference's DataLoader shuffles the task list (``shuffle=True``, pascal_voc.py:511-516) and draws the augmentation in
@@ -135,6 +131,36 @@ class PascalVOCEpisodes:
                         raise ValueError(f"image / label size mismatch in class {cls}: {img.shape[:2]} vs {lab.shape}")
                 samples += train_samples(p[:self.shot], p[self.shot:], self.height, self.width, rng)
             yield samples
+
+
+class OneExampleLoader(PascalVOCEpisodes):
+    """``OneExampleLoader`` of the reference (pascal_voc.py:533-558; ``visualize with p.cls=<id> p.sup=<name> p.qry=<name>``,
+    entry/pemp_stage1.py:198-201): ONE chosen episode of the validation directory, no sampler, no cache."""
+
+    def __init__(self, cfg, split, shot, query=1):
+        super().__init__(cfg, split, shot, query, train=False)
+        self.cache = False
+
+    def reset_sampler(self):
+        pass
+
+    def sample_tasks(self):
+        pass
+
+    def __len__(self):
+        return len(self.tasks)
+
+    def choose(self, cls, sup_names, qry_names):
+        def as_list(v):
+            v = [v] if isinstance(v, (str, int)) else list(v)
+            if not all(isinstance(n, str) for n in v):     # 2007_000032 unquoted is an int literal to Python (and to Sacred's parser)
+                raise ValueError(f"sample names must be strings, got {v}: quote them on the command line (p.sup='\"2007_000032\"')")
+            return v
+        sup_names, qry_names = as_list(sup_names), as_list(qry_names)
+        if len(sup_names) != self.shot or len(qry_names) != self.query:
+            raise ValueError(f"p.sup / p.qry: {self.shot} support and {self.query} query sample name(s) expected")
+        self.tasks = [(int(cls), sup_names + qry_names)]
+        return self
 
 
 def load(cfg, train_mode, split, shot, query=1, one_cls=0):

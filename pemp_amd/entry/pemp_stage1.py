@@ -470,7 +470,7 @@ def evaluate_and_save(model, dataset, out_dir, n_episodes, device=None):
 
 
 @ex.command
-def visualize(_config, split, shot, seed, tag, exp_id, ckpt):
+def visualize(_config, split, shot, seed, tag, exp_id, ckpt, p):
     """``python -m pemp_amd.entry.pemp_stage1 visualize with split=0 test_n=20``: predictions and response maps of
     the first ``test_n`` evaluation episodes into ``http/static/<exp>`` (the layout the reference's html viewer reads)."""
     if split < 0:
@@ -481,7 +481,14 @@ def visualize(_config, split, shot, seed, tag, exp_id, ckpt):
     load_for_eval(model, _config, exp_id, ckpt)                  # entry/pemp_stage1.py:208-209
     model = model.cuda().eval()
     dcfg = _config["data"]
-    data = eval_episodes(dcfg, shot, split, decoded=True)
+    if p["cls"] > 0:            # one chosen episode (entry/pemp_stage1.py:198-201): only a dataset on disk has named samples
+        if not dcfg.get("base_dir"):
+            raise ValueError("visualize with p.cls=.. p.sup=.. p.qry=.. needs data.base_dir (sample names belong to a dataset on disk)")
+        from ..data_kits.pascal_voc import OneExampleLoader
+        data = OneExampleLoader(dcfg, split, shot).choose(p["cls"], p["sup"], p["qry"])
+        dcfg = dict(dcfg, test_n=1)
+    else:
+        data = eval_episodes(dcfg, shot, split, decoded=True)
     out = f"http/static/{exp_id}_{dcfg['dataset'].lower()}_{shot}shot_{tag}_s{split}"
     accs = evaluate_and_save(model, data, out, dcfg["test_n"])
     return f"saved {len(accs)} episodes to {out}; mean Dice {np.mean(accs):.3f}"

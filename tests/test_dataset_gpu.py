@@ -113,3 +113,18 @@ def test_commands_run_on_a_directory(hip_lib, dev, tmp_path):
     meta = json.loads((first / "data.json").read_text())
     assert meta["sup"] == ds2.names(0)[0][0] and meta["qry"] == ds2.names(0)[1][0] and meta["cls_id"] == ds2.tasks[0][0]
     assert any(p.name.endswith(f"_qry_pred_{meta['qry']}.png") for p in first.iterdir())
+    # ... and ONE chosen episode (OneExampleLoader: p.cls / p.sup / p.qry, entry/pemp_stage1.py:198-201)
+    names = ds2.sample_by_class[2]
+    os.chdir(tmp_path)
+    try:
+        one = run("visualize", "with", *[c for c in common if not c.startswith("data.test_n")], "exp_id=1", "tag=one", "p.cls=2", f"p.sup='{names[0]}'",
+                  f"p.qry=['{names[1]}']")
+        with pytest.raises(ValueError, match="quote them"):             # 2009_00200 unquoted parses as the int 200900200
+            run("visualize", "with", *common, "exp_id=1", "p.cls=2", f"p.sup={names[0]}", f"p.qry='{names[1]}'")
+        with pytest.raises(ValueError, match="data.base_dir"):
+            run("visualize", "with", "split=0", f"g.model_dir={tmp_path / 'runs'}", "data.height=97", "data.width=97", "exp_id=1", "p.cls=2", "p.sup=a", "p.qry=b")
+    finally:
+        os.chdir(cwd)
+    assert one.startswith("saved 1 episodes")
+    meta = json.loads((tmp_path / "http" / "static" / "1_pascal_1shot_one_s0" / "000_02" / "data.json").read_text())
+    assert meta["sup"] == names[0] and meta["qry"] == names[1] and meta["cls_id"] == 2 and meta["cls_name"] == "bicycle"
