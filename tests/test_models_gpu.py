@@ -105,7 +105,8 @@ def test_stage2_matches_reference_golden(hip_lib, dev, fixture):
     g = util.gold(fixture)
     shot, H = int(g["shot"]), int(g["H"])
     net = m.PEMPStage2(shot, 1, None)
-    net.load_state_dict(util.wgen_state_dict("stage2_rn50cm", seed=4321))
+    sd2 = util.wgen_state_dict("stage2_rn50cm", seed=4321)
+    net.load_state_dict(sd2)
     net = net.to(dev).eval()
     for e, seed in enumerate(g["seeds"]):
         hw = tuple(int(v) for v in g[f"e{e}_out_hw"])
@@ -117,8 +118,10 @@ def test_stage2_matches_reference_golden(hip_lib, dev, fixture):
         ap = net.adaptive_p.cpu()
         ref = torch.from_numpy(g[f"e{e}_adaptive_p"])
         assert ((ap - ref).abs() / (1 + ref.abs())).max().item() < 2e-3
-        _, margin = util.response_reference(net._last_feats, t["sup_mask"], net.ctr, 1, shot, 3, 20, hw)
-        util.assert_response_exact(resp[0, ::7, ::7], g[f"e{e}_resp_s7"], margin[0, ::7, ::7], what=fixture)
+        # margins from the ORACLE's features (its share of sampled pixels inside the margin: <= 0.0139)
+        _, margin = util.response_reference(util.oracle_stage2_feats(sd2, t["sup_img"], t["sup_mask"], t["qry_img"], prior), t["sup_mask"], sd2["ctr"],
+                                            1, shot, 3, 20, hw)
+        util.assert_response_exact(resp[0, ::7, ::7], g[f"e{e}_resp_s7"], margin[0, ::7, ::7], what=fixture, max_masked=0.03)
 
 
 @pytest.mark.parametrize("fixture", ["stage2_vgg16cm_small", "stage2_vgg16cm_small5"])
@@ -130,7 +133,8 @@ def test_stage2_vgg16cm_matches_reference_golden(hip_lib, dev, fixture):
     g = util.gold(fixture)
     shot, H = int(g["shot"]), int(g["H"])
     net = m.PEMPStage2(shot, 1, None, backbone2="vgg16")
-    net.load_state_dict(util.wgen_state_dict("stage2_vgg16cm", seed=4321))
+    sd2 = util.wgen_state_dict("stage2_vgg16cm", seed=4321)
+    net.load_state_dict(sd2)
     net = net.to(dev).eval()
     for e, seed in enumerate(g["seeds"]):
         hw = tuple(int(v) for v in g[f"e{e}_out_hw"])
@@ -144,8 +148,10 @@ def test_stage2_vgg16cm_matches_reference_golden(hip_lib, dev, fixture):
         ap = net.adaptive_p.cpu()
         ref = torch.from_numpy(g[f"e{e}_adaptive_p"])
         assert ((ap - ref).abs() / (1 + ref.abs())).max().item() < 2e-3
-        _, margin = util.response_reference(net._last_feats, t["sup_mask"], net.ctr, 1, shot, 3, 20, hw)
-        util.assert_response_exact(resp[0, ::7, ::7], g[f"e{e}_resp_s7"], margin[0, ::7, ::7], what=fixture)
+        # margins from the ORACLE's features (its share of sampled pixels inside the margin: 0.0602 on small/e0, <= 0.0077 elsewhere)
+        _, margin = util.response_reference(util.oracle_stage2_feats(sd2, t["sup_img"], t["sup_mask"], t["qry_img"], prior, "vgg16"), t["sup_mask"],
+                                            sd2["ctr"], 1, shot, 3, 20, hw)
+        util.assert_response_exact(resp[0, ::7, ::7], g[f"e{e}_resp_s7"], margin[0, ::7, ::7], what=fixture, max_masked=0.08)
         assert torch.equal(again, again2)                      # hipGraph replay of the VGG16CM engine is stable
 
 

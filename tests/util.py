@@ -194,6 +194,18 @@ def oracle_stage1_feats(sd, sup_img, qry_img, backbone="resnet50"):
     return torch.cat((f[:, :S].flatten(0, 1), f[:, S:].flatten(0, 1))).permute(0, 2, 3, 1).contiguous()
 
 
+def oracle_stage2_feats(sd, sup_img, sup_mask, qry_img, qry_prior, backbone2="resnet50"):
+    """As ``oracle_stage1_feats`` for PEMPStage2's encoder (images + prior channel, communication modules)."""
+    from oracle import ref_cpu
+    sup_img, sup_mask, qry_img, qry_prior = (t.detach().cpu() for t in (sup_img, sup_mask, qry_img, qry_prior))
+    B, S = sup_img.shape[:2]
+    Q = qry_img.shape[1]
+    with torch.no_grad():
+        f = ref_cpu.encoder_stage2(sd, sup_img, sup_mask, qry_img, qry_prior, backbone2)
+    f = f.view(B, S + Q, *f.shape[1:])
+    return torch.cat((f[:, :S].flatten(0, 1), f[:, S:].flatten(0, 1))).permute(0, 2, 3, 1).contiguous()
+
+
 def assert_response_exact(resp_got, resp_ref, margin_map, margin=MARGIN, what="", max_masked=0.12):
     """Exact agreement of the response index wherever its decision margin exceeds ``margin``.  Returns the masked
     fraction (coinciding meta-prototypes -- centres that attract no pixel pool to the same vector -- give exact ties
