@@ -193,10 +193,14 @@ class Evaluator:
 
     def test_step_device(self, inputs, qry_msk):
         """-> (argmax uint8 [B,Ho,Wo], stats f64 [B,8]) both on the GPU, no host synchronisation."""
-        dev_in = [x.to(self.device, non_blocking=True) for x in inputs]
         tgt = qry_msk.view(-1, *qry_msk.shape[-2:]).to(self.device, non_blocking=True)
         with torch.no_grad():
-            pred = self._lowres(dev_in)
+            if self.use_graph and type(self)._lowres is Evaluator._lowres and not any(x.is_cuda for x in inputs):
+                # host tensors (the reference's test_step body): straight into the graph's static input buffers
+                with ops.eval_splitk(ops.EVAL_SPLITK if self.splitk is None else self.splitk):
+                    pred = self.model.lowres_graphed(*inputs, device=self.device)[0]
+            else:
+                pred = self._lowres([x.to(self.device, non_blocking=True) for x in inputs])
             am, stats, _ = ops.eval_tail(pred, tgt, ws_cache=self._ws)
         return am, stats
 

@@ -154,25 +154,32 @@ class _HeadMixin:
         self.__dict__["_last_protos"] = pro
         return ops.cosine_proto_max(qry, pro, dist_scalar, want_resp=ret_ind)
 
-    def lowres_graphed(self, *inputs, ret_ind=False):
+    def lowres_graphed(self, *inputs, ret_ind=False, device=None):
         """``lowres`` replayed from a captured hipGraph (one per input signature).
 
         The ~80 launches of one episode are short (tens of µs), so eager issue is bound by the
         host (ctypes + launch ≈ 5-10 µs each); the graph removes that.  Inputs are copied into
         static buffers; the returned tensors are the graph's static outputs and are overwritten
-        by the next call with the same signature.
+        by the next call with the same signature.  ``device``: HOST tensors are accepted and go
+        straight into the static buffers on that device (one H2D copy each -- the reference's
+        ``test_step`` body hands over host tensors, entry/pemp_stage1.py:48-49 -- instead of a
+        fresh device tensor plus a device-to-device copy); the compute still has no CPU path.
         """
-        self._require_eval_gpu(self, *inputs)
-        eng = self._engine_for(inputs[0].device)
+        if device is None or any(t.is_cuda for t in inputs):
+            self._require_eval_gpu(self, *inputs)
+            device = inputs[0].device
+        elif self.training:
+            self._require_eval_gpu(self)
+        eng = self._engine_for(torch.device(device))
         key = tuple((tuple(t.shape), t.dtype) for t in inputs) + (ret_ind, ops.EVAL_SPLITK)    # the conv variants are baked in
         # (the bf16 variant has its own engine, hence its own graphs)
         graphs = eng.setdefault("graphs", {})
         entry = graphs.get(key)
         if entry is None:
-            static_in = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in inputs]
+            static_in = [torch.empty(t.shape, dtype=t.dtype, device=device) for t in inputs]
             for s, t in zip(static_in, inputs):
                 s.copy_(t)
-            side = torch.cuda.Stream(device=inputs[0].device)
+            side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(2):                       # warm-up: populates arena + workspaces

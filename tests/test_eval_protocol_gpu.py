@@ -194,3 +194,22 @@ def test_one_episode_step_with_split_k_matches_the_batched_step(hip_lib, dev, mo
             st1 = st1.cpu().numpy()[0]
             assert abs(st1[0] / st1[1] - st8[i, 0] / st8[i, 1]) <= 1e-5
             assert np.abs(st1[2:] - st8[i, 2:]).max() <= 1e-3 * lab[i].numel()
+
+
+def test_reference_test_step_body_takes_host_tensors(hip_lib, dev):
+    """``Evaluator.test_step`` as the reference calls it (entry/pemp_stage1.py:48-53: host tensors in, numpy prediction and a float
+    loss out): host inputs go straight into the hipGraph's static input buffers (one H2D copy each) -- same prediction and loss,
+    bit for bit, as the same episode handed over on the device, pageable or pinned."""
+    from pemp_amd.entry import pemp_stage1 as e
+    net = e.ModelClass(None)
+    net.load_state_dict(util.wgen_state_dict("stage1_rn50"))
+    net = net.to(dev).eval()
+    ev = e.Evaluator(net, device=dev)
+    for seed in (3, 4):
+        t = util.episode_tensors(seed, 1, 97, (80, 120))
+        host = (t["sup_img"], t["sup_mask"], t["qry_img"])
+        p0, l0 = ev.test_step(tuple(x.to(dev) for x in host), t["qry_mask"].to(dev))
+        p1, l1 = ev.test_step(host, t["qry_mask"])
+        p2, l2 = ev.test_step(tuple(x.pin_memory() for x in host), t["qry_mask"])
+        assert isinstance(p1, np.ndarray) and p1.shape == (1, 80, 120) and isinstance(l1, float)
+        assert np.array_equal(p0, p1) and np.array_equal(p0, p2) and l0 == l1 == l2
