@@ -259,9 +259,18 @@ class Evaluator:
     def test_step(self, inputs, qry_msk, **kwargs):
         """Reference contract (entry/pemp_stage1.py:48-53): -> (qry_pred numpy [B,H,W], loss float)."""
         am, stats = self.test_step_device(inputs, qry_msk)
-        st = stats.cpu().numpy()
+        # both results through pinned buffers, ONE host synchronisation (the reference's body has two: loss.item(), .cpu())
+        key = ("host", tuple(am.shape), tuple(stats.shape))
+        host = self.__dict__.setdefault("_host_bufs", {})
+        bufs = host.get(key)
+        if bufs is None:
+            bufs = host[key] = (torch.empty(am.shape, dtype=am.dtype, pin_memory=True), torch.empty(stats.shape, dtype=stats.dtype, pin_memory=True))
+        bufs[0].copy_(am, non_blocking=True)
+        bufs[1].copy_(stats, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        st = bufs[1].numpy()
         loss = float(st[:, 0].sum() / max(st[:, 1].sum(), 1.0))
-        return am.cpu().numpy(), loss
+        return bufs[0].numpy().copy(), loss
 
     def _episodes(self, dataset, indices):
         """(inputs, qry_msk, cls) per episode.  Datasets with ``decoded_task`` (uint8 sources) go through the
