@@ -1158,8 +1158,7 @@ def train_end_to_end(tr, dev, B=4, S=1, steps=10, warmup=3):
             yield batch
 
     loader = EpisodeLoader(batches(), EpisodeTransform(401, 401, device=dev))
-    losses, per_ep = [], None
-    t0 = None
+    losses, t0 = [], None
     for i, (img, planes, labels) in enumerate(loader):
         if i == warmup:
             torch.cuda.synchronize()
@@ -1637,6 +1636,8 @@ def main():
         if args.model == "stage1" and isinstance(out["cpu_baseline"], dict) and "episodes" in out["cpu_baseline"]:
             rows = {"episodes": out["cpu_baseline"].pop("episodes")}
             guarded("miou", lambda: miou_vs_cpu(net, dev, rows))
+        elif isinstance(out.get("cpu_baseline"), dict):
+            out["cpu_baseline"].pop("episodes", None)          # per-episode rows: only the stage-1 line compares them (`miou`)
     # the other BASELINE.json configurations, measured in this process so that they sit under the driver's clock too
     if headline and args.dataset == "COCO" and args.shot == 1 and args.bf16_side:
         guarded("bf16_variant", lambda: bf16_variant(run, dev, args))       # the COCO-shaped round's delta mIoU
